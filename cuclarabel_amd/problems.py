@@ -1,0 +1,209 @@
+"""Synthetic (P, q, A, b, cones) generators for the five BASELINE.json configurations,
+exactly as SURVEY.md section 8(d) specifies them (numpy `default_rng(1000 + cfg [+ j])`).
+
+These are workload generators for tests and bench.py -- host-side numpy/scipy, not part of
+the solver path.  Each returns a `Problem` with P as upper-triangular CSC, A as CSC, the
+cone list, and a reproducible strictly-interior iterate (s0, z0) from which the KKT values
+for timing are taken (so the benchmark needs no IPM loop).
+"""
+from dataclasses import dataclass, field
+import numpy as np
+import scipy.sparse as sp
+
+from .cones import (ZeroConeT, NonnegativeConeT, SecondOrderConeT, PSDTriangleConeT,
+                    total_numel)
+
+
+@dataclass
+class Problem:
+    name: str
+    P: sp.csc_matrix          # n x n, upper triangle only
+    q: np.ndarray
+    A: sp.csc_matrix          # m x n
+    b: np.ndarray
+    cones: list
+    s0: np.ndarray
+    z0: np.ndarray
+    x0: np.ndarray
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n(self):
+        return self.P.shape[0]
+
+    @property
+    def m(self):
+        return self.A.shape[0]
+
+
+def _triu_csc(P):
+    P = sp.triu(sp.csc_matrix(P), format="csc")
+    P.sort_indices()
+    P.sum_duplicates()
+    return P
+
+
+def _csc(A):
+    A = sp.csc_matrix(A)
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def interior_point(cones, rng):
+    """Strictly interior point per cone: NN |N(0,1)|+0.1; SOC [||t||+1; t]; PSD svec(GG'+I);
+    zero cone rows get 0 (they carry no scaling)."""
+    out = np.zeros(total_numel(cones))
+    off = 0
+    for c in cones:
+        k = c.numel
+        if isinstance(c, NonnegativeConeT):
+            out[off:off + k] = np.abs(rng.standard_normal(k)) + 0.1
+        elif isinstance(c, SecondOrderConeT):
+            t = rng.standard_normal(k - 1)
+            out[off] = np.linalg.norm(t) + 1.0
+            out[off + 1:off + k] = t
+        elif isinstance(c, PSDTriangleConeT):
+            d = c.dim
+            G = rng.standard_normal((d, d))
+            M = G @ G.T + np.eye(d)
+            out[off:off + k] = mat_to_svec(M)
+        off += k
+    return out
+
+
+def mat_to_svec(M):
+    """Column-major upper triangle, off-diagonals scaled by sqrt(2)
+    (`coneops_psdtrianglecone.jl:486-497`)."""
+    d = M.shape[0]
+    out = np.empty(d * (d + 1) // 2)
+    idx = 0
+    for col in range(d):
+        for row in range(col + 1):
+            out[idx] = M[row, col] if row == col else (M[row, col] + M[col, row]) / np.sqrt(2.0)
+            idx += 1
+    return out
+
+
+def svec_to_mat(x, d):
+    M = np.zeros((d, d))
+    idx = 0
+    for col in range(d):
+        for row in range(col + 1):
+            if row == col:
+                M[row, col] = x[idx]
+            else:
+                M[row, col] = M[col, row] = x[idx] / np.sqrt(2.0)
+            idx += 1
+    return M
+
+
+def _finish(name, P, A, cones, rng, q=None, b=None, meta=None, seed=None):
+    n, m = P.shape[0], A.shape[0]
+    x0 = rng.standard_normal(n)
+    s0 = interior_point(cones, rng)
+    if b is None:
+        b = A @ x0 + s0
+    if q is None:
+        q = rng.standard_normal(n)
+    zrng = np.random.default_rng((seed if seed is not None else 0) + 7_000_000)
+    z0 = interior_point(cones, zrng)
+    return Problem(name, _triu_csc(P), q, _csc(A), np.asarray(b, dtype=float), cones,
+                   s0, z0, x0, meta or {})
+
+
+def _local_window_A(m, n, nnz_per_row, rng, halfwidth=50, long_range_frac=0.0):
+    rows = np.repeat(np.arange(m), nnz_per_row)
+    home = (np.arange(m) * n) // m
+    cols = np.repeat(home, nnz_per_row) + rng.integers(-halfwidth, halfwidth + 1, size=m * nnz_per_row)
+    cols = np.clip(cols, 0, n - 1)
+    if long_range_frac > 0:
+        sel = rng.random(cols.shape[0]) < long_range_frac
+        cols[sel] = rng.integers(0, n, size=int(sel.sum()))
+    vals = rng.standard_normal(m * nnz_per_row)
+    return sp.coo_matrix((vals, (rows, cols)), shape=(m, n))
+
+
+def config1(seed=1001, n=500, m=1000, density=0.01):
+    """cfg1: small random QP, NN(m); P = B'B + 0.01 I, B = sprandn(n,n,0.01); A = sprandn(m,n,0.01)."""
+    rng = np.random.default_rng(seed)
+    B = sp.random(n, n, density=density, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    P = (B.T @ B + 0.01 * sp.identity(n)).tocsc()
+    A = sp.random(m, n, density=density, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    cones = [NonnegativeConeT(m)]
+    return _finish("cfg1_qp", P, A, cones, rng, seed=seed)
+
+
+def config2(seed=1002, n=100_000, soc_dim=100, long_range_frac=0.0, halfwidth=50):
+    """cfg2: SOCP, m = 2n = NN(n) + (n/soc_dim) x SOC(soc_dim); P = diag(U(0.1,1));
+    A has 4 nnz/row at columns home(i) + U{-50..50}."""
+    rng = np.random.default_rng(seed)
+    m = 2 * n
+    nsoc = n // soc_dim
+    P = sp.diags(rng.uniform(0.1, 1.0, size=n)).tocsc()
+    A = _local_window_A(m, n, 4, rng, halfwidth=halfwidth, long_range_frac=long_range_frac)
+    cones = [NonnegativeConeT(n)] + [SecondOrderConeT(soc_dim) for _ in range(nsoc)]
+    return _finish(f"cfg2_socp_n{n}", P, A, cones, rng, seed=seed,
+                   meta={"long_range_frac": long_range_frac})
+
+
+def config3(seed=1003, nblocks=100, blk=500):
+    """cfg3: portfolio-style QP, P = blockdiag of dense PSD blocks GG'/blk + 0.1 I;
+    A = [1'; -I], b = [1; 0], cones Zero(1) + NN(n)."""
+    rng = np.random.default_rng(seed)
+    n = nblocks * blk
+    blocks = []
+    for _ in range(nblocks):
+        G = rng.standard_normal((blk, blk))
+        blocks.append(sp.csc_matrix(np.triu(G @ G.T / blk + 0.1 * np.eye(blk))))
+    P = sp.block_diag(blocks, format="csc")
+    A = sp.vstack([sp.csc_matrix(np.ones((1, n))), -sp.identity(n, format="csc")], format="csc")
+    b = np.concatenate([[1.0], np.zeros(n)])
+    cones = [ZeroConeT(1), NonnegativeConeT(n)]
+    return _finish(f"cfg3_portfolio_n{n}", P, A, cones, rng, b=b, seed=seed)
+
+
+def config4(j=0, seed=1004, n=10_000):
+    """cfg4: element j of the batch of independent SOCPs (cfg2's generator at n=10k)."""
+    pb = config2(seed=seed + j, n=n)
+    pb.name = f"cfg4_socp_n{n}_j{j}"
+    return pb
+
+
+def config5(seed=1005, n=5000, npsd=200, psd_dim=20, nsoc=100, soc_dim=50):
+    """cfg5: SDP, 200 x PSD(20) + 100 x SOC(50); A 3 nnz/row local window; P = 1e-3 I."""
+    rng = np.random.default_rng(seed)
+    cones = [PSDTriangleConeT(psd_dim) for _ in range(npsd)] + \
+            [SecondOrderConeT(soc_dim) for _ in range(nsoc)]
+    m = total_numel(cones)
+    P = (1e-3 * sp.identity(n)).tocsc()
+    A = _local_window_A(m, n, 3, rng)
+    return _finish(f"cfg5_sdp_n{n}", P, A, cones, rng, seed=seed)
+
+
+def config_unstructured(seed=1012, n=10_000):
+    """Fully unstructured stress variant of cfg2 at n=10k only."""
+    rng = np.random.default_rng(seed)
+    m = 2 * n
+    P = sp.diags(rng.uniform(0.1, 1.0, size=n)).tocsc()
+    rows = np.repeat(np.arange(m), 4)
+    cols = rng.integers(0, n, size=4 * m)
+    A = sp.coo_matrix((rng.standard_normal(4 * m), (rows, cols)), shape=(m, n))
+    cones = [NonnegativeConeT(n)] + [SecondOrderConeT(100) for _ in range(n // 100)]
+    return _finish(f"cfg2u_socp_n{n}", P, A, cones, rng, seed=seed)
+
+
+def small_mixed(seed=7, n=40, nn=30, socs=(3, 4, 5, 12), psds=(2, 3, 4), zero=3, density=0.15):
+    """Small problem touching every cone kind and both SOC forms -- the parity workhorse."""
+    rng = np.random.default_rng(seed)
+    cones = []
+    if zero:
+        cones.append(ZeroConeT(zero))
+    cones.append(NonnegativeConeT(nn))
+    cones += [SecondOrderConeT(d) for d in socs]
+    cones += [PSDTriangleConeT(d) for d in psds]
+    m = total_numel(cones)
+    B = sp.random(n, n, density=density, random_state=rng, data_rvs=rng.standard_normal)
+    P = (B.T @ B).tocsc()
+    A = sp.random(m, n, density=density, random_state=rng, data_rvs=rng.standard_normal).tocsc()
+    return _finish(f"mixed_n{n}", P, A, cones, rng, seed=seed)
