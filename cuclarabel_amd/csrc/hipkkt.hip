@@ -1,0 +1,1064 @@
+// libhipkkt.so: the C ABI of include/hipkkt.h over the symbolic analysis (symbolic.cpp), the KKT
+// assembly (kkt_assembly.cpp) and the device kernels (kernels.hip).
+#include "../../include/hipkkt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "kkt_assembly.hpp"
+#include "symbolic.hpp"
+
+namespace hipkkt {
+
+static thread_local std::string g_last_error;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t count)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        HIP_CHECK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+    }
+    void zero(hipStream_t st) { HIP_CHECK(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), st)); }
+    template <class V>
+    void upload(const std::vector<V>& v)
+    {
+        static_assert(sizeof(V) == sizeof(T), "element size mismatch");
+        alloc(v.size());
+        if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+struct Launch {
+    int begin, count, bs;
+    size_t lds_factor, lds_solve;
+    int nbk;
+};
+
+static constexpr size_t kLdsCap = 160 * 1024 - 512;
+
+// ------------------------------------------------------------------------------------
+//  The numeric engine shared by both API levels
+// ------------------------------------------------------------------------------------
+class LDLEngine {
+public:
+    Symbolic S;
+    hipStream_t stream = nullptr;
+    double dyn_eps, dyn_delta;
+
+    LDLEngine(int N, const int64_t* colptr, const int64_t* rowval, int base, const std::vector<int>& dsigns,
+              const hipkkt_settings& st)
+    {
+        SymbolicOptions opt;
+        opt.ordering = st.ordering;
+        opt.amd_dense_scale = st.amd_dense_scale > 0 ? st.amd_dense_scale : 1.5;
+        if (st.nd_leaf_size > 0) opt.nd_leaf_size = st.nd_leaf_size;
+        opt.user_perm = st.user_perm;
+        // user_perm arrives in the caller's index base; analyse() applies `base` to it
+        analyse(N, colptr, rowval, base, opt, S);
+        dyn_eps = st.dynamic_regularization_eps;
+        dyn_delta = st.dynamic_regularization_delta;
+        build_schedule();
+        upload(dsigns);
+    }
+
+    void factor(const double* d_Kval, const double* d_eps)
+    {
+        flags.zero(stream);
+        FactorArgs a;
+        a.T = tree();
+        a.Kval = d_Kval;
+        a.eps = d_eps;
+        a.fronts = fronts.p;
+        a.upd = upd.p;
+        a.Dinv = Dinv.p;
+        a.flags = flags.p;
+        a.dyn_eps = dyn_eps;
+        a.dyn_delta = dyn_delta;
+        for (const Launch& L : launches) {
+            a.nbk = L.nbk;
+            launch_factor(a, L.begin, L.count, L.bs, L.lds_factor, stream);
+        }
+        HIP_CHECK(hipGetLastError());
+    }
+
+    // d_b, d_x in the caller's (original) ordering; may alias
+    void solve(const double* d_b, double* d_x)
+    {
+        SolveArgs a;
+        a.T = tree();
+        a.fronts = fronts.p;
+        a.Dinv = Dinv.p;
+        a.b = d_b;
+        a.out = d_x;
+        a.xp = xp.p;
+        a.uvec = uvec.p;
+        for (const Launch& L : launches) launch_fwd(a, L.begin, L.count, L.bs, L.lds_solve, stream);
+        for (auto it = launches.rbegin(); it != launches.rend(); ++it)
+            launch_bwd(a, it->begin, it->count, it->bs, it->lds_solve, stream);
+        HIP_CHECK(hipGetLastError());
+    }
+
+    // synchronises: {#dynamic regularisations, non-finite flag}
+    void read_flags(int out[2])
+    {
+        HIP_CHECK(hipMemcpyAsync(out, flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+
+    int* flags_ptr() { return flags.p; }
+
+private:
+    DBuf<int> d_sn_start, d_rows, d_rel, d_ncolpar, d_child_ptr, d_child_idx, d_ksrc, d_kdst, d_sched, d_perm;
+    DBuf<int64_t> d_rowptr, d_front_off, d_upd_off, d_kptr;
+    DBuf<signed char> d_psign;
+    DBuf<double> fronts, upd, Dinv, xp, uvec;
+    DBuf<int> flags;
+    std::vector<Launch> launches;
+    std::vector<int> sched;
+
+    TreeDev tree() const
+    {
+        TreeDev t;
+        t.sn_start = d_sn_start.p; t.rowptr = d_rowptr.p; t.rows = d_rows.p; t.rel = d_rel.p;
+        t.ncolpar = d_ncolpar.p; t.front_off = d_front_off.p; t.upd_off = d_upd_off.p;
+        t.child_ptr = d_child_ptr.p; t.child_idx = d_child_idx.p; t.kptr = d_kptr.p;
+        t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
+        return t;
+    }
+
+    int front_size(int s) const
+    {
+        return (S.sn_start[s + 1] - S.sn_start[s]) + (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    }
+
+    void build_schedule()
+    {
+        sched.clear();
+        launches.clear();
+        for (const Level& lv : S.levels) {
+            std::vector<int> small, big;
+            for (int t = lv.begin; t < lv.end; ++t) {
+                int s = S.level_sn[t];
+                (front_size(s) <= 64 ? small : big).push_back(s);
+            }
+            auto work = [&](int s) { return (double)front_size(s) * (S.sn_start[s + 1] - S.sn_start[s]); };
+            auto by_work = [&](int a, int b) { double wa = work(a), wb = work(b); return wa != wb ? wa > wb : a < b; };
+            std::sort(small.begin(), small.end(), by_work);
+            std::sort(big.begin(), big.end(), by_work);
+            for (int cls = 0; cls < 2; ++cls) {
+                const std::vector<int>& v = cls == 0 ? big : small;
+                if (v.empty()) continue;
+                Launch L;
+                L.begin = (int)sched.size();
+                L.count = (int)v.size();
+                L.bs = cls == 0 ? 256 : 64;
+                int fmax = 0;
+                for (int s : v) fmax = std::max(fmax, front_size(s));
+                size_t ldB = (size_t)((fmax + 7) & ~3);
+                int nbk = kMaxNbk;
+                while (nbk > 1 && (2 * kMaxNbk + ldB * nbk) * sizeof(double) > kLdsCap) --nbk;
+                if ((2 * kMaxNbk + ldB * nbk) * sizeof(double) > kLdsCap)
+                    throw std::runtime_error("front too large for the single-workgroup factor kernel");
+                L.nbk = nbk;
+                L.lds_factor = (2 * kMaxNbk + ldB * nbk) * sizeof(double);
+                L.lds_solve = ((size_t)((fmax + 1) & ~1) + kTriBlock * (kTriBlock + 1)) * sizeof(double);
+                if (L.lds_solve > kLdsCap) throw std::runtime_error("front too large for the solve kernels");
+                launches.push_back(L);
+                sched.insert(sched.end(), v.begin(), v.end());
+            }
+        }
+    }
+
+    void upload(const std::vector<int>& dsigns)
+    {
+        d_sn_start.upload(S.sn_start);
+        d_rowptr.upload(S.rowptr);
+        d_rows.upload(S.rows);
+        d_rel.upload(S.rel);
+        std::vector<int> ncolpar(S.nsuper, 0);
+        for (int s = 0; s < S.nsuper; ++s) {
+            int p = S.sn_parent[s];
+            if (p < 0) continue;
+            int pnc = S.sn_start[p + 1] - S.sn_start[p], k = 0;
+            for (int64_t q = S.rowptr[s]; q < S.rowptr[s + 1] && S.rel[q] < pnc; ++q) ++k;
+            ncolpar[s] = k;
+        }
+        d_ncolpar.upload(ncolpar);
+        d_front_off.upload(S.front_off);
+        d_upd_off.upload(S.upd_off);
+        d_child_ptr.upload(S.child_ptr);
+        d_child_idx.upload(S.child_idx);
+        d_kptr.upload(S.kptr);
+        d_ksrc.upload(S.ksrc);
+        d_kdst.upload(S.kdst);
+        d_sched.upload(sched);
+        d_perm.upload(S.perm);
+        std::vector<signed char> ps(S.N);
+        for (int k = 0; k < S.N; ++k) ps[k] = (signed char)(dsigns[S.perm[k]] >= 0 ? 1 : -1);
+        d_psign.upload(ps);
+        fronts.alloc((size_t)S.front_store);
+        upd.alloc((size_t)S.update_store);
+        Dinv.alloc((size_t)S.N);
+        xp.alloc((size_t)S.N);
+        uvec.alloc(S.rows.size());
+        flags.alloc(2);
+        HIP_CHECK(hipMemset(fronts.p, 0, std::max<size_t>(fronts.n, 1) * sizeof(double)));
+        HIP_CHECK(hipMemset(Dinv.p, 0, std::max<size_t>(Dinv.n, 1) * sizeof(double)));
+        HIP_CHECK(hipMemset(flags.p, 0, 2 * sizeof(int)));
+    }
+};
+
+static void fill_info(const Symbolic& S, hipkkt_info* info)
+{
+    info->N = S.N;
+    info->nnzK = S.nnzK;
+    info->nnzL = S.nnzL_struct;
+    info->nnzL_stored = S.nnzL;
+    info->nsuper = S.nsuper;
+    info->nlevels = (int64_t)S.levels.size();
+    info->max_front = S.max_front;
+    info->etree_height = S.etree_height;
+    info->factor_flops = S.flops;
+    info->front_bytes = (double)S.front_store * 8.0;
+    info->update_bytes = (double)S.update_store * 8.0;
+}
+
+struct PinnedScalars {
+    double* h = nullptr;
+    PinnedScalars() { HIP_CHECK(hipHostMalloc((void**)&h, 8 * sizeof(double))); }
+    ~PinnedScalars() { if (h) (void)hipHostFree(h); }
+};
+
+// phase timing with hipEvents on the handle's stream
+struct Profiler {
+    bool enabled = false;
+    struct Span { hipEvent_t a, b; int phase; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    hipkkt_profile acc{};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    int begin(int phase, hipStream_t st)
+    {
+        if (!enabled) return -1;
+        Span s{get(), get(), phase};
+        HIP_CHECK(hipEventRecord(s.a, st));
+        spans.push_back(s);
+        return (int)spans.size() - 1;
+    }
+    void end(int id, hipStream_t st)
+    {
+        if (id < 0) return;
+        HIP_CHECK(hipEventRecord(spans[id].b, st));
+    }
+    void resolve()
+    {
+        for (Span& s : spans) {
+            HIP_CHECK(hipEventSynchronize(s.b));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
+            switch (s.phase) {
+            case 0: acc.update_ms += ms; acc.n_update++; break;
+            case 1: acc.factor_ms += ms; acc.n_factor++; break;
+            case 2: acc.trisolve_ms += ms; acc.n_trisolve++; break;
+            case 3: acc.residual_ms += ms; acc.n_residual++; break;
+            default: acc.other_ms += ms;
+            }
+            pool.push_back(s.a);
+            pool.push_back(s.b);
+        }
+        spans.clear();
+    }
+    ~Profiler()
+    {
+        for (Span& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+}  // namespace hipkkt
+
+using namespace hipkkt;
+
+// ====================================================================================
+//  handles
+// ====================================================================================
+struct hipkkt_ldl_s {
+    int device = 0;
+    hipkkt_settings st;
+    hipStream_t stream = nullptr;
+    int64_t N = 0, nnzK = 0;
+    int base = 0;
+    std::unique_ptr<LDLEngine> eng;
+    DBuf<double> Kval, vals, b, x;
+    DBuf<int> idx;
+    ~hipkkt_ldl_s() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+struct hipkkt_kkt_s {
+    int device = 0;
+    hipkkt_settings st;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    KKTAssembly K;
+    std::unique_ptr<LDLEngine> eng;
+    // values and maps
+    DBuf<double> Kval, Pval, Aval;
+    DBuf<int> mapP, mapA, mapHs, mapDiag, mapU, mapV, mapD, soc_of_entry;
+    // residual SpMV
+    DBuf<int64_t> fptr;
+    DBuf<int> fcol, fmap;
+    int lanes_per_row = 8;
+    // vectors
+    DBuf<double> b, x, e, dx, rx, rz, sbuf, zbuf, ybuf;
+    double *cur_x = nullptr, *cur_dx = nullptr;
+    DBuf<double> partial, scal;      // scal: [0] eps, [1] norme, [2] normb
+    std::unique_ptr<PinnedScalars> pin;
+    // cones
+    DBuf<int> c_kind, c_off, c_numel, c_sidx, c_soff, c_elem, c_soclist;
+    DBuf<int64_t> c_boff;
+    DBuf<double> w, eta, soc_u, soc_v, soc_eta2, Hs;
+    DBuf<int> fail;
+    int nsoc = 0;
+    bool has_psd = false, scaling_valid = false;
+    double last_eps = 0;
+    int64_t last_ir = 0;
+    Profiler prof;
+    ~hipkkt_kkt_s() { if (stream && own_stream) (void)hipStreamDestroy(stream); }
+
+    ConeDev cone_dev() const
+    {
+        ConeDev C;
+        C.ncones = (int)K.cones.size();
+        C.kind = c_kind.p; C.off = c_off.p; C.numel = c_numel.p; C.boff = c_boff.p; C.sidx = c_sidx.p;
+        C.soff = c_soff.p; C.elem_cone = c_elem.p; C.soc_list = c_soclist.p; C.nsoc = nsoc;
+        return C;
+    }
+    ConeState cone_state()
+    {
+        ConeState S;
+        S.w = w.p; S.eta = eta.p; S.u = soc_u.p; S.v = soc_v.p; S.eta2 = soc_eta2.p; S.Hs = Hs.p; S.fail = fail.p;
+        return S;
+    }
+};
+
+template <class F>
+static int guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const ArgError& e) {
+        g_last_error = e.what();
+        return HIPKKT_ERR_ARG;
+    } catch (const HipError& e) {
+        g_last_error = e.what();
+        return HIPKKT_ERR_HIP;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return HIPKKT_ERR_INTERNAL;
+    }
+}
+
+static int select_device(const hipkkt_settings& st)
+{
+    int dev = st.device;
+    if (dev < 0) HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipSetDevice(dev));
+    return dev;
+}
+
+extern "C" {
+
+int hipkkt_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+const char* hipkkt_last_error(void) { return g_last_error.c_str(); }
+const char* hipkkt_version(void) { return "hipkkt 0.1.0 (gfx950)"; }
+
+void hipkkt_default_settings(hipkkt_settings* s)
+{
+    s->static_regularization_constant = 1e-8;
+    s->static_regularization_proportional = DBL_EPSILON * DBL_EPSILON;
+    s->dynamic_regularization_eps = 1e-13;
+    s->dynamic_regularization_delta = 2e-7;
+    s->iterative_refinement_reltol = 1e-13;
+    s->iterative_refinement_abstol = 1e-12;
+    s->iterative_refinement_stop_ratio = 5.0;
+    s->iterative_refinement_max_iter = 10;
+    s->static_regularization_enable = 1;
+    s->iterative_refinement_enable = 1;
+    s->ordering = HIPKKT_ORDER_ND;
+    s->nd_leaf_size = 1000;
+    s->device = -1;
+    s->user_perm = nullptr;
+    s->amd_dense_scale = 1.5;
+}
+
+// ------------------------------------------------------------------------ level A
+int hipkkt_ldl_create(hipkkt_ldl_t* out, int64_t N, const int64_t* colptr, const int64_t* rowval,
+                      const double* nzval, const int64_t* dsigns, const hipkkt_settings* settings, int base)
+{
+    return guarded([&]() {
+        if (!out || !colptr || !rowval || !nzval || !dsigns || N <= 0 || N > 2000000000)
+            throw ArgError("hipkkt_ldl_create: bad argument");
+        if (base != 0 && base != 1) throw ArgError("index_base must be 0 or 1");
+        std::unique_ptr<hipkkt_ldl_s> h(new hipkkt_ldl_s);
+        if (settings) h->st = *settings; else hipkkt_default_settings(&h->st);
+        h->device = select_device(h->st);
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->N = N;
+        h->nnzK = colptr[N] - base;
+        h->base = base;
+        std::vector<int> ds((size_t)N);
+        for (int64_t i = 0; i < N; ++i) ds[i] = dsigns[i] >= 0 ? 1 : -1;
+        h->eng.reset(new LDLEngine((int)N, colptr, rowval, base, ds, h->st));
+        h->eng->stream = h->stream;
+        h->Kval.alloc((size_t)h->nnzK);
+        HIP_CHECK(hipMemcpy(h->Kval.p, nzval, (size_t)h->nnzK * sizeof(double), hipMemcpyHostToDevice));
+        h->b.alloc((size_t)N);
+        h->x.alloc((size_t)N);
+        *out = h.release();
+        return HIPKKT_OK;
+    });
+}
+
+void hipkkt_ldl_destroy(hipkkt_ldl_t h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+static void ldl_stage_index(hipkkt_ldl_t h, const int64_t* index, int64_t k)
+{
+    std::vector<int> idx((size_t)k);
+    for (int64_t i = 0; i < k; ++i) {
+        int64_t v = index[i] - h->base;
+        if (v < 0 || v >= h->nnzK) throw ArgError("value index out of range");
+        idx[i] = (int)v;
+    }
+    if (h->idx.n < (size_t)k) h->idx.alloc((size_t)k);
+    HIP_CHECK(hipMemcpyAsync(h->idx.p, idx.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+int hipkkt_ldl_update_values(hipkkt_ldl_t h, const int64_t* index, const double* values, int64_t k)
+{
+    return guarded([&]() {
+        if (!h || k < 0 || (k > 0 && (!index || !values))) throw ArgError("hipkkt_ldl_update_values: bad argument");
+        if (k == 0) return HIPKKT_OK;
+        HIP_CHECK(hipSetDevice(h->device));
+        ldl_stage_index(h, index, k);
+        if (h->vals.n < (size_t)k) h->vals.alloc((size_t)k);
+        HIP_CHECK(hipMemcpyAsync(h->vals.p, values, (size_t)k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_scatter(h->Kval.p, h->idx.p, h->vals.p, k, 1.0, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_scale_values(hipkkt_ldl_t h, const int64_t* index, double scale, int64_t k)
+{
+    return guarded([&]() {
+        if (!h || k < 0 || (k > 0 && !index)) throw ArgError("hipkkt_ldl_scale_values: bad argument");
+        if (k == 0) return HIPKKT_OK;
+        HIP_CHECK(hipSetDevice(h->device));
+        ldl_stage_index(h, index, k);
+        launch_scale(h->Kval.p, h->idx.p, scale, k, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_refactor(hipkkt_ldl_t h)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        h->eng->factor(h->Kval.p, nullptr);
+        int fl[2];
+        h->eng->read_flags(fl);
+        return fl[1] ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;      // directldl_qdldl.jl:79
+    });
+}
+
+int hipkkt_ldl_solve_dev(hipkkt_ldl_t h, double* d_x, const double* d_b)
+{
+    return guarded([&]() {
+        if (!h || !d_x || !d_b) throw ArgError("hipkkt_ldl_solve_dev: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        h->eng->solve(d_b, d_x);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_solve(hipkkt_ldl_t h, double* x, const double* b)
+{
+    return guarded([&]() {
+        if (!h || !x || !b) throw ArgError("hipkkt_ldl_solve: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemcpyAsync(h->b.p, b, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->eng->solve(h->b.p, h->x.p);
+        HIP_CHECK(hipMemcpyAsync(x, h->x.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_info(hipkkt_ldl_t h, hipkkt_info* info)
+{
+    return guarded([&]() {
+        if (!h || !info) throw ArgError("hipkkt_ldl_info: bad argument");
+        std::memset(info, 0, sizeof(*info));
+        fill_info(h->eng->S, info);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_get_perm(hipkkt_ldl_t h, int64_t* perm)
+{
+    return guarded([&]() {
+        if (!h || !perm) throw ArgError("hipkkt_ldl_get_perm: bad argument");
+        for (int64_t i = 0; i < h->N; ++i) perm[i] = h->eng->S.perm[i];
+        return HIPKKT_OK;
+    });
+}
+
+// ------------------------------------------------------------------------ level B
+int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pcolptr, const int64_t* Prowval,
+                      const double* Pnzval, const int64_t* Acolptr, const int64_t* Arowval, const double* Anzval,
+                      int64_t ncones, const int32_t* kinds, const int64_t* dims, const hipkkt_settings* settings,
+                      int base)
+{
+    return guarded([&]() {
+        if (!out || !Pcolptr || !Acolptr || n < 0 || m < 0 || ncones < 0 || (ncones > 0 && (!kinds || !dims)))
+            throw ArgError("hipkkt_kkt_create: bad argument");
+        if (base != 0 && base != 1) throw ArgError("index_base must be 0 or 1");
+        if (n + m == 0) throw ArgError("empty problem");
+        std::unique_ptr<hipkkt_kkt_s> h(new hipkkt_kkt_s);
+        if (settings) h->st = *settings; else hipkkt_default_settings(&h->st);
+        h->device = select_device(h->st);
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        try {
+            assemble_kkt(n, m, Pcolptr, Prowval, Pnzval, Acolptr, Arowval, Anzval, ncones, kinds, dims, base, h->K);
+        } catch (const std::runtime_error& e) {
+            throw ArgError(e.what());
+        }
+        KKTAssembly& K = h->K;
+        hipkkt_settings st = h->st;
+        if (st.ordering == HIPKKT_ORDER_USER && !st.user_perm) throw ArgError("ORDER_USER needs user_perm");
+        std::vector<int64_t> rv(K.rowval.begin(), K.rowval.end());
+        // K is 0-based here; a user permutation stays in the caller's base
+        std::vector<int64_t> uperm;
+        if (st.ordering == HIPKKT_ORDER_USER) {
+            uperm.resize(K.N);
+            for (int i = 0; i < K.N; ++i) uperm[i] = st.user_perm[i] - base;
+            st.user_perm = uperm.data();
+        }
+        h->eng.reset(new LDLEngine(K.N, K.colptr.data(), rv.data(), 0, K.dsigns, st));
+        h->eng->stream = h->stream;
+        h->st.user_perm = nullptr;
+
+        h->Kval.upload(K.nzval);
+        h->mapP.upload(K.mapP);
+        h->mapA.upload(K.mapA);
+        h->mapHs.upload(K.mapHs);
+        h->mapDiag.upload(K.map_diag);
+        h->mapU.upload(K.mapU);
+        h->mapV.upload(K.mapV);
+        h->mapD.upload(K.mapD);
+        h->Pval.alloc(K.mapP.size());
+        h->Aval.alloc(K.mapA.size());
+        // full symmetric CSR image of K for the residual
+        {
+            const int N = K.N;
+            std::vector<int64_t> ptr((size_t)N + 1, 0);
+            for (int j = 0; j < N; ++j)
+                for (int64_t q = K.colptr[j]; q < K.colptr[j + 1]; ++q) {
+                    int i = K.rowval[q];
+                    ptr[i + 1]++;
+                    if (i != j) ptr[j + 1]++;
+                }
+            for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
+            std::vector<int> col((size_t)ptr[N]), vmap((size_t)ptr[N]);
+            std::vector<int64_t> nx(ptr.begin(), ptr.end() - 1);
+            // row i gets its upper-triangle partners (i, j>i) from column scans in ascending j and its
+            // lower partners from its own column; fill lower part first so columns ascend within a row
+            for (int j = 0; j < N; ++j) {            // entries (i<j) stored in column j: row j, col i
+                for (int64_t q = K.colptr[j]; q < K.colptr[j + 1]; ++q) {
+                    int i = K.rowval[q];
+                    int64_t d = nx[j]++;
+                    col[d] = i;
+                    vmap[d] = (int)q;
+                }
+            }
+            for (int j = 0; j < N; ++j)              // mirrored entries: row i, col j (j > i), ascending j
+                for (int64_t q = K.colptr[j]; q < K.colptr[j + 1]; ++q) {
+                    int i = K.rowval[q];
+                    if (i == j) continue;
+                    int64_t d = nx[i]++;
+                    col[d] = j;
+                    vmap[d] = (int)q;
+                }
+            h->fptr.upload(ptr);
+            h->fcol.upload(col);
+            h->fmap.upload(vmap);
+            double avg = (double)ptr[N] / std::max(N, 1);
+            h->lanes_per_row = avg > 24.0 ? 64 : 8;
+        }
+        const size_t N = (size_t)K.N;
+        h->b.alloc(N); h->x.alloc(N); h->e.alloc(N); h->dx.alloc(N);
+        HIP_CHECK(hipMemset(h->b.p, 0, N * sizeof(double)));
+        HIP_CHECK(hipMemset(h->x.p, 0, N * sizeof(double)));
+        h->cur_x = h->x.p;
+        h->cur_dx = h->dx.p;
+        h->rx.alloc((size_t)K.n); h->rz.alloc((size_t)K.m);
+        h->sbuf.alloc((size_t)K.m); h->zbuf.alloc((size_t)K.m); h->ybuf.alloc((size_t)K.m);
+        h->partial.alloc(4096);
+        h->scal.alloc(8);
+        HIP_CHECK(hipMemset(h->scal.p, 0, 8 * sizeof(double)));
+        h->pin.reset(new PinnedScalars);
+        // cones
+        {
+            size_t nc = K.cones.size();
+            std::vector<int> kind(nc), off(nc), numel(nc), sidx(nc), soff(nc), elem((size_t)K.m), soclist, soc_of;
+            std::vector<int64_t> boff(nc);
+            soc_of.assign((size_t)K.sparse_len, 0);
+            for (size_t c = 0; c < nc; ++c) {
+                const ConeInfo& ci = K.cones[c];
+                kind[c] = ci.kind; off[c] = ci.off; numel[c] = ci.numel; boff[c] = ci.boff;
+                sidx[c] = ci.sparse ? ci.sidx : -1;
+                soff[c] = ci.sparse ? ci.soff : -1;
+                for (int t = 0; t < ci.numel; ++t) elem[ci.off + t] = (int)c;
+                if (ci.kind == HIPKKT_CONE_SOC) soclist.push_back((int)c);
+                if (ci.kind == HIPKKT_CONE_PSD) h->has_psd = true;
+                if (ci.sparse) for (int t = 0; t < ci.numel; ++t) soc_of[ci.soff + t] = ci.sidx;
+            }
+            h->nsoc = (int)soclist.size();
+            h->c_kind.upload(kind); h->c_off.upload(off); h->c_numel.upload(numel); h->c_boff.upload(boff);
+            h->c_sidx.upload(sidx); h->c_soff.upload(soff); h->c_elem.upload(elem); h->c_soclist.upload(soclist);
+            h->soc_of_entry.upload(soc_of);
+            h->w.alloc((size_t)K.m); h->eta.alloc(nc);
+            h->soc_u.alloc((size_t)K.sparse_len); h->soc_v.alloc((size_t)K.sparse_len);
+            h->soc_eta2.alloc((size_t)K.nsparse); h->Hs.alloc((size_t)K.nHs);
+            h->fail.alloc(1);
+            HIP_CHECK(hipMemset(h->fail.p, 0, sizeof(int)));
+        }
+        *out = h.release();
+        return HIPKKT_OK;
+    });
+}
+
+void hipkkt_kkt_destroy(hipkkt_kkt_t h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+int hipkkt_kkt_info(hipkkt_kkt_t h, hipkkt_info* info)
+{
+    return guarded([&]() {
+        if (!h || !info) throw ArgError("hipkkt_kkt_info: bad argument");
+        std::memset(info, 0, sizeof(*info));
+        fill_info(h->eng->S, info);
+        info->n = h->K.n; info->m = h->K.m; info->p = h->K.p;
+        info->nHs = h->K.nHs; info->nsparse_soc = h->K.nsparse; info->sparse_soc_len = h->K.sparse_len;
+        return HIPKKT_OK;
+    });
+}
+
+// scatter of -Hs and the sparse-cone columns, static regulariser, numeric factorisation
+// (kktsolver_directldl.jl:211-294).  Hs/u/v/eta2 already on the device.
+static int kkt_update_device(hipkkt_kkt_t h)
+{
+    KKTAssembly& K = h->K;
+    int pu = h->prof.begin(0, h->stream);
+    launch_scatter(h->Kval.p, h->mapHs.p, h->Hs.p, K.nHs, -1.0, h->stream);       // :225-228
+    launch_soc_columns(h->Kval.p, h->mapU.p, h->mapV.p, h->mapD.p, h->soc_u.p, h->soc_v.p, h->soc_eta2.p,
+                       h->soc_of_entry.p, K.sparse_len, K.nsparse, h->stream);     // :235-241
+    const double* eps_ptr = nullptr;
+    if (h->st.static_regularization_enable) {                                      // :259-279
+        launch_regularizer(h->Kval.p, h->mapDiag.p, K.N, h->st.static_regularization_constant,
+                           h->st.static_regularization_proportional, h->partial.p, h->scal.p, h->stream);
+        eps_ptr = h->scal.p;
+    }
+    h->prof.end(pu, h->stream);
+    int pf = h->prof.begin(1, h->stream);
+    h->eng->factor(h->Kval.p, eps_ptr);          // K itself stays un-regularised (:283-291)
+    h->prof.end(pf, h->stream);
+    // read back: flags, eps, cone failure
+    int fl[2] = {0, 0};
+    int conefail = 0;
+    HIP_CHECK(hipMemcpyAsync(h->pin->h, h->scal.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(&conefail, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    h->eng->read_flags(fl);
+    h->last_eps = h->st.static_regularization_enable ? h->pin->h[0] : 0.0;
+    h->prof.acc.dynamic_regularizations += fl[0];
+    if (conefail) return HIPKKT_NUMERIC_FAILURE;
+    return fl[1] ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
+}
+
+int hipkkt_kkt_update_cones(hipkkt_kkt_t h, const double* Hs, const double* soc_u, const double* soc_v,
+                            const double* soc_eta2)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        KKTAssembly& K = h->K;
+        if ((K.nHs > 0 && !Hs) || (K.nsparse > 0 && (!soc_u || !soc_v || !soc_eta2)))
+            throw ArgError("hipkkt_kkt_update_cones: missing cone data");
+        HIP_CHECK(hipSetDevice(h->device));
+        if (K.nHs) HIP_CHECK(hipMemcpyAsync(h->Hs.p, Hs, (size_t)K.nHs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (K.nsparse) {
+            HIP_CHECK(hipMemcpyAsync(h->soc_u.p, soc_u, (size_t)K.sparse_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(h->soc_v.p, soc_v, (size_t)K.sparse_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(h->soc_eta2.p, soc_eta2, (size_t)K.nsparse * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
+        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        h->scaling_valid = false;
+        return kkt_update_device(h);
+    });
+}
+
+int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double* d_s, const double* d_z)
+{
+    return guarded([&]() {
+        if (!h || (h->K.m > 0 && (!d_s || !d_z))) throw ArgError("hipkkt_kkt_update_from_sz: bad argument");
+        if (h->has_psd)
+            throw ArgError("update_from_sz: PSD cones are scaled by the caller in this version; use hipkkt_kkt_update_cones");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        int pu = h->prof.begin(0, h->stream);
+        launch_cone_scaling(h->cone_dev(), h->cone_state(), d_s, d_z, h->K.m, h->stream);
+        h->prof.end(pu, h->stream);
+        h->scaling_valid = true;
+        return kkt_update_device(h);
+    });
+}
+
+int hipkkt_kkt_update_from_sz(hipkkt_kkt_t h, const double* s, const double* z)
+{
+    return guarded([&]() {
+        if (!h || (h->K.m > 0 && (!s || !z))) throw ArgError("hipkkt_kkt_update_from_sz: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        size_t bytes = (size_t)h->K.m * sizeof(double);
+        if (bytes) {
+            HIP_CHECK(hipMemcpyAsync(h->sbuf.p, s, bytes, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(h->zbuf.p, z, bytes, hipMemcpyHostToDevice, h->stream));
+        }
+        return hipkkt_kkt_update_from_sz_dev(h, h->sbuf.p, h->zbuf.p);
+    });
+}
+
+int hipkkt_kkt_update_P(hipkkt_kkt_t h, const double* Pnzval)
+{
+    return guarded([&]() {
+        if (!h || (h->K.mapP.size() && !Pnzval)) throw ArgError("hipkkt_kkt_update_P: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        size_t k = h->K.mapP.size();
+        if (!k) return HIPKKT_OK;
+        HIP_CHECK(hipMemcpyAsync(h->Pval.p, Pnzval, k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_scatter(h->Kval.p, h->mapP.p, h->Pval.p, (int64_t)k, 1.0, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_update_A(hipkkt_kkt_t h, const double* Anzval)
+{
+    return guarded([&]() {
+        if (!h || (h->K.mapA.size() && !Anzval)) throw ArgError("hipkkt_kkt_update_A: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        size_t k = h->K.mapA.size();
+        if (!k) return HIPKKT_OK;
+        HIP_CHECK(hipMemcpyAsync(h->Aval.p, Anzval, k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_scatter(h->Kval.p, h->mapA.p, h->Aval.p, (int64_t)k, 1.0, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_setrhs_dev(hipkkt_kkt_t h, const double* d_rx, const double* d_rz)
+{
+    return guarded([&]() {
+        if (!h || (h->K.n && !d_rx) || (h->K.m && !d_rz)) throw ArgError("hipkkt_kkt_setrhs: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        launch_pack_rhs(h->b.p, d_rx, d_rz, h->K.n, h->K.m, h->K.p, h->stream);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_setrhs(hipkkt_kkt_t h, const double* rx, const double* rz)
+{
+    return guarded([&]() {
+        if (!h || (h->K.n && !rx) || (h->K.m && !rz)) throw ArgError("hipkkt_kkt_setrhs: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        if (h->K.n) HIP_CHECK(hipMemcpyAsync(h->rx.p, rx, (size_t)h->K.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (h->K.m) HIP_CHECK(hipMemcpyAsync(h->rz.p, rz, (size_t)h->K.m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_pack_rhs(h->b.p, h->rx.p, h->rz.p, h->K.n, h->K.m, h->K.p, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));     // rx/rz staging may be overwritten by the next call
+        return HIPKKT_OK;
+    });
+}
+
+// e = b - K xi, returns ||e||_inf via pinned read-back (slot 1), optionally ||b||_inf too (slot 2)
+static double kkt_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, double* normb)
+{
+    SpmvDev A;
+    A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.N = h->K.N; A.lanes_per_row = h->lanes_per_row;
+    int pr = h->prof.begin(3, h->stream);
+    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + 1, h->stream);
+    if (with_normb) launch_norm_inf(h->b.p, h->K.N, h->partial.p, h->scal.p + 2, h->stream);
+    h->prof.end(pr, h->stream);
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 1, h->scal.p + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (with_normb) *normb = h->pin->h[2];
+    return h->pin->h[1];
+}
+
+static void kkt_trisolve(hipkkt_kkt_t h, const double* rhs, double* out)
+{
+    int ps = h->prof.begin(2, h->stream);
+    h->eng->solve(rhs, out);
+    h->prof.end(ps, h->stream);
+}
+
+// kktsolver_solve! with _iterative_refinement (kktsolver_directldl.jl:346-449); leaves the
+// solution in h->cur_x.  Returns HIPKKT_OK or HIPKKT_NUMERIC_FAILURE.
+static int kkt_solve_core(hipkkt_kkt_t h)
+{
+    const hipkkt_settings& st = h->st;
+    double* x = h->cur_x;
+    double* dx = h->cur_dx;
+    kkt_trisolve(h, h->b.p, x);
+    h->last_ir = 0;
+    if (!st.iterative_refinement_enable) {
+        int bad = 0;
+        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        launch_check_finite(x, h->K.N, h->fail.p, h->stream);
+        HIP_CHECK(hipMemcpyAsync(&bad, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return bad ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
+    }
+    double normb = 0.0;
+    double norme = kkt_refine_error(h, x, true, &normb);
+    if (!std::isfinite(norme)) return HIPKKT_NUMERIC_FAILURE;
+    for (int i = 0; i < st.iterative_refinement_max_iter; ++i) {
+        if (norme <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb) break;
+        const double lastnorme = norme;
+        kkt_trisolve(h, h->e.p, dx);                             // dx = K^{-1} e
+        launch_axpby_sum(dx, dx, x, h->K.N, h->stream);          // prospective solution x + dx
+        norme = kkt_refine_error(h, dx, false, nullptr);
+        h->last_ir++;
+        h->prof.acc.ir_iterations++;
+        if (!std::isfinite(norme)) return HIPKKT_NUMERIC_FAILURE;
+        const double ratio = lastnorme / norme;
+        if (ratio < st.iterative_refinement_stop_ratio) {
+            if (ratio > 1.0) std::swap(x, dx);
+            break;
+        }
+        std::swap(x, dx);
+    }
+    h->cur_x = x;
+    h->cur_dx = dx;
+    return HIPKKT_OK;
+}
+
+int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double* d_lhsx, double* d_lhsz)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        int rc = kkt_solve_core(h);
+        if (rc != HIPKKT_OK) return rc;
+        if (d_lhsx && h->K.n)
+            HIP_CHECK(hipMemcpyAsync(d_lhsx, h->cur_x, (size_t)h->K.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (d_lhsz && h->K.m)
+            HIP_CHECK(hipMemcpyAsync(d_lhsz, h->cur_x + h->K.n, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_solve(hipkkt_kkt_t h, double* lhsx, double* lhsz)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        int rc = kkt_solve_core(h);
+        if (rc != HIPKKT_OK) return rc;
+        if (lhsx && h->K.n)
+            HIP_CHECK(hipMemcpyAsync(lhsx, h->cur_x, (size_t)h->K.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (lhsz && h->K.m)
+            HIP_CHECK(hipMemcpyAsync(lhsz, h->cur_x + h->K.n, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_mul_Hs(hipkkt_kkt_t h, double* y, const double* x)
+{
+    return guarded([&]() {
+        if (!h || !y || !x) throw ArgError("hipkkt_kkt_mul_Hs: bad argument");
+        if (!h->scaling_valid || h->has_psd) throw ArgError("mul_Hs needs a device-side scaling (update_from_sz) without PSD cones");
+        HIP_CHECK(hipSetDevice(h->device));
+        size_t bytes = (size_t)h->K.m * sizeof(double);
+        HIP_CHECK(hipMemcpyAsync(h->sbuf.p, x, bytes, hipMemcpyHostToDevice, h->stream));
+        launch_mul_Hs(h->cone_dev(), h->cone_state(), h->ybuf.p, h->sbuf.p, h->K.m, h->stream);
+        HIP_CHECK(hipMemcpyAsync(y, h->ybuf.p, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_get_pattern(hipkkt_kkt_t h, int64_t* colptr, int64_t* rowval)
+{
+    return guarded([&]() {
+        if (!h || !colptr || !rowval) throw ArgError("hipkkt_kkt_get_pattern: bad argument");
+        std::copy(h->K.colptr.begin(), h->K.colptr.end(), colptr);
+        for (int64_t q = 0; q < h->K.nnzK; ++q) rowval[q] = h->K.rowval[q];
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_get_values(hipkkt_kkt_t h, double* nzval)
+{
+    return guarded([&]() {
+        if (!h || !nzval) throw ArgError("hipkkt_kkt_get_values: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemcpyAsync(nzval, h->Kval.p, (size_t)h->K.nnzK * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_get_maps(hipkkt_kkt_t h, int64_t* mapP, int64_t* mapA, int64_t* mapHs, int64_t* map_diag,
+                        int64_t* mapU, int64_t* mapV, int64_t* mapD, int64_t* dsigns)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        auto cp = [](const std::vector<int>& v, int64_t* o) { if (o) for (size_t i = 0; i < v.size(); ++i) o[i] = v[i]; };
+        cp(h->K.mapP, mapP); cp(h->K.mapA, mapA); cp(h->K.mapHs, mapHs); cp(h->K.map_diag, map_diag);
+        cp(h->K.mapU, mapU); cp(h->K.mapV, mapV); cp(h->K.mapD, mapD); cp(h->K.dsigns, dsigns);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_get_perm(hipkkt_kkt_t h, int64_t* perm)
+{
+    return guarded([&]() {
+        if (!h || !perm) throw ArgError("hipkkt_kkt_get_perm: bad argument");
+        for (int i = 0; i < h->K.N; ++i) perm[i] = h->eng->S.perm[i];
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_get_Hs(hipkkt_kkt_t h, double* Hs)
+{
+    return guarded([&]() {
+        if (!h || (h->K.nHs && !Hs)) throw ArgError("hipkkt_kkt_get_Hs: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        if (h->K.nHs) HIP_CHECK(hipMemcpyAsync(Hs, h->Hs.p, (size_t)h->K.nHs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+double hipkkt_kkt_last_regularizer(hipkkt_kkt_t h) { return h ? h->last_eps : 0.0; }
+int64_t hipkkt_kkt_last_ir_iterations(hipkkt_kkt_t h) { return h ? h->last_ir : 0; }
+
+int hipkkt_kkt_set_stream(hipkkt_kkt_t h, void* stream)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->own_stream && h->stream) HIP_CHECK(hipStreamDestroy(h->stream));
+        h->stream = (hipStream_t)stream;
+        h->own_stream = false;
+        h->eng->stream = h->stream;
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_synchronize(hipkkt_kkt_t h)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_profile_enable(hipkkt_kkt_t h, int enable)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        h->prof.resolve();
+        h->prof.enabled = enable != 0;
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_profile_reset(hipkkt_kkt_t h)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        h->prof.resolve();
+        h->prof.acc = hipkkt_profile{};
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_profile_get(hipkkt_kkt_t h, hipkkt_profile* out)
+{
+    return guarded([&]() {
+        if (!h || !out) throw ArgError("hipkkt_kkt_profile_get: bad argument");
+        h->prof.resolve();
+        *out = h->prof.acc;
+        return HIPKKT_OK;
+    });
+}
+
+}  // extern "C"

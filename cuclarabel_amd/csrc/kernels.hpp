@@ -1,0 +1,120 @@
+// Device kernels of the supernodal multifrontal LDL^T, the tree solves, the KKT value updates,
+// the residual SpMV and the cone scalings.  gfx950 (wave64) only.
+//
+// Data layout in HBM (all fronts of the tree are resident at once -- 288 GB makes the classic
+// multifrontal stack unnecessary, and a static layout lets every per-iteration step be a pure
+// function of precomputed index maps):
+//   panel store   per supernode s: f_s x nc_s column-major (ld = f_s), f_s = nc_s + nb_s.
+//                 after factorisation: strictly-lower part = L, diagonal = D.
+//   update store  per supernode s: nb_s x nb_s column-major (ld = nb_s), lower triangle =
+//                 the Schur complement s hands to its parent.
+//   uvec          per supernode s: nb_s doubles, forward-solve contributions to the ancestors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace hipkkt {
+
+struct TreeDev {                 // device copies of the symbolic structure
+    const int* sn_start;         // nsuper+1
+    const int64_t* rowptr;       // nsuper+1
+    const int* rows;             // sum nb
+    const int* rel;              // sum nb: local row in the parent's front
+    const int* ncolpar;          // nsuper: how many of s's rows fall in its parent's columns
+    const int64_t* front_off;    // nsuper+1
+    const int64_t* upd_off;      // nsuper+1
+    const int* child_ptr;        // nsuper+1
+    const int* child_idx;
+    const int64_t* kptr;         // nsuper+1
+    const int* ksrc;
+    const int* kdst;
+    const int* sched;            // supernodes in launch order (level by level, size class inside)
+    const signed char* psign;    // N: expected pivot sign, permuted order
+    const int* perm;             // N: perm[new] = old
+};
+
+struct FactorArgs {
+    TreeDev T;
+    const double* Kval;          // caller's K.nzval (original order, un-regularised)
+    const double* eps;           // device scalar: static regulariser to add as eps*sign, or null
+    double* fronts;
+    double* upd;
+    double* Dinv;                // N, permuted order
+    int* flags;                  // [0] #dynamic regularisations, [1] non-finite pivot seen
+    double dyn_eps, dyn_delta;
+    int nbk;                     // block-column width (<= 16), chosen so the LDS buffer fits
+};
+
+struct SolveArgs {
+    TreeDev T;
+    const double* fronts;
+    const double* Dinv;
+    const double* b;             // original order
+    double* out;                 // original order
+    double* xp;                  // N, permuted work vector
+    double* uvec;                // sum nb
+};
+
+constexpr int kTriBlock = 32;    // diagonal-block width of the triangular solves
+constexpr int kMaxNbk = 16;
+
+void launch_factor(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
+void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
+void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
+
+// ---- KKT value updates (kktsolver_directldl.jl:130-188, 211-245, 374-386)
+void launch_scatter(double* Kval, const int* idx, const double* vals, int64_t n, double scale, hipStream_t st);
+void launch_scale(double* Kval, const int* idx, double scale, int64_t n, hipStream_t st);
+// per sparse SOC t: K[mapU] = u * (-eta2), K[mapV] = v * (-eta2), K[mapD] = (-eta2, +eta2)
+void launch_soc_columns(double* Kval, const int* mapU, const int* mapV, const int* mapD,
+                        const double* u, const double* v, const double* eta2, const int* soc_of_entry,
+                        int sparse_len, int nsparse, hipStream_t st);
+// eps = c0 + c1 * max_i |Kval[diag[i]]|  (kktsolver_directldl.jl:297-310) -> *eps_out
+void launch_regularizer(const double* Kval, const int* diag, int N, double c0, double c1,
+                        double* partial, double* eps_out, hipStream_t st);
+
+// ---- residual: e = b - K_sym x on the un-regularised K, and infinity norms
+struct SpmvDev {
+    const int64_t* ptr;          // N+1, full symmetric CSR
+    const int* col;
+    const int* vmap;             // entry -> index into Kval
+    int N;
+    int lanes_per_row;           // 8 or 64
+};
+// norm_out[0] = ||e||_inf (NaN if any entry is non-finite)
+void launch_residual(const SpmvDev& A, const double* Kval, const double* b, const double* x, double* e,
+                     double* partial, double* norm_out, hipStream_t st);
+void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st);
+void launch_axpby_sum(double* y, const double* a, const double* b, int n, hipStream_t st);   // y = a + b
+void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m, int p, hipStream_t st);
+void launch_check_finite(const double* v, int n, int* flag, hipStream_t st);
+
+// ---- cone scalings on the device (update_scaling! + get_Hs!, src/cones/coneops_*.jl)
+struct ConeDev {
+    int ncones;
+    const int* kind;             // per cone
+    const int* off;              // rng_cones start
+    const int* numel;
+    const int64_t* boff;         // rng_blocks start
+    const int* sidx;             // sparse SOC index or -1
+    const int* soff;             // offset in concatenated u/v or -1
+    // per-element cone id for the elementwise (zero / nonnegative) kernels
+    const int* elem_cone;        // m
+    // list of second-order cones
+    const int* soc_list;
+    int nsoc;
+};
+struct ConeState {
+    double* w;                   // m: NN: sqrt(s/z); SOC: normalised w
+    double* eta;                 // per cone (SOC)
+    double* u;                   // sparse_len
+    double* v;                   // sparse_len
+    double* eta2;                // nsparse
+    double* Hs;                  // |Hs| positive blocks
+    int* fail;                   // set to 1 when a point is not interior
+};
+void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, const double* z, int m,
+                         hipStream_t st);
+void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st);
+
+}  // namespace hipkkt

@@ -1,0 +1,255 @@
+"""Host-side mirror of the reference's KKT solver objects over the C ABI.
+
+`HipKKTSolver` has the methods of `DirectLDLKKTSolver <: AbstractKKTSolver`
+(`/root/reference/src/kktsolvers/kktsolver_directldl.jl:46-92,197-386`, contract
+`kktsolver_defaults.jl:2-48`) and `HipDirectLDLSolver` those of an
+`AbstractDirectLDLSolver` backend (`direct-ldl/directldl_defaults.jl:1-72`, example
+`directldl_qdldl.jl`).  Method names drop Julia's `!`; Bool returns keep the reference's
+meaning (True = success, False = numeric failure; usage errors raise).
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import check, f64, i64, ptr
+from .cones import cone_kinds_dims
+
+
+class LinearSolverInfo:
+    """types.jl:198-206"""
+
+    def __init__(self, name, threads, direct, nnzA, nnzL):
+        self.name, self.threads, self.direct, self.nnzA, self.nnzL = name, threads, direct, nnzA, nnzL
+
+    def __repr__(self):
+        return (f"LinearSolverInfo(name={self.name!r}, threads={self.threads}, direct={self.direct}, "
+                f"nnzA={self.nnzA}, nnzL={self.nnzL})")
+
+
+class HipKKTSolver:
+    """DirectLDLKKTSolver on the MI355X: KKT assembly maps, value scatter, regularisation,
+    numeric LDL', triangular solves and iterative refinement all run on the device."""
+
+    def __init__(self, P, A, cones, m=None, n=None, settings=None):
+        L = _lib.lib()
+        P = sp.triu(sp.csc_matrix(P), format="csc")
+        P.sort_indices()
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        self.n = P.shape[0] if n is None else n
+        self.m = A.shape[0] if m is None else m
+        if P.shape != (self.n, self.n) or A.shape != (self.m, self.n):
+            raise ValueError("P must be n x n and A m x n")
+        self.cones = list(cones)
+        kinds, dims = cone_kinds_dims(self.cones)
+        self.settings = settings if settings is not None else _lib.default_settings()
+        self._h = C.c_void_p()
+        Pp, Pi, Px = i64(P.indptr), i64(P.indices), f64(P.data)
+        Ap, Ai, Ax = i64(A.indptr), i64(A.indices), f64(A.data)
+        rc = L.hipkkt_kkt_create(C.byref(self._h), self.n, self.m, ptr(Pp), ptr(Pi), ptr(Px),
+                                 ptr(Ap), ptr(Ai), ptr(Ax), len(self.cones), ptr(kinds), ptr(dims),
+                                 C.byref(self.settings), 0)
+        if not check(rc, "hipkkt_kkt_create"):
+            raise _lib.HipKKTError("hipkkt_kkt_create reported a numeric failure")
+        self._nnzP, self._nnzA = P.nnz, A.nnz
+        info = _lib.Info()
+        check(L.hipkkt_kkt_info(self._h, C.byref(info)), "hipkkt_kkt_info")
+        self.info = info.as_dict()
+        self.p = info.p
+        self.N = info.N
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().hipkkt_kkt_destroy(h)
+            self._h = None
+
+    # ---- AbstractKKTSolver interface (kktsolver_defaults.jl:2-48)
+    def kktsolver_update(self, Hsblocks, soc_u=None, soc_v=None, soc_eta2=None):
+        """kktsolver_update!(kktsolver, cones) with the cone data flattened the way the glue does:
+        get_Hs! output plus each sparse second-order cone's (u, v, eta^2)."""
+        Hs = f64(Hsblocks)
+        u = f64(soc_u if soc_u is not None else [])
+        v = f64(soc_v if soc_v is not None else [])
+        e2 = f64(soc_eta2 if soc_eta2 is not None else [])
+        if Hs.size != self.info["nHs"] or u.size != self.info["sparse_soc_len"] or \
+                v.size != u.size or e2.size != self.info["nsparse_soc"]:
+            raise ValueError("cone data has the wrong length")
+        return check(_lib.lib().hipkkt_kkt_update_cones(self._h, ptr(Hs), ptr(u), ptr(v), ptr(e2)),
+                     "hipkkt_kkt_update_cones")
+
+    def kktsolver_update_from_sz(self, s, z):
+        """Device-native variant: update_scaling! + get_Hs! run on the GPU from (s, z)."""
+        s, z = f64(s), f64(z)
+        if s.size != self.m or z.size != self.m:
+            raise ValueError("s, z must have length m")
+        return check(_lib.lib().hipkkt_kkt_update_from_sz(self._h, ptr(s), ptr(z)),
+                     "hipkkt_kkt_update_from_sz")
+
+    def kktsolver_update_from_sz_dev(self, d_s, d_z):
+        return check(_lib.lib().hipkkt_kkt_update_from_sz_dev(self._h, C.c_void_p(d_s), C.c_void_p(d_z)),
+                     "hipkkt_kkt_update_from_sz_dev")
+
+    def kktsolver_setrhs(self, rhsx, rhsz):
+        rx, rz = f64(rhsx), f64(rhsz)
+        if rx.size != self.n or rz.size != self.m:
+            raise ValueError("rhs has the wrong length")
+        check(_lib.lib().hipkkt_kkt_setrhs(self._h, ptr(rx), ptr(rz)), "hipkkt_kkt_setrhs")
+
+    def kktsolver_solve(self, lhsx=None, lhsz=None):
+        """kktsolver_solve!(kktsolver, lhsx, lhsz): writes into the given arrays (either may be
+        None, as in the reference) and returns is_success."""
+        for a, k in ((lhsx, self.n), (lhsz, self.m)):
+            if a is not None and (a.dtype != np.float64 or a.size != k or not a.flags.c_contiguous):
+                raise ValueError("lhs arrays must be contiguous float64 of the right length")
+        return check(_lib.lib().hipkkt_kkt_solve(self._h, ptr(lhsx), ptr(lhsz)), "hipkkt_kkt_solve")
+
+    def kktsolver_setrhs_dev(self, d_rx, d_rz):
+        check(_lib.lib().hipkkt_kkt_setrhs_dev(self._h, C.c_void_p(d_rx), C.c_void_p(d_rz)), "hipkkt_kkt_setrhs_dev")
+
+    def kktsolver_solve_dev(self, d_lhsx, d_lhsz):
+        return check(_lib.lib().hipkkt_kkt_solve_dev(self._h, C.c_void_p(d_lhsx) if d_lhsx else None,
+                                                     C.c_void_p(d_lhsz) if d_lhsz else None),
+                     "hipkkt_kkt_solve_dev")
+
+    def kktsolver_update_P(self, P):
+        Px = f64(P.data if sp.issparse(P) else P)
+        if Px.size != self._nnzP:
+            raise ValueError("P.nzval has the wrong length")
+        check(_lib.lib().hipkkt_kkt_update_P(self._h, ptr(Px)), "hipkkt_kkt_update_P")
+
+    def kktsolver_update_A(self, A):
+        Ax = f64(A.data if sp.issparse(A) else A)
+        if Ax.size != self._nnzA:
+            raise ValueError("A.nzval has the wrong length")
+        check(_lib.lib().hipkkt_kkt_update_A(self._h, ptr(Ax)), "hipkkt_kkt_update_A")
+
+    def kktsolver_linear_solver_info(self):
+        return LinearSolverInfo("hipldl", 1, True, self.info["nnzK"], self.info["nnzL"])
+
+    # ---- extras
+    def mul_Hs(self, x):
+        x = f64(x)
+        y = np.zeros(self.m)
+        check(_lib.lib().hipkkt_kkt_mul_Hs(self._h, ptr(y), ptr(x)), "hipkkt_kkt_mul_Hs")
+        return y
+
+    def get_Hs(self):
+        out = np.zeros(max(self.info["nHs"], 1))
+        check(_lib.lib().hipkkt_kkt_get_Hs(self._h, ptr(out)), "hipkkt_kkt_get_Hs")
+        return out[:self.info["nHs"]]
+
+    def KKT(self):
+        """The assembled triu CSC KKT matrix with its current (un-regularised) values."""
+        colptr = np.zeros(self.N + 1, dtype=np.int64)
+        rowval = np.zeros(self.info["nnzK"], dtype=np.int64)
+        nzval = np.zeros(self.info["nnzK"])
+        L = _lib.lib()
+        check(L.hipkkt_kkt_get_pattern(self._h, ptr(colptr), ptr(rowval)), "hipkkt_kkt_get_pattern")
+        check(L.hipkkt_kkt_get_values(self._h, ptr(nzval)), "hipkkt_kkt_get_values")
+        return sp.csc_matrix((nzval, rowval, colptr), shape=(self.N, self.N))
+
+    def maps(self):
+        i = self.info
+        out = dict(P=np.zeros(self._nnzP, np.int64), A=np.zeros(self._nnzA, np.int64),
+                   Hsblocks=np.zeros(i["nHs"], np.int64), diag_full=np.zeros(self.N, np.int64),
+                   soc_u=np.zeros(i["sparse_soc_len"], np.int64), soc_v=np.zeros(i["sparse_soc_len"], np.int64),
+                   soc_D=np.zeros(2 * i["nsparse_soc"], np.int64), dsigns=np.zeros(self.N, np.int64))
+        check(_lib.lib().hipkkt_kkt_get_maps(self._h, *[ptr(out[k]) for k in
+              ("P", "A", "Hsblocks", "diag_full", "soc_u", "soc_v", "soc_D", "dsigns")]), "hipkkt_kkt_get_maps")
+        return out
+
+    def perm(self):
+        out = np.zeros(self.N, dtype=np.int64)
+        check(_lib.lib().hipkkt_kkt_get_perm(self._h, ptr(out)), "hipkkt_kkt_get_perm")
+        return out
+
+    @property
+    def diagonal_regularizer(self):
+        return _lib.lib().hipkkt_kkt_last_regularizer(self._h)
+
+    @property
+    def last_ir_iterations(self):
+        return int(_lib.lib().hipkkt_kkt_last_ir_iterations(self._h))
+
+    def set_stream(self, stream_ptr):
+        check(_lib.lib().hipkkt_kkt_set_stream(self._h, C.c_void_p(stream_ptr)), "hipkkt_kkt_set_stream")
+
+    def synchronize(self):
+        check(_lib.lib().hipkkt_kkt_synchronize(self._h), "hipkkt_kkt_synchronize")
+
+    def profile_enable(self, on=True):
+        check(_lib.lib().hipkkt_kkt_profile_enable(self._h, int(on)), "hipkkt_kkt_profile_enable")
+
+    def profile_reset(self):
+        check(_lib.lib().hipkkt_kkt_profile_reset(self._h), "hipkkt_kkt_profile_reset")
+
+    def profile(self):
+        p = _lib.Profile()
+        check(_lib.lib().hipkkt_kkt_profile_get(self._h, C.byref(p)), "hipkkt_kkt_profile_get")
+        return p.as_dict()
+
+
+class HipDirectLDLSolver:
+    """An AbstractDirectLDLSolver backend (`ldlsolver_constructor(::Val{:hipldl})`):
+    constructor(KKT, Dsigns, settings), update_values!, scale_values!, refactor!, solve!."""
+
+    matrix_shape = "triu"           # ldlsolver_matrix_shape
+
+    @staticmethod
+    def is_available():             # ldlsolver_is_available: must not throw
+        try:
+            return bool(_lib.lib().hipkkt_available())
+        except Exception:
+            return False
+
+    def __init__(self, KKT, Dsigns, settings=None):
+        L = _lib.lib()
+        KKT = sp.csc_matrix(KKT)
+        KKT.sort_indices()
+        if sp.tril(KKT, -1).nnz:
+            raise ValueError("KKT must be upper triangular (:triu)")
+        self.N = KKT.shape[0]
+        self.nnzK = KKT.nnz
+        self.settings = settings if settings is not None else _lib.default_settings()
+        self._h = C.c_void_p()
+        cp, ri, nz, ds = i64(KKT.indptr), i64(KKT.indices), f64(KKT.data), i64(Dsigns)
+        rc = L.hipkkt_ldl_create(C.byref(self._h), self.N, ptr(cp), ptr(ri), ptr(nz), ptr(ds),
+                                 C.byref(self.settings), 0)
+        if not check(rc, "hipkkt_ldl_create"):
+            raise _lib.HipKKTError("hipkkt_ldl_create reported a numeric failure")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().hipkkt_ldl_destroy(h)
+            self._h = None
+
+    def update_values(self, index, values):
+        idx, v = i64(index), f64(values)
+        check(_lib.lib().hipkkt_ldl_update_values(self._h, ptr(idx), ptr(v), idx.size), "hipkkt_ldl_update_values")
+
+    def scale_values(self, index, scale):
+        idx = i64(index)
+        check(_lib.lib().hipkkt_ldl_scale_values(self._h, ptr(idx), float(scale), idx.size), "hipkkt_ldl_scale_values")
+
+    def refactor(self, K=None):
+        return check(_lib.lib().hipkkt_ldl_refactor(self._h), "hipkkt_ldl_refactor")
+
+    def solve(self, K, x, b):
+        b = f64(b)
+        if x.dtype != np.float64 or x.size != self.N or b.size != self.N:
+            raise ValueError("x, b must be float64 of length N")
+        check(_lib.lib().hipkkt_ldl_solve(self._h, ptr(x), ptr(b)), "hipkkt_ldl_solve")
+
+    def linear_solver_info(self):
+        info = _lib.Info()
+        check(_lib.lib().hipkkt_ldl_info(self._h, C.byref(info)), "hipkkt_ldl_info")
+        return LinearSolverInfo("hipldl", 1, True, info.nnzK, info.nnzL)
+
+    def perm(self):
+        out = np.zeros(self.N, dtype=np.int64)
+        check(_lib.lib().hipkkt_ldl_get_perm(self._h, ptr(out)), "hipkkt_ldl_get_perm")
+        return out

@@ -1,0 +1,177 @@
+/*
+ * hipkkt.h -- C ABI of libhipkkt.so: an MI355X-native (HIP, gfx950) KKT linear-system solver
+ * that drops in behind Clarabel.jl's KKT-solver interfaces.  fp64 throughout.
+ *
+ * Two boundaries are exported; citations are into /root/reference:
+ *
+ *   Level A  hipkkt_ldl_*   replaces an AbstractDirectLDLSolver backend
+ *            contract  src/kktsolvers/direct-ldl/directldl_defaults.jl:1-72
+ *            example   src/kktsolvers/direct-ldl/directldl_qdldl.jl:1-96   (the CPU path)
+ *   Level B  hipkkt_kkt_*   replaces the whole DirectLDLKKTSolver <: AbstractKKTSolver
+ *            contract  src/kktsolvers/kktsolver_defaults.jl:2-48
+ *            example   src/kktsolvers/kktsolver_directldl.jl:5-466
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every array it passes and may free or
+ *     move it as soon as the call returns (the library copies during the call).
+ *   - index arrays are int64 with the caller's `index_base` (1 for Julia, 0 for C/Python).
+ *   - return value: 0 = success; > 0 = numeric failure (non-finite pivot or residual), which the
+ *     reference reports as `false` (directldl_qdldl.jl:79, kktsolver_directldl.jl:411,429);
+ *     < 0 = usage or HIP error (hipkkt_last_error() has the text).
+ *   - one handle = one HIP stream; calls on one handle must be sequential (the reference calls
+ *     its backend from one thread: update_values!* -> refactor! -> solve!*).
+ *   - functions ending in _dev take DEVICE pointers (resident in HBM on the handle's device) and
+ *     are asynchronous on the handle's stream unless they return a status that needs a read-back.
+ */
+#ifndef HIPKKT_H
+#define HIPKKT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPKKT_OK 0
+#define HIPKKT_NUMERIC_FAILURE 1
+#define HIPKKT_ERR_ARG (-1)
+#define HIPKKT_ERR_HIP (-2)
+#define HIPKKT_ERR_INTERNAL (-3)
+
+/* cone kinds (src/cones/cone_api.jl:18-55); dims[] = numel, except PSD: matrix side */
+#define HIPKKT_CONE_ZERO 0
+#define HIPKKT_CONE_NN 1
+#define HIPKKT_CONE_SOC 2
+#define HIPKKT_CONE_PSD 3
+
+/* fill-reducing ordering */
+#define HIPKKT_ORDER_AMD 0      /* approximate minimum degree (what the reference asks QDLDL for) */
+#define HIPKKT_ORDER_ND 1       /* nested dissection over AMD leaves: short, bushy trees (default) */
+#define HIPKKT_ORDER_NATURAL 2
+#define HIPKKT_ORDER_USER 3     /* settings.user_perm */
+
+typedef struct hipkkt_ldl_s *hipkkt_ldl_t;
+typedef struct hipkkt_kkt_s *hipkkt_kkt_t;
+
+/* mirrors the path-relevant fields of Clarabel.Settings (src/settings.jl:110-132) */
+typedef struct {
+    double static_regularization_constant;      /* 1e-8   :118 */
+    double static_regularization_proportional;  /* eps^2  :119 */
+    double dynamic_regularization_eps;          /* 1e-13  :123 */
+    double dynamic_regularization_delta;        /* 2e-7   :124 */
+    double iterative_refinement_reltol;         /* 1e-13  :128 */
+    double iterative_refinement_abstol;         /* 1e-12  :129 */
+    double iterative_refinement_stop_ratio;     /* 5      :131 */
+    int32_t iterative_refinement_max_iter;      /* 10     :130 */
+    int32_t static_regularization_enable;       /* true   :117 */
+    int32_t iterative_refinement_enable;        /* true   :127 */
+    int32_t ordering;                           /* HIPKKT_ORDER_*, default ND */
+    int32_t nd_leaf_size;                       /* sub-domain size below which ND hands over to AMD */
+    int32_t device;                             /* HIP device ordinal, -1 = current */
+    const int64_t *user_perm;                   /* length N, caller's index base; ORDER_USER only */
+    double amd_dense_scale;                     /* 1.5 (directldl_qdldl.jl:24) */
+} hipkkt_settings;
+
+typedef struct {
+    int64_t n, m, p, N;        /* N = n + m + p, p = 2 per sparse second-order cone */
+    int64_t nnzK;              /* entries of the triu KKT matrix */
+    int64_t nnzL;              /* structural nnz(L) (QDLDL's count; what linear_solver_info reports) */
+    int64_t nnzL_stored;       /* incl. explicit zeros of amalgamated supernodes */
+    int64_t nsuper, nlevels, max_front, etree_height;
+    int64_t nHs;               /* length of Hsblocks */
+    int64_t nsparse_soc, sparse_soc_len;
+    double factor_flops;
+    double front_bytes, update_bytes;
+} hipkkt_info;
+
+/* accumulated device time per phase (hipEvents on the handle's stream), for bench.py */
+typedef struct {
+    double update_ms, factor_ms, trisolve_ms, residual_ms, other_ms;
+    int64_t n_update, n_factor, n_trisolve, n_residual;
+    int64_t ir_iterations;     /* refinement rounds beyond the first residual check */
+    int64_t dynamic_regularizations;
+} hipkkt_profile;
+
+/* -------------------------------------------------------------------- general */
+int hipkkt_available(void);                 /* 1 if a gfx950 device is usable; never throws
+                                               (ldlsolver_is_available, directldl_defaults.jl:22-27) */
+const char *hipkkt_last_error(void);
+void hipkkt_default_settings(hipkkt_settings *s);
+const char *hipkkt_version(void);
+
+/* ------------------------------------------- Level A: AbstractDirectLDLSolver */
+/* constructor (directldl_qdldl.jl:6-28): symbolic analysis of the triu CSC matrix K, keeps a
+ * device copy of nzval.  dsigns: +1/-1 expected pivot signs (kktsolver_directldl.jl:112-126). */
+int hipkkt_ldl_create(hipkkt_ldl_t *out, int64_t N, const int64_t *colptr, const int64_t *rowval,
+                      const double *nzval, const int64_t *dsigns, const hipkkt_settings *settings,
+                      int index_base);
+void hipkkt_ldl_destroy(hipkkt_ldl_t h);
+/* update_values! / scale_values! (directldl_qdldl.jl:46-68): index = positions in K.nzval */
+int hipkkt_ldl_update_values(hipkkt_ldl_t h, const int64_t *index, const double *values, int64_t k);
+int hipkkt_ldl_scale_values(hipkkt_ldl_t h, const int64_t *index, double scale, int64_t k);
+/* refactor! (directldl_qdldl.jl:72-81): numeric LDL^T; 1 if some pivot is not finite */
+int hipkkt_ldl_refactor(hipkkt_ldl_t h);
+/* solve! (directldl_qdldl.jl:85-96): x = K^{-1} b, host vectors of length N, x != b allowed */
+int hipkkt_ldl_solve(hipkkt_ldl_t h, double *x, const double *b);
+int hipkkt_ldl_solve_dev(hipkkt_ldl_t h, double *d_x, const double *d_b);
+/* linear_solver_info (directldl_qdldl.jl:35-42) */
+int hipkkt_ldl_info(hipkkt_ldl_t h, hipkkt_info *info);
+int hipkkt_ldl_get_perm(hipkkt_ldl_t h, int64_t *perm /* N, 0-based */);
+
+/* ---------------------------------------------- Level B: AbstractKKTSolver */
+/* constructor (kktsolver_directldl.jl:46-92): P n x n triu CSC, A m x n CSC, cone list.
+ * Does the KKT assembly + data maps (directldl_kkt_assembly.jl:15-175), Dsigns, symbolic LDL. */
+int hipkkt_kkt_create(hipkkt_kkt_t *out, int64_t n, int64_t m,
+                      const int64_t *Pcolptr, const int64_t *Prowval, const double *Pnzval,
+                      const int64_t *Acolptr, const int64_t *Arowval, const double *Anzval,
+                      int64_t ncones, const int32_t *cone_kinds, const int64_t *cone_dims,
+                      const hipkkt_settings *settings, int index_base);
+void hipkkt_kkt_destroy(hipkkt_kkt_t h);
+int hipkkt_kkt_info(hipkkt_kkt_t h, hipkkt_info *info);
+
+/* kktsolver_update! (kktsolver_directldl.jl:197-294) with the cone data the reference reads from
+ * its cones: Hsblocks = get_Hs! output (positive W'W blocks, |Hs| values), and for each sparse
+ * second-order cone its u, v (concatenated) and eta^2.  Scatter, regularise, refactor. */
+int hipkkt_kkt_update_cones(hipkkt_kkt_t h, const double *Hsblocks, const double *soc_u,
+                            const double *soc_v, const double *soc_eta2);
+/* device-native variant: NT scaling + Hs blocks computed on the device from (s, z)
+ * (update_scaling! + get_Hs!, src/cones/coneops_*.jl), then as above.  Returns 1 also when a
+ * point is not interior (update_scaling! returning false). */
+int hipkkt_kkt_update_from_sz(hipkkt_kkt_t h, const double *s, const double *z);
+int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double *d_s, const double *d_z);
+/* kktsolver_update_P! / kktsolver_update_A! (kktsolver_directldl.jl:374-386) */
+int hipkkt_kkt_update_P(hipkkt_kkt_t h, const double *Pnzval);
+int hipkkt_kkt_update_A(hipkkt_kkt_t h, const double *Anzval);
+/* kktsolver_setrhs! (:313-327) and kktsolver_solve! (:346-371, with iterative refinement
+ * :389-449).  lhsx / lhsz may be NULL (Union{Nothing,...}). */
+int hipkkt_kkt_setrhs(hipkkt_kkt_t h, const double *rhsx, const double *rhsz);
+int hipkkt_kkt_solve(hipkkt_kkt_t h, double *lhsx, double *lhsz);
+int hipkkt_kkt_setrhs_dev(hipkkt_kkt_t h, const double *d_rhsx, const double *d_rhsz);
+int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double *d_lhsx, double *d_lhsz);
+/* y = W'W x over all cones with the current scaling (mul_Hs!, coneops_compositecone.jl:138-150);
+ * valid after hipkkt_kkt_update_from_sz*.  Host vectors of length m. */
+int hipkkt_kkt_mul_Hs(hipkkt_kkt_t h, double *y, const double *x);
+
+/* introspection used by the parity tests: the assembled K (triu CSC, 0-based) and data maps */
+int hipkkt_kkt_get_pattern(hipkkt_kkt_t h, int64_t *colptr /* N+1 */, int64_t *rowval /* nnzK */);
+int hipkkt_kkt_get_values(hipkkt_kkt_t h, double *nzval /* nnzK, un-regularised */);
+int hipkkt_kkt_get_maps(hipkkt_kkt_t h, int64_t *mapP, int64_t *mapA, int64_t *mapHs,
+                        int64_t *map_diag_full, int64_t *map_soc_u, int64_t *map_soc_v,
+                        int64_t *map_soc_D, int64_t *dsigns);   /* any may be NULL */
+int hipkkt_kkt_get_perm(hipkkt_kkt_t h, int64_t *perm /* N, 0-based */);
+int hipkkt_kkt_get_Hs(hipkkt_kkt_t h, double *Hsblocks /* |Hs|, positive */);
+double hipkkt_kkt_last_regularizer(hipkkt_kkt_t h);
+int64_t hipkkt_kkt_last_ir_iterations(hipkkt_kkt_t h);
+
+/* run on the caller's stream (e.g. torch's current stream) instead of the handle's own */
+int hipkkt_kkt_set_stream(hipkkt_kkt_t h, void *hip_stream);
+int hipkkt_kkt_synchronize(hipkkt_kkt_t h);
+/* per-phase device timing */
+int hipkkt_kkt_profile_enable(hipkkt_kkt_t h, int enable);
+int hipkkt_kkt_profile_reset(hipkkt_kkt_t h);
+int hipkkt_kkt_profile_get(hipkkt_kkt_t h, hipkkt_profile *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,7 @@
+import sys; sys.path.insert(0,'/root/repo/scratch'); sys.path.insert(0,'/root/repo')
+from run_sym import *
+pb=problems.config2(n=100000)
+import sys
+for leaf in (200,1000,4000,16000):
+    print('== ND leaf',leaf, flush=True); run(pb,1,leaf)
+print('== AMD', flush=True); run(pb,0)
