@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- KKT factorize+solve throughput (fp64) per IPM iteration on MI355X.
+
+One "step" = one interior-point iteration's KKT work on the BASELINE.json workload
+(configs[1]: random sparse SOCP, n=100k, m=200k, NN(100k)+1000xSOC(100)):
+    1 x cone scaling + value scatter + static regularisation   (kktsolver_update!, a5-a9)
+    1 x numeric LDL^T                                            (refactor!, a11)
+    3 x solve with iterative refinement                          (kktsolver_solve!, a13-a14:
+        constant RHS, affine RHS, combined RHS -- kktsystem.jl:87-88,170-171)
+with (s, z) and the three right-hand sides already resident in HBM.  N > 1 GPUs: every rank
+runs the same workload on its own problem instance (seed + rank), no data-path collective
+(independent problems shard: SURVEY.md section 8e) -> weak scaling; one tiny RCCL all-reduce
+of the timing at the end.
+
+Usage:  python bench.py --gpus N --steps K --warmup W
+        (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(info):
+    """bytes per unit of work on the scalar CSC layout the reference
+    uses (8 B value + 4 B index per entry of L), with QDLDL's structural nnz(L)."""
+    N, nnzK, nnzL = info["N"], info["nnzK"], info["nnzL"]
+    nHs, slen = info["nHs"], info["sparse_soc_len"]
+    B_solve = 2 * nnzL * 12 + 2 * (N + 1) * 4 + 6 * N * 8
+    B_spmv = nnzK * 12 + (N + 1) * 4 + 3 * N * 8
+    B_upd = (nHs + 2 * slen) * 20 + N * 28
+    B_fact = nnzK * 12 + nnzL * 12 + N * 8
+    return dict(solve=B_solve, spmv=B_spmv, update=B_upd, factor=B_fact)
+
+
+def cpu_baseline(pb, n_units):
+    """The oracle (C restatement of the reference's QDLDL path, 1 thread, AMD ordering) timed on
+    this box's host: `n_units` IPM-iteration units after one warm-up.  TEST INFRASTRUCTURE used
+    only as the reported baseline, never as the thing measured."""
+    import subprocess
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "libkktoracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    from tests.oracle_bindings import make_oracle
+    from cuclarabel_amd import _lib
+    o0 = make_oracle(pb, perm=np.arange(pb.n + pb.m + 2 * sum(1 for c in pb.cones if c.kind == 2 and c.dim > 4)))
+    perm, _ = _lib.symbolic_analyse(o0.K(), ordering=_lib.ORDER_AMD)      # the reference orders with AMD
+    del o0
+    o = make_oracle(pb, perm=perm)
+    rng = np.random.default_rng(0)
+    rhs = [(rng.standard_normal(pb.n), rng.standard_normal(pb.m)) for _ in range(3)]
+    times = []
+    ir = 0
+    for it in range(n_units + 1):
+        t0 = time.perf_counter()
+        assert o.update_scaling(pb.s0, pb.z0)
+        assert o.kktsolver_update()
+        for rx, rz in rhs:
+            o.kktsolver_setrhs(rx, rz)
+            ok, _, _ = o.kktsolver_solve()
+            assert ok
+            ir += o.last_ir_iters
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return dict(value=1.0 / med, unit="KKT factorize+solve/s", cores=1, kind="port",
+                sample=f"{n_units} timed units (+1 warm-up) of the same workload, median; oracle/libkktoracle.so "
+                       f"(scalar up-looking LDL', AMD ordering, nnzL={o.nnzL}), host threads=1 of {os.cpu_count()}",
+                ms_per_unit=med * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100_000, help="primal dimension of the SOCP (BASELINE: 100000)")
+    ap.add_argument("--ordering", default="nd", choices=["nd", "amd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-units", type=int, default=4)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cuclarabel_amd import _lib, problems
+    from cuclarabel_amd.kktsolver import HipKKTSolver
+
+    pb = problems.config2(seed=1002 + rank, n=args.n)
+    st = _lib.default_settings(device=local_rank,
+                               ordering=_lib.ORDER_ND if args.ordering == "nd" else _lib.ORDER_AMD)
+    t0 = time.perf_counter()
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
+    setup_s = time.perf_counter() - t0
+    stream = torch.cuda.current_stream(dev)
+    ks.set_stream(stream.cuda_stream)
+
+    rng = np.random.default_rng(0)
+    d_s = torch.from_numpy(pb.s0).to(dev)
+    d_z = torch.from_numpy(pb.z0).to(dev)
+    rhs = [(torch.from_numpy(rng.standard_normal(pb.n)).to(dev), torch.from_numpy(rng.standard_normal(pb.m)).to(dev))
+           for _ in range(3)]
+    lx = torch.zeros(pb.n, dtype=torch.float64, device=dev)
+    lz = torch.zeros(pb.m, dtype=torch.float64, device=dev)
+
+    def step():
+        if not ks.kktsolver_update_from_sz_dev(d_s.data_ptr(), d_z.data_ptr()):
+            raise RuntimeError("factorisation failed")
+        for rx, rz in rhs:
+            ks.kktsolver_setrhs_dev(rx.data_ptr(), rz.data_ptr())
+            if not ks.kktsolver_solve_dev(lx.data_ptr(), lz.data_ptr()):
+                raise RuntimeError("solve failed")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ks.profile_enable(True)
+    ks.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ks.profile()
+    ks.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # RCCL, 8 bytes
+        elapsed = float(t.item())
+
+    if rank == 0:
+        info = ks.info
+        B = algorithmic_bytes(info)
+        phases = {}
+        for name, ms_key, n_key, byt in (("factor", "factor_ms", "n_factor", B["factor"]),
+                                         ("trisolve", "trisolve_ms", "n_trisolve", B["solve"]),
+                                         ("residual", "residual_ms", "n_residual", B["spmv"]),
+                                         ("update", "update_ms", "n_update", B["update"])):
+            cnt = max(prof[n_key], 1)
+            avg_ms = prof[ms_key] / cnt
+            gbs = byt / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            phases[name] = dict(total_ms=prof[ms_key], launches=prof[n_key], avg_ms=avg_ms,
+                                algorithmic_bytes=byt, achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
+        dominant = max(("factor", "trisolve"), key=lambda k: phases[k]["total_ms"])
+        d = phases[dominant]
+        roofline = dict(kernel=dominant, bound="hbm", achieved=d["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=d["frac"], traffic=None,
+                        note="phase = all kernel launches of one %s; algorithmic bytes per SURVEY.md 8(d)" % dominant)
+        out = {
+            "metric": "KKT factorize+solve/sec (fp64) per IPM iter, 100k-var SOCP",
+            "value": world * args.steps / elapsed,
+            "unit": "KKT factorize+solve/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2: random sparse SOCP n=%d m=%d NN(%d)+%dxSOC(100), P=diag, A 4 nnz/row local "
+                                   "window; 1 update + 1 LDL' refactor + 3 solves with IR per step" %
+                                   (pb.n, pb.m, pb.n, pb.n // 100),
+                       "N": info["N"], "nnzK": info["nnzK"], "nnzL": info["nnzL"], "nnzL_stored": info["nnzL_stored"],
+                       "fill_ratio": info["nnzL"] / info["nnzK"], "etree_height": info["etree_height"],
+                       "nsuper": info["nsuper"], "levels": info["nlevels"], "max_front": info["max_front"],
+                       "factor_flops": info["factor_flops"], "ordering": args.ordering,
+                       "ir_rounds_per_step": prof["ir_iterations"] / max(args.steps, 1),
+                       "setup_s": setup_s, "parallelism": "independent problems per GPU"},
+            "roofline": roofline,
+            "phases": phases,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pb, args.cpu_units)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

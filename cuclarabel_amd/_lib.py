@@ -64,6 +64,7 @@ SYMBOLS = {
     "hipkkt_last_error": (C.c_char_p, []),
     "hipkkt_default_settings": (None, [_P]),
     "hipkkt_version": (C.c_char_p, []),
+    "hipkkt_symbolic_analyse": (C.c_int, [C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "hipkkt_ldl_create": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int]),
     "hipkkt_ldl_destroy": (None, [_P]),
     "hipkkt_ldl_update_values": (C.c_int, [_P, _P, _P, C.c_int64]),
@@ -152,3 +153,17 @@ def i64(a):
 
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def symbolic_analyse(K_triu, ordering=ORDER_ND, nd_leaf_size=0):
+    """Host-only ordering + structure statistics of a triu CSC pattern -> (perm, info dict)."""
+    import scipy.sparse as sp
+    K = sp.csc_matrix(K_triu)
+    K.sort_indices()
+    N = K.shape[0]
+    cp, ri = i64(K.indptr), i64(K.indices)
+    perm = np.zeros(N, dtype=np.int64)
+    info = Info()
+    check(lib().hipkkt_symbolic_analyse(N, ptr(cp), ptr(ri), 0, ordering, nd_leaf_size, ptr(perm), C.byref(info)),
+          "hipkkt_symbolic_analyse")
+    return perm, info.as_dict()

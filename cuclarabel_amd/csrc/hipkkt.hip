@@ -433,6 +433,25 @@ void hipkkt_default_settings(hipkkt_settings* s)
     s->amd_dense_scale = 1.5;
 }
 
+int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* rowval, int base, int ordering,
+                            int nd_leaf_size, int64_t* perm_out, hipkkt_info* info_out)
+{
+    return guarded([&]() {
+        if (!colptr || !rowval || N <= 0 || N > 2000000000 || (base != 0 && base != 1))
+            throw ArgError("hipkkt_symbolic_analyse: bad argument");
+        if (ordering != HIPKKT_ORDER_AMD && ordering != HIPKKT_ORDER_ND && ordering != HIPKKT_ORDER_NATURAL)
+            throw ArgError("hipkkt_symbolic_analyse: ordering must be AMD, ND or NATURAL");
+        SymbolicOptions opt;
+        opt.ordering = ordering;
+        if (nd_leaf_size > 0) opt.nd_leaf_size = nd_leaf_size;
+        Symbolic S;
+        analyse((int)N, colptr, rowval, base, opt, S);
+        if (perm_out) for (int64_t i = 0; i < N; ++i) perm_out[i] = S.perm[i];
+        if (info_out) { std::memset(info_out, 0, sizeof(*info_out)); fill_info(S, info_out); }
+        return HIPKKT_OK;
+    });
+}
+
 // ------------------------------------------------------------------------ level A
 int hipkkt_ldl_create(hipkkt_ldl_t* out, int64_t N, const int64_t* colptr, const int64_t* rowval,
                       const double* nzval, const int64_t* dsigns, const hipkkt_settings* settings, int base)

@@ -22,7 +22,7 @@ enum OrderingKind { ORDER_AMD = 0, ORDER_ND = 1, ORDER_NATURAL = 2, ORDER_USER =
 struct SymbolicOptions {
     int ordering = ORDER_ND;
     double amd_dense_scale = 1.5;     // directldl_qdldl.jl:24
-    int nd_leaf_size = 200;
+    int nd_leaf_size = 1000;
     // relaxed supernode amalgamation: merge a child into its parent when the merged supernode
     // has <= relax_cols[k] columns and the fraction of explicit zeros stays <= relax_zeros[k]
     int relax_cols[3] = {8, 32, 128};

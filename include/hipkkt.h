@@ -99,6 +99,12 @@ const char *hipkkt_last_error(void);
 void hipkkt_default_settings(hipkkt_settings *s);
 const char *hipkkt_version(void);
 
+/* host-only symbolic analysis of a triu CSC pattern (no GPU needed): fill-reducing permutation
+ * (perm[k] = 0-based original index eliminated k-th) and the structure statistics.  This is the
+ * setup step QDLDL.qdldl(...; logical=true) performs for the reference (directldl_qdldl.jl:18-25). */
+int hipkkt_symbolic_analyse(int64_t N, const int64_t *colptr, const int64_t *rowval, int index_base,
+                            int ordering, int nd_leaf_size, int64_t *perm_out, hipkkt_info *info_out);
+
 /* ------------------------------------------- Level A: AbstractDirectLDLSolver */
 /* constructor (directldl_qdldl.jl:6-28): symbolic analysis of the triu CSC matrix K, keeps a
  * device copy of nzval.  dsigns: +1/-1 expected pivot signs (kktsolver_directldl.jl:112-126). */
