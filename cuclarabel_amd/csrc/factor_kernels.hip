@@ -1,0 +1,552 @@
+// Numeric supernodal multifrontal LDL^T (gfx950, wave64).
+//
+// Replaces QDLDL.refactor! (call site /root/reference/src/kktsolvers/direct-ldl/
+// directldl_qdldl.jl:72-81).  Same pivot rule -- D_k*sign_k < eps  =>  D_k = sign_k*delta -- applied
+// at pivot time inside the dense panel; no pivoting, static structure.
+//
+// Per level of the assembly tree, three kernels:
+//   k_front_wave    fronts that fit one wave's LDS slice (f <= 64): assemble, factor and form the
+//                   update block entirely in LDS, one wave per front, four fronts per workgroup.
+//   k_panel         larger fronts, one workgroup each: zero + scatter K (+ static eps*sign) +
+//                   gather the children's update entries that land in the panel, then a
+//                   right-looking blocked LDL^T with the current block column staged in LDS.
+//   k_schur         the update block U = (children pass-through) - L21 D L21^T, tiled 64x64 over
+//                   many workgroups per front so the few big fronts near the root still fill CUs.
+// Every extend-add is a gather by the owner of the target, children in a fixed order, each child
+// through an injective ascending map: sums are reproducible run to run (no atomics).
+//
+// Loads are issued in explicit batches before first use: a one-load-then-use loop serialises
+// on HBM/L2 latency (the first version of these kernels ran 10x slower for that reason).
+#include "kernels.hpp"
+
+namespace hipkkt {
+
+__device__ inline double rl_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// Ordering of LDS traffic inside ONE wave: the LDS executes a wave's DS instructions in issue order, so
+// a ds_write followed by another lane's ds_read of that address needs no hardware fence -- only the
+// compiler must not reorder or cache across the point.  (A seq_cst wavefront fence also drains
+// outstanding global stores/loads, which put ~1 us into every pivot step.)
+#define WAVE_FENCE() asm volatile("" ::: "memory")
+
+// first index t in [0, n) with arr[t] >= v  (arr ascending)
+__device__ inline int lower_bound_dev(const int* __restrict__ arr, int n, int v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (arr[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// =====================================================================================
+//  small fronts: one wave per front, LDS slice = panel (f x nc) + update block (nb x nb)
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int count, int slice)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= count) return;
+    const TreeDev& T = A.T;
+    const int s = T.sched[begin + item];
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const int f = nc + nb;
+    double* __restrict__ F = A.fronts + T.front_off[s];
+    double* __restrict__ U = A.upd + T.upd_off[s];
+    double* P = smem + (size_t)wv * slice;       // f x nc, ld f
+    double* Us = P + f * nc;                     // nb x nb, ld nb
+
+    for (int i = lane; i < f * nc + nb * nb; i += 64) P[i] = 0.0;
+    WAVE_FENCE();
+    {   // K entries
+        const int64_t e0 = T.kptr[s];
+        const int ne = (int)(T.kptr[s + 1] - e0);
+        for (int e = lane; e < ne; e += 64) P[T.kdst[e0 + e]] = A.Kval[T.ksrc[e0 + e]];
+    }
+    WAVE_FENCE();
+    if (A.eps) {
+        const double eps = *A.eps;
+        if (lane < nc) P[lane + lane * f] += eps * (double)T.psign[c0 + lane];
+    }
+    // children, one after the other: panel part and pass-through part in one sweep
+    for (int ce = T.child_ptr[s]; ce < T.child_ptr[s + 1]; ++ce) {
+        const int c = T.child_idx[ce];
+        const int64_t crp = T.rowptr[c];
+        const int nbc = (int)(T.rowptr[c + 1] - crp);
+        const double* __restrict__ Uc = A.upd + T.upd_off[c];
+        const int* __restrict__ relc = T.rel + crp;
+        WAVE_FENCE();
+        for (int b = 0; b < nbc; ++b) {
+            const int rb = relc[b];
+            for (int a = b + lane; a < nbc; a += 64) {
+                const int ra = relc[a];
+                const double v = Uc[a + (int64_t)b * nbc];
+                if (rb < nc) P[ra + rb * f] += v;
+                else Us[(ra - nc) + (rb - nc) * nb] += v;
+            }
+        }
+    }
+    WAVE_FENCE();
+    // factor the panel: lane = row
+    const double my_sg = (lane < nc) ? (double)T.psign[c0 + lane] : 1.0;
+    for (int k = 0; k < nc; ++k) {
+        double d = P[k + k * f];
+        const double sg = rl_f64(my_sg, k);
+        const bool reg = (d * sg < A.dyn_eps);
+        if (reg) d = sg * A.dyn_delta;
+        const double dinv = 1.0 / d;
+        if (lane == 0) {
+            if (reg) atomicAdd(&A.flags[0], 1);
+            if (!isfinite(dinv)) A.flags[1] = 1;
+            A.Dinv[c0 + k] = dinv;
+        }
+        if (lane > k && lane < f) {
+            const double vik = P[lane + k * f];
+            const double lik = vik * dinv;
+            const int jmax = min(lane, nc - 1);
+            for (int j = k + 1; j <= jmax; ++j) P[lane + j * f] -= lik * P[j + k * f];
+        }
+        WAVE_FENCE();
+        if (lane > k && lane < f) P[lane + k * f] *= dinv;
+        if (lane == k) P[k + k * f] = d;
+        WAVE_FENCE();
+    }
+    // write L and D
+    for (int i = lane; i < f * nc; i += 64) {
+        const int j = i / f, r = i - j * f;
+        if (r >= j) F[i] = P[i];
+    }
+    // update block: U(a,b) = Us(a,b) - sum_k L(a,k) d_k L(b,k), lane = row a
+    if (lane < nb) {
+        const int a = lane;
+        for (int b = 0; b <= a; ++b) {
+            double acc = 0.0;
+            for (int k = 0; k < nc; ++k) acc = fma(P[nc + a + k * f] * P[k + k * f], P[nc + b + k * f], acc);
+            U[a + (int64_t)b * nb] = Us[a + b * nb] - acc;
+        }
+    }
+}
+
+// =====================================================================================
+//  panel kernel: one workgroup per front, the whole f x nc panel resident in LDS
+//  (the symbolic phase splits wider supernodes so that f*nc fits: SymbolicOptions::panel_cap).
+//  Global traffic: K values and the children's update entries in (batched, independent loads),
+//  L and D out once.
+//    children   every wave owns the panel columns j = wave (mod #waves) and applies the extend-add
+//               items of its columns in order -- no barrier between children, fixed summation order.
+//    per 16-column block: diagonal block in the registers of one wave (readlane broadcasts),
+//               rows below by one thread per row (TRSM against the d*L copy in LDS), trailing
+//               update by 4x4 register tiles whose rows are 64 apart (bank-conflict free).
+// =====================================================================================
+constexpr int NB = 16;
+constexpr int kBdCols = 128;       // trailing columns per block whose d*L copy is kept (nc - 16 <= 128 enforced by host)
+
+// apply the extend-add items [i0, i1) (whole columns, owned by this wave) into the LDS panel P (ld f):
+// eight items in flight -- one round of descriptor loads, one round of (rel, value) loads, then
+// the LDS adds in item order
+__device__ inline void apply_items_panel(const TreeDev& T, const double* __restrict__ upd, double* P, int f,
+                                         int64_t i0, int64_t i1, int lane)
+{
+    for (int64_t ii = i0; ii < i1; ii += 8) {
+        ExtItem it[8];
+        double v[8];
+        int tg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            it[q] = T.items[min(ii + q, i1 - 1)];
+            if (ii + q >= i1) it[q].cnt = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool ok = lane < it[q].cnt;
+            v[q] = ok ? upd[it[q].uoff + lane] : 0.0;
+            tg[q] = ok ? T.rel[it[q].relstart + lane] + it[q].tcol * f : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (tg[q] >= 0) P[tg[q]] += v[q];
+            // long child columns: remaining 64-row blocks
+            for (int t = lane + 64; t < it[q].cnt; t += 64)
+                P[T.rel[it[q].relstart + t] + it[q].tcol * f] += upd[it[q].uoff + t];
+        }
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = BS / 64;
+    const TreeDev& T = A.T;
+    const int s = T.sched[begin + blockIdx.x];
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const int f = nc + nb;
+    double* __restrict__ F = A.fronts + T.front_off[s];
+
+    double* sh_d = smem;                          // NB
+    double* sh_dinv = smem + NB;                  // NB
+    double* Lb = smem + 2 * NB;                   // NB x NB: Lb[j*NB + t] = d_t * L(j,t), t < j
+    double* colb = smem + 2 * NB + NB * NB;       // NB: pivot column broadcast buffer
+    double* Bd = smem + 3 * NB + NB * NB;         // NB x kBdCols: d_k * L(j,k) for the trailing columns
+    double* P = Bd + NB * kBdCols;                // f x nc, ld f (+ 256 doubles of slack behind it)
+
+    HIPKKT_STAMP(A, 0);
+    const long long clk0 = A.stamps ? clock64() : 0;
+    // ---- 1. zero the panel
+    for (int i = tid; i < f * nc; i += BS) P[i] = 0.0;
+    __syncthreads();
+    HIPKKT_STAMP(A, 1);
+    // ---- 2. scatter K, four entries per thread in flight
+    {
+        const int64_t e0 = T.kptr[s];
+        const int ne = (int)(T.kptr[s + 1] - e0);
+        for (int base = 0; base < ne; base += 4 * BS) {
+            int src[4], dst[4];
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = base + q * BS + tid;
+                src[q] = e < ne ? T.ksrc[e0 + e] : -1;
+                dst[q] = e < ne ? T.kdst[e0 + e] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = src[q] >= 0 ? A.Kval[src[q]] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (dst[q] >= 0) P[dst[q]] = v[q];
+        }
+    }
+    __syncthreads();
+    if (A.eps) {
+        const double eps = *A.eps;
+        for (int k = tid; k < nc; k += BS) P[k + k * f] += eps * (double)T.psign[c0 + k];
+    }
+    __syncthreads();
+    HIPKKT_STAMP(A, 2);
+    // ---- 3. children: each wave applies a slice of whole columns' items (host-cut, 16 slices)
+    {
+        const int64_t* __restrict__ wc = T.wave_cut + (int64_t)s * 17;
+        constexpr int SPW = 16 / NW > 0 ? 16 / NW : 1;      // slices per wave
+        if (wv * SPW < 16) {
+            const int64_t i0 = wc[wv * SPW], i1 = wc[min(16, (wv + 1) * SPW)];
+            if (i1 > i0) apply_items_panel(T, A.upd, P, f, i0, i1, lane);
+        }
+    }
+    HIPKKT_STAMP(A, 3);
+    long long t_i = 0, t_ii = 0, t_iii = 0, t0 = 0;
+    // ---- 4. blocked right-looking factorisation inside LDS
+    for (int kb = 0; kb < nc; kb += NB) {
+        const int w = min(NB, nc - kb);
+        __syncthreads();
+        if (A.stamps) t0 = wall_clock64();
+        // (i) diagonal block by wave 0, wave-synchronous through LDS: lane (i = lane & 15, g = lane >> 4)
+        //     holds a(i, 4g .. 4g+3); per pivot the column is broadcast through colb
+        if (wv == 0) {
+            const int i = lane & 15, g = lane >> 4;
+            const double my_sg = (lane < w) ? (double)T.psign[c0 + kb + lane] : 1.0;
+            int nreg = 0;
+            bool bad = false;
+            double a4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * g + q;
+                a4[q] = (i < w && j <= i) ? P[(kb + i) + (kb + j) * f] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (k < w) {
+                    // owner lanes of column k publish it (unscaled: v_ik = l_ik d_k; v_kk = raw pivot)
+                    if (g == (k >> 2)) colb[i] = a4[k & 3];
+                    WAVE_FENCE();
+                    double d = colb[k];
+                    const double sg = rl_f64(my_sg, k);
+                    const bool reg = (d * sg < A.dyn_eps);
+                    if (reg) d = sg * A.dyn_delta;
+                    const double dinv = 1.0 / d;
+                    const double lik = colb[i] * dinv;
+                    nreg += reg ? 1 : 0;
+                    bad = bad || !isfinite(dinv);
+                    if (lane == 0) {
+                        sh_d[k] = d;
+                        sh_dinv[k] = dinv;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = 4 * g + q;
+                        const double vjk = colb[j];
+                        if (j > k && j <= i) a4[q] = fma(-lik, vjk, a4[q]);
+                    }
+                    if (g == (k >> 2)) {
+                        if (i > k) a4[k & 3] = lik;           // scaled L(i,k)
+                        else if (i == k) a4[k & 3] = d;
+                    }
+                    WAVE_FENCE();
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * g + q;
+                if (i < w && j <= i) P[(kb + i) + (kb + j) * f] = a4[q];
+                if (i < w && j < i) Lb[i * NB + j] = a4[q] * sh_d[j];
+            }
+            if (lane < w) A.Dinv[c0 + kb + lane] = sh_dinv[lane];
+            if (lane == 0) {
+                if (nreg) atomicAdd(&A.flags[0], nreg);
+                if (bad) A.flags[1] = 1;
+            }
+        }
+        __syncthreads();
+        if (A.stamps) { long long t1 = wall_clock64(); t_i += t1 - t0; t0 = t1; }
+        // (ii) rows below the block: L(i,j) = (A(i,j) - sum_{t<j} L(i,t) * [d_t L(j,t)]) / d_j
+        for (int i = kb + w + tid; i < f; i += BS) {
+            double l[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) l[j] = (j < w) ? P[i + (kb + j) * f] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < w) {
+                    double acc = l[j];
+#pragma unroll
+                    for (int t = 0; t < j; ++t) acc = fma(-l[t], Lb[j * NB + t], acc);
+                    l[j] = acc * sh_dinv[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) if (j < w) P[i + (kb + j) * f] = l[j];
+        }
+        __syncthreads();
+        if (A.stamps) { long long t1 = wall_clock64(); t_ii += t1 - t0; t0 = t1; }
+        // (iii) trailing update of the remaining panel columns: wave tiles of (4 x 64 rows) x 4 cols.
+        //       Bd[k][c] = d_k L(g0 + c, k) is built once per block so the inner loop is 8 LDS reads
+        //       per 16 FMAs; rows past f read the slack behind the panel and are masked at the store.
+        const int g0 = kb + w;
+        const int Tc = nc - g0, Tr = f - g0;
+        if (Tc > 0) {
+            for (int idx = tid; idx < NB * Tc; idx += BS) {
+                const int k = idx / Tc, c = idx - k * Tc;
+                Bd[k * kBdCols + c] = (k < w) ? P[(g0 + c) + (kb + k) * f] * sh_d[k] : 0.0;
+            }
+            __syncthreads();
+            const int ncg = (Tc + 3) >> 2, nrb = (Tr + 255) >> 8;
+            for (int wt = wv; wt < ncg * nrb; wt += NW) {
+                const int cg = wt / nrb, rb = wt - cg * nrb;
+                const int cb = 4 * cg;                          // column offset from g0
+                const int ib = g0 + 256 * rb + lane;            // rows ib + 64 a
+                if (256 * rb + 255 < cb) continue;              // wholly above the diagonal
+                double acc[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 4
+                for (int k = 0; k < NB; ++k) {
+                    const double* __restrict__ col = P + (kb + k) * f + ib;
+                    const double* __restrict__ bd = Bd + k * kBdCols + cb;
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) av[a] = col[64 * a];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bv[b] = bd[b];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int j = g0 + cb + b;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int i = ib + 64 * a;
+                        if (j < nc && i < f && i >= j) P[i + j * f] -= acc[a][b];
+                    }
+                }
+            }
+        }
+        if (A.stamps) { __syncthreads(); long long t1 = wall_clock64(); t_iii += t1 - t0; }
+    }
+    __syncthreads();
+    HIPKKT_STAMP(A, 4);
+    // ---- 5. write L and D (lower part of the panel)
+    for (int idx = tid; idx < f * nc; idx += BS) {
+        const int j = idx / f, r = idx - j * f;
+        if (r >= j) F[idx] = P[idx];
+    }
+    __syncthreads();
+    HIPKKT_STAMP(A, 5);
+    if (A.stamps && blockIdx.x == 0 && tid == 0) {
+        A.stamps[A.stamp_row * 16 + 8] = t_i;
+        A.stamps[A.stamp_row * 16 + 9] = t_ii;
+        A.stamps[A.stamp_row * 16 + 10] = t_iii;
+        A.stamps[A.stamp_row * 16 + 11] = f;
+        A.stamps[A.stamp_row * 16 + 12] = nc;
+        A.stamps[A.stamp_row * 16 + 13] = T.child_ptr[s + 1] - T.child_ptr[s];
+        A.stamps[A.stamp_row * 16 + 14] = clock64() - clk0;
+    }
+}
+
+// =====================================================================================
+//  Schur complement: U(TSxTS tile) = sum over children of their pass-through entries
+//                                    - L21 D L21^T,   one workgroup per tile
+// =====================================================================================
+constexpr int TS = 64;     // tile side
+constexpr int KC = 16;     // k-chunk staged in LDS
+
+__global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin)
+{
+    __shared__ double As[KC][TS + 4];     // L21 rows of the tile's row range
+    __shared__ double Bs[KC][TS + 4];     // L21 rows of the tile's column range, times d_k
+    __shared__ double Ct[TS][TS + 1];     // the tile, [col][row]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TreeDev& T = A.T;
+    const int2 tl = tiles[tile_begin + blockIdx.x];
+    const int s = tl.x;
+    const int ti = tl.y >> 16, tj = tl.y & 0xffff;
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + T.front_off[s];
+    double* __restrict__ U = A.upd + T.upd_off[s];
+    const int r0 = ti * TS, q0 = tj * TS;                 // tile origin inside U
+    const int nr = min(TS, nb - r0), nq = min(TS, nb - q0);
+
+    // thread -> 4x4 micro-tile: rows tx + 16 a, cols 4 ty + b  (rows 16 apart: conflict-free LDS reads)
+    const int tx = tid & 15, ty = tid >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+
+    for (int k0 = 0; k0 < nc; k0 += KC) {
+        const int kw = min(KC, nc - k0);
+        {
+            const int k = tid >> 4, rr = (tid & 15) * 4;
+            double av[4], bv[4];
+            const double dk = (k < kw) ? F[(k0 + k) + (int64_t)(k0 + k) * f] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                av[q] = (k < kw && rr + q < nr) ? F[(nc + r0 + rr + q) + (int64_t)(k0 + k) * f] : 0.0;
+                bv[q] = (k < kw && rr + q < nq) ? F[(nc + q0 + rr + q) + (int64_t)(k0 + k) * f] : 0.0;
+            }
+            __syncthreads();           // previous chunk fully consumed
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                As[k][rr + q] = av[q];
+                Bs[k][rr + q] = bv[q] * dk;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < KC; ++k) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[k][tx + 16 * a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = Bs[k][4 * ty + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) Ct[4 * ty + b][tx + 16 * a] = -acc[a][b];
+    __syncthreads();
+    // children pass-through: wave wv owns tile columns q = wv (mod 4); items of a column in order
+    {
+        const int64_t lbase = (int64_t)c0 + T.rowptr[s] + nc + q0;
+        const int rlo = nc + r0;
+        for (int q = wv; q < nq; q += 4) {
+            const int64_t i0 = T.item_ptr[lbase + q], i1 = T.item_ptr[lbase + q + 1];
+            double* colp = &Ct[q][0];
+            for (int64_t ii = i0; ii < i1; ii += 2) {
+                ExtItem it[2];
+                int alo[2], ahi[2], r[2];
+                double v[2];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    if (ii + z < i1) it[z] = T.items[ii + z];
+                    else { it[z] = it[0]; it[z].cnt = 0; }
+                }
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const int* __restrict__ cc = T.cuts + T.cut_ptr[it[z].child];
+                    alo[z] = (it[z].cnt > 0) ? max(cc[ti], it[z].b) : 0;
+                    ahi[z] = (it[z].cnt > 0) ? cc[ti + 1] : 0;
+                }
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const int a = alo[z] + lane;          // at most 64 rows of a tile
+                    const bool ok = a < ahi[z];
+                    const int t = a - it[z].b;
+                    v[z] = ok ? A.upd[it[z].uoff + t] : 0.0;
+                    r[z] = ok ? T.rel[it[z].relstart + t] - rlo : -1;
+                }
+#pragma unroll
+                for (int z = 0; z < 2; ++z) if (r[z] >= 0) colp[r[z]] += v[z];
+            }
+        }
+    }
+    __syncthreads();
+    // store the lower part of the tile
+    for (int idx = tid; idx < TS * TS; idx += 256) {
+        const int b = idx >> 6, a = idx & 63;
+        if (a < nr && b < nq && (r0 + a) >= (q0 + b)) U[(r0 + a) + (int64_t)(q0 + b) * nb] = Ct[b][a];
+    }
+}
+
+size_t panel_lds_bytes(int fmax, int panel_max)
+{
+    (void)fmax;
+    return ((size_t)3 * NB + NB * NB + NB * kBdCols + (size_t)panel_max + 256) * sizeof(double);
+}
+
+static void init_factor_lds()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void launch_front_wave(const FactorArgs& a, int begin, int count, int slice_doubles, hipStream_t st)
+{
+    if (count <= 0) return;
+    init_factor_lds();
+    hipLaunchKernelGGL(k_front_wave, dim3((count + 3) / 4), dim3(256), (size_t)4 * slice_doubles * sizeof(double), st,
+                       a, begin, count, slice_doubles);
+}
+void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
+{
+    if (count <= 0) return;
+    init_factor_lds();
+    if (bs == 1024) hipLaunchKernelGGL(k_panel<1024>, dim3(count), dim3(1024), lds, st, a, begin);
+    else if (bs == 512) hipLaunchKernelGGL(k_panel<512>, dim3(count), dim3(512), lds, st, a, begin);
+    else hipLaunchKernelGGL(k_panel<256>, dim3(count), dim3(256), lds, st, a, begin);
+}
+void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st)
+{
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_schur, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin);
+}
+
+}  // namespace hipkkt

@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -57,9 +58,11 @@ struct DBuf {
 };
 
 struct Launch {
-    int begin, count, bs;
-    size_t lds_factor, lds_solve;
-    int nbk;
+    int begin, count;
+    bool small;                 // one wave per front
+    int bs_panel, nbk, slice;   // panel kernel block size / block-column width; small-front LDS slice
+    size_t lds_panel, lds_solve;
+    int tile_begin, ntiles;     // Schur tiles of this launch's fronts
 };
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
@@ -102,11 +105,45 @@ public:
         a.flags = flags.p;
         a.dyn_eps = dyn_eps;
         a.dyn_delta = dyn_delta;
-        for (const Launch& L : launches) {
-            a.nbk = L.nbk;
-            launch_factor(a, L.begin, L.count, L.bs, L.lds_factor, stream);
+        a.stamps = nullptr;
+        a.stamp_row = 0;
+        static const bool want_stamps = std::getenv("HIPKKT_STAMPS") != nullptr;
+        if (want_stamps) {
+            if (!stamps.p) { stamps.alloc(launches.size() * 16); }
+            stamps.zero(stream);
+            a.stamps = (long long*)stamps.p;
         }
+        int li = 0;
+        for (const Launch& L : launches) {
+            a.stamp_row = li++;
+            if (L.small) {
+                launch_front_wave(a, L.begin, L.count, L.slice, stream);
+            } else {
+                a.nbk = L.nbk;
+                launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, stream);
+                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, stream);
+            }
+        }
+        // T = L11^{-1} for the block solve kernels: all supernodes at once, off the tree's critical path
+        launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, stream);
         HIP_CHECK(hipGetLastError());
+        if (want_stamps) {
+            std::vector<long long> h(launches.size() * 16);
+            HIP_CHECK(hipMemcpyAsync(h.data(), stamps.p, h.size() * 8, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            static int printed = 0;
+            if (printed++ == 2) {
+                for (size_t r = 0; r < launches.size(); ++r) {
+                    const long long* q = &h[r * 16];
+                    if (launches[r].small) continue;
+                    std::fprintf(stderr, "[stamps] launch %zu fronts %d f=%lld nc=%lld kids=%lld | zero %.1f K %.1f kids %.1f factor %.1f "
+                                 "(diag %.1f trsm %.1f trail %.1f) store %.1f us  clk %.0f MHz\n", r, launches[r].count, q[11], q[12], q[13],
+                                 (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01,
+                                 q[8] * 0.01, q[9] * 0.01, q[10] * 0.01, (q[5] - q[4]) * 0.01,
+                                 (double)q[14] / ((q[5] - q[0]) * 0.01));
+                }
+            }
+        }
     }
 
     // d_b, d_x in the caller's (original) ordering; may alias
@@ -115,14 +152,15 @@ public:
         SolveArgs a;
         a.T = tree();
         a.fronts = fronts.p;
+        a.tinv = tinv.p;
         a.Dinv = Dinv.p;
         a.b = d_b;
         a.out = d_x;
         a.xp = xp.p;
         a.uvec = uvec.p;
-        for (const Launch& L : launches) launch_fwd(a, L.begin, L.count, L.bs, L.lds_solve, stream);
+        for (const Launch& L : launches) launch_fwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, stream);
         for (auto it = launches.rbegin(); it != launches.rend(); ++it)
-            launch_bwd(a, it->begin, it->count, it->bs, it->lds_solve, stream);
+            launch_bwd(a, it->begin, it->count, it->small ? 64 : 256, it->lds_solve, stream);
         HIP_CHECK(hipGetLastError());
     }
 
@@ -139,10 +177,23 @@ private:
     DBuf<int> d_sn_start, d_rows, d_rel, d_ncolpar, d_child_ptr, d_child_idx, d_ksrc, d_kdst, d_sched, d_perm;
     DBuf<int64_t> d_rowptr, d_front_off, d_upd_off, d_kptr;
     DBuf<signed char> d_psign;
-    DBuf<double> fronts, upd, Dinv, xp, uvec;
+    DBuf<double> fronts, upd, Dinv, xp, uvec, tinv;
+    DBuf<int64_t> d_tinv_off;
+    DBuf<int> d_tinv_list;
+    std::vector<int> tinv_list;
+    int tinv_ncmax = 1;
     DBuf<int> flags;
+    DBuf<int64_t> stamps;
+    DBuf<int64_t> d_tiles;       // int2 {supernode, ti<<16|tj}
+    DBuf<int64_t> d_cut_ptr;     // per supernode (as a child): offset into d_cuts
+    DBuf<int> d_cuts;            // first child-row index reaching each 64-row tile boundary of the parent's U
+    DBuf<int64_t> d_item_ptr;
+    DBuf<int64_t> d_items;       // ExtItem = 4 x int64
+    DBuf<int64_t> d_wave_cut;
+    DBuf<int> d_gl_src;
     std::vector<Launch> launches;
     std::vector<int> sched;
+    std::vector<int64_t> tiles;
 
     TreeDev tree() const
     {
@@ -151,6 +202,8 @@ private:
         t.ncolpar = d_ncolpar.p; t.front_off = d_front_off.p; t.upd_off = d_upd_off.p;
         t.child_ptr = d_child_ptr.p; t.child_idx = d_child_idx.p; t.kptr = d_kptr.p;
         t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
+        t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p;
+        t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
         return t;
     }
 
@@ -163,34 +216,63 @@ private:
     {
         sched.clear();
         launches.clear();
+        tiles.clear();
+        tinv_list.clear();
+        auto ncols = [&](int s) { return S.sn_start[s + 1] - S.sn_start[s]; };
+        auto is_small = [&](int s) {
+            int f = front_size(s), nc = ncols(s), nb = f - nc;
+            return f <= kSmallFrontMax && f * nc + nb * nb <= kSmallSliceMax;
+        };
         for (const Level& lv : S.levels) {
             std::vector<int> small, big;
             for (int t = lv.begin; t < lv.end; ++t) {
                 int s = S.level_sn[t];
-                (front_size(s) <= 64 ? small : big).push_back(s);
+                (is_small(s) ? small : big).push_back(s);
             }
-            auto work = [&](int s) { return (double)front_size(s) * (S.sn_start[s + 1] - S.sn_start[s]); };
+            auto work = [&](int s) { return (double)front_size(s) * front_size(s) * ncols(s); };
             auto by_work = [&](int a, int b) { double wa = work(a), wb = work(b); return wa != wb ? wa > wb : a < b; };
             std::sort(small.begin(), small.end(), by_work);
             std::sort(big.begin(), big.end(), by_work);
             for (int cls = 0; cls < 2; ++cls) {
                 const std::vector<int>& v = cls == 0 ? big : small;
                 if (v.empty()) continue;
-                Launch L;
+                Launch L{};
                 L.begin = (int)sched.size();
                 L.count = (int)v.size();
-                L.bs = cls == 0 ? 256 : 64;
-                int fmax = 0;
-                for (int s : v) fmax = std::max(fmax, front_size(s));
-                size_t ldB = (size_t)((fmax + 7) & ~3);
-                int nbk = kMaxNbk;
-                while (nbk > 1 && (2 * kMaxNbk + ldB * nbk) * sizeof(double) > kLdsCap) --nbk;
-                if ((2 * kMaxNbk + ldB * nbk) * sizeof(double) > kLdsCap)
-                    throw std::runtime_error("front too large for the single-workgroup factor kernel");
-                L.nbk = nbk;
-                L.lds_factor = (2 * kMaxNbk + ldB * nbk) * sizeof(double);
-                L.lds_solve = ((size_t)((fmax + 1) & ~1) + kTriBlock * (kTriBlock + 1)) * sizeof(double);
+                L.small = cls == 1;
+                int fmax = 0, slice = 0;
+                for (int s : v) {
+                    int f = front_size(s), nc = ncols(s), nb = f - nc;
+                    fmax = std::max(fmax, f);
+                    slice = std::max(slice, f * nc + nb * nb);
+                }
+                L.slice = (slice + 1) & ~1;
+                int pmax = 0;
+                for (int s : v) pmax = std::max(pmax, front_size(s) * ncols(s));
+                L.nbk = kMaxNbk;
+                L.bs_panel = fmax > 128 ? 1024 : (fmax > 96 ? 512 : 256);
+                L.lds_panel = panel_lds_bytes(fmax, pmax);
+                if (!L.small && L.lds_panel > kLdsCap)
+                    throw std::runtime_error("panel does not fit LDS (panel_cap too large?)");
+                int ncmax = 0;
+                for (int s : v) ncmax = std::max(ncmax, ncols(s));
+                L.lds_solve = L.small ? 0 : solve_lds_bytes(fmax, ncmax);
+                if (!L.small) for (int s : v) if (ncols(s) > 1) { tinv_list.push_back(s); tinv_ncmax = std::max(tinv_ncmax, ncols(s)); }
                 if (L.lds_solve > kLdsCap) throw std::runtime_error("front too large for the solve kernels");
+                L.tile_begin = (int)tiles.size();
+                if (!L.small) {
+                    for (int s : v) {
+                        int nb = front_size(s) - ncols(s);
+                        int nt = (nb + 63) / 64;
+                        for (int ti = 0; ti < nt; ++ti)
+                            for (int tj = 0; tj <= ti; ++tj) {
+                                // int2 {x = s, y = ti<<16 | tj}, little endian in one int64
+                                uint64_t lo = (uint32_t)s, hi = (uint32_t)((ti << 16) | tj);
+                                tiles.push_back((int64_t)(lo | (hi << 32)));
+                            }
+                    }
+                }
+                L.ntiles = (int)tiles.size() - L.tile_begin;
                 launches.push_back(L);
                 sched.insert(sched.end(), v.begin(), v.end());
             }
@@ -220,6 +302,100 @@ private:
         d_ksrc.upload(S.ksrc);
         d_kdst.upload(S.kdst);
         d_sched.upload(sched);
+        d_tiles.upload(tiles);
+        {
+            std::vector<int64_t> toff(S.nsuper + 1, 0);
+            std::vector<char> in_list(S.nsuper, 0);
+            for (int s : tinv_list) in_list[s] = 1;
+            for (int s = 0; s < S.nsuper; ++s) {
+                int64_t nc = S.sn_start[s + 1] - S.sn_start[s];
+                toff[s + 1] = toff[s] + (in_list[s] ? 2 * nc * nc : 0);
+            }
+            d_tinv_off.upload(toff);
+            tinv.alloc((size_t)toff[S.nsuper]);
+            HIP_CHECK(hipMemset(tinv.p, 0, std::max<size_t>(tinv.n, 1) * sizeof(double)));
+            // big ones first: the kernel is one thread per column
+            std::sort(tinv_list.begin(), tinv_list.end(), [&](int a, int b) {
+                int na = S.sn_start[a + 1] - S.sn_start[a], nb2 = S.sn_start[b + 1] - S.sn_start[b];
+                return na != nb2 ? na > nb2 : a < b;
+            });
+            d_tinv_list.upload(tinv_list);
+        }
+        {
+            std::vector<int64_t> cut_ptr(S.nsuper + 1, 0);
+            std::vector<int> cuts;
+            for (int c = 0; c < S.nsuper; ++c) {
+                cut_ptr[c] = (int64_t)cuts.size();
+                int p = S.sn_parent[c];
+                if (p < 0) continue;
+                int pnc = S.sn_start[p + 1] - S.sn_start[p];
+                int pnb = (int)(S.rowptr[p + 1] - S.rowptr[p]);
+                int nt = (pnb + 63) / 64;
+                const int* rb = S.rel.data() + S.rowptr[c];
+                int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
+                for (int t = 0; t <= nt; ++t)
+                    cuts.push_back((int)(std::lower_bound(rb, rb + nbc, pnc + 64 * t) - rb));
+            }
+            cut_ptr[S.nsuper] = (int64_t)cuts.size();
+            d_cut_ptr.upload(cut_ptr);
+            d_cuts.upload(cuts);
+        }
+        {
+            // extend-add items and forward-solve gather lists, both keyed by the parent's local index
+            const int64_t nloc = (int64_t)S.N + (int64_t)S.rows.size();
+            std::vector<int64_t> ptr((size_t)nloc + 1, 0);
+            auto lbase = [&](int s) { return (int64_t)S.sn_start[s] + S.rowptr[s]; };
+            for (int c = 0; c < S.nsuper; ++c) {
+                int p = S.sn_parent[c];
+                if (p < 0) continue;
+                for (int64_t q = S.rowptr[c]; q < S.rowptr[c + 1]; ++q) ptr[lbase(p) + S.rel[q] + 1]++;
+            }
+            for (int64_t i = 0; i < nloc; ++i) ptr[i + 1] += ptr[i];
+            static_assert(sizeof(ExtItem) == 32, "ExtItem layout");
+            std::vector<ExtItem> items((size_t)ptr[nloc]);
+            std::vector<int> gsrc((size_t)ptr[nloc]);
+            std::vector<int64_t> nxt(ptr.begin(), ptr.end() - 1);
+            for (int p = 0; p < S.nsuper; ++p)
+                for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {     // children in fixed order
+                    int c = S.child_idx[e];
+                    int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
+                    for (int b = 0; b < nbc; ++b) {
+                        int64_t q = S.rowptr[c] + b;
+                        int64_t d = nxt[lbase(p) + S.rel[q]]++;
+                        ExtItem it;
+                        it.uoff = S.upd_off[c] + (int64_t)b * nbc + b;
+                        it.relstart = (int)q;
+                        it.cnt = nbc - b;
+                        it.child = c;
+                        it.b = b;
+                        it.tcol = S.rel[q];
+                        it.pad = 0;
+                        items[d] = it;
+                        gsrc[d] = (int)q;
+                    }
+                }
+            if (S.rows.size() >= ((size_t)1 << 31)) throw std::runtime_error("row structure exceeds int32 indexing");
+            d_item_ptr.upload(ptr);
+            std::vector<int64_t> raw(items.size() * 4);
+            std::memcpy(raw.data(), items.data(), items.size() * sizeof(ExtItem));
+            d_items.upload(raw);
+            // 16 slices of each supernode's panel items, cut on column boundaries
+            std::vector<int64_t> wcut((size_t)S.nsuper * 17, 0);
+            for (int s = 0; s < S.nsuper; ++s) {
+                const int nc = S.sn_start[s + 1] - S.sn_start[s];
+                const int64_t* cp = ptr.data() + lbase(s);      // nc + 1 column pointers
+                const int64_t I0 = cp[0], I1 = cp[nc];
+                int j = 0;
+                for (int w = 0; w < 16; ++w) {
+                    const int64_t target = I0 + ((I1 - I0) * w) / 16;
+                    while (j < nc && cp[j] < target) ++j;
+                    wcut[(size_t)s * 17 + w] = cp[j];
+                }
+                wcut[(size_t)s * 17 + 16] = I1;
+            }
+            d_wave_cut.upload(wcut);
+            d_gl_src.upload(gsrc);
+        }
         d_perm.upload(S.perm);
         std::vector<signed char> ps(S.N);
         for (int k = 0; k < S.N; ++k) ps[k] = (signed char)(dsigns[S.perm[k]] >= 0 ? 1 : -1);

@@ -6,338 +6,6 @@
 namespace hipkkt {
 
 // =====================================================================================
-//  Numeric LDL^T: one workgroup per supernode, levels of the assembly tree launched in order.
-//  Replaces QDLDL.refactor! (call site /root/reference/src/kktsolvers/direct-ldl/
-//  directldl_qdldl.jl:72-81): same pivot rule -- D_k*sign_k < eps  =>  D_k = sign_k*delta --
-//  applied at pivot time inside the dense panel, no pivoting, static structure.
-//
-//  Per front:  zero panel -> scatter K (+ static eps*sign on the diagonal) -> extend-add the
-//  children's update blocks that land in the panel -> right-looking blocked LDL^T with the
-//  current block column staged in LDS -> update block U = -L21 D L21^T -> extend-add the
-//  children's pass-through part into U.  Children are added one after another in a fixed order,
-//  each by an injective map, so the sums are reproducible run to run (no atomics).
-// =====================================================================================
-template <int BS>
-__global__ __launch_bounds__(BS) void k_factor(FactorArgs A, int begin)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x;
-    const TreeDev& T = A.T;
-    const int s = T.sched[begin + blockIdx.x];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
-    const int f = nc + nb;
-    double* __restrict__ F = A.fronts + T.front_off[s];
-    double* __restrict__ U = A.upd + T.upd_off[s];
-
-    double* sh_d = smem;                 // kMaxNbk
-    double* sh_dinv = smem + kMaxNbk;    // kMaxNbk
-    double* Bl = smem + 2 * kMaxNbk;     // ldB x nbk block column
-
-    // ---- 1. zero the panel
-    for (int i = tid; i < f * nc; i += BS) F[i] = 0.0;
-    __syncthreads();
-    // ---- 2. scatter the K entries of these columns, then the static regulariser
-    for (int64_t e = T.kptr[s] + tid; e < T.kptr[s + 1]; e += BS) F[T.kdst[e]] = A.Kval[T.ksrc[e]];
-    __syncthreads();
-    if (A.eps) {
-        const double eps = *A.eps;
-        for (int k = tid; k < nc; k += BS) F[k + (int64_t)k * f] += eps * (double)T.psign[c0 + k];
-    }
-    // ---- 3. children: entries whose column lands in this supernode's columns
-    for (int ce = T.child_ptr[s]; ce < T.child_ptr[s + 1]; ++ce) {
-        const int c = T.child_idx[ce];
-        const int64_t crp = T.rowptr[c];
-        const int nbc = (int)(T.rowptr[c + 1] - crp);
-        const int kc = T.ncolpar[c];
-        const double* __restrict__ Uc = A.upd + T.upd_off[c];
-        const int* __restrict__ relc = T.rel + crp;
-        __syncthreads();
-        for (int idx = tid; idx < kc * nbc; idx += BS) {
-            const int b = idx / nbc, a = idx - b * nbc;
-            if (a >= b) F[relc[a] + (int64_t)relc[b] * f] += Uc[a + (int64_t)b * nbc];
-        }
-    }
-    __syncthreads();
-
-    // ---- 4. blocked right-looking factorisation, trailing update over panel and U
-    const int nbk = A.nbk;
-    for (int kb = 0; kb < nc; kb += nbk) {
-        const int w = min(nbk, nc - kb);
-        const int R = f - kb;
-        const int ldB = (R + 7) & ~3;        // >= R + 4: tiles may read up to 3 rows past R
-        for (int idx = tid; idx < ldB * w; idx += BS) {
-            const int j = idx / ldB, i = idx - j * ldB;
-            Bl[idx] = (i < R && i >= j) ? F[(kb + i) + (int64_t)(kb + j) * f] : 0.0;
-        }
-        for (int k = 0; k < w; ++k) {
-            __syncthreads();
-            double d = Bl[k + k * ldB];
-            const double sg = (double)T.psign[c0 + kb + k];
-            const bool reg = (d * sg < A.dyn_eps);
-            if (reg) d = sg * A.dyn_delta;
-            const double dinv = 1.0 / d;
-            if (tid == 0) {
-                sh_d[k] = d;
-                sh_dinv[k] = dinv;
-                if (reg) atomicAdd(&A.flags[0], 1);
-                if (!isfinite(dinv)) A.flags[1] = 1;
-            }
-            const double* __restrict__ colk = Bl + k * ldB;
-            for (int i = k + 1 + tid; i < R; i += BS) {
-                const double lik = colk[i] * dinv;
-                const int jmax = min(i, w - 1);
-                for (int j = k + 1; j <= jmax; ++j) Bl[i + j * ldB] -= lik * colk[j];
-            }
-        }
-        __syncthreads();
-        // scale to L, write L and D back, keep L in LDS for the trailing update
-        for (int idx = tid; idx < ldB * w; idx += BS) {
-            const int j = idx / ldB, i = idx - j * ldB;
-            if (i >= R) continue;
-            if (i > j) {
-                const double l = Bl[idx] * sh_dinv[j];
-                Bl[idx] = l;
-                F[(kb + i) + (int64_t)(kb + j) * f] = l;
-            } else if (i == j) {
-                F[(kb + i) + (int64_t)(kb + j) * f] = sh_d[j];
-                A.Dinv[c0 + kb + j] = sh_dinv[j];
-            }
-        }
-        __syncthreads();
-        // trailing update: C(i,j) -= sum_k L(i,k) d_k L(j,k), i >= j, over columns kb+w .. f
-        const int Tn = f - kb - w;
-        if (Tn > 0) {
-            const int ntile = (Tn + 3) >> 2;
-            const int nt = ntile * (ntile + 1) / 2;
-            const int g0 = kb + w;           // global front index of local 0
-            for (int t = tid; t < nt; t += BS) {
-                int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-                while (tr * (tr + 1) / 2 > t) --tr;
-                while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-                const int tc = t - tr * (tr + 1) / 2;
-                const double* __restrict__ Ar = Bl + w + 4 * tr;
-                const double* __restrict__ Bc = Bl + w + 4 * tc;
-                double acc[4][4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-                for (int k = 0; k < w; ++k) {
-                    const double dk = sh_d[k];
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) av[a] = Ar[k * ldB + a];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) bv[b] = Bc[k * ldB + b] * dk;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-                }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int j = 4 * tc + b;
-                    if (j >= Tn) continue;
-                    const int gj = g0 + j;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int i = 4 * tr + a;
-                        if (i >= Tn || i < j) continue;
-                        const int gi = g0 + i;
-                        if (gj < nc) {
-                            F[gi + (int64_t)gj * f] -= acc[a][b];
-                        } else {
-                            double* u = U + (gi - nc) + (int64_t)(gj - nc) * nb;
-                            *u = (kb == 0) ? -acc[a][b] : (*u - acc[a][b]);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- 6. children: pass-through part into the update block
-    for (int ce = T.child_ptr[s]; ce < T.child_ptr[s + 1]; ++ce) {
-        const int c = T.child_idx[ce];
-        const int64_t crp = T.rowptr[c];
-        const int nbc = (int)(T.rowptr[c + 1] - crp);
-        const int kc = T.ncolpar[c];
-        const int wc = nbc - kc;
-        const double* __restrict__ Uc = A.upd + T.upd_off[c];
-        const int* __restrict__ relc = T.rel + crp;
-        __syncthreads();
-        for (int idx = tid; idx < wc * wc; idx += BS) {
-            const int bb = idx / wc, aa = idx - bb * wc;
-            if (aa < bb) continue;
-            const int a = kc + aa, b = kc + bb;
-            U[(relc[a] - nc) + (int64_t)(relc[b] - nc) * nb] += Uc[a + (int64_t)b * nbc];
-        }
-    }
-}
-
-// dynamic LDS above 64 KiB has to be asked for once per kernel
-template <class K>
-static void allow_big_lds(K kernel)
-{
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-}
-static void init_lds_limits()
-{
-    static bool done = false;
-    if (done) return;
-    done = true;
-    allow_big_lds(k_factor<64>);
-    allow_big_lds(k_factor<256>);
-}
-
-void launch_factor(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
-{
-    if (count <= 0) return;
-    init_lds_limits();
-    if (bs == 64) hipLaunchKernelGGL(k_factor<64>, dim3(count), dim3(64), lds, st, a, begin);
-    else hipLaunchKernelGGL(k_factor<256>, dim3(count), dim3(256), lds, st, a, begin);
-}
-
-// =====================================================================================
-//  Triangular solves on the supernodal tree.  Replaces QDLDL.solve! (directldl_qdldl.jl:85-96):
-//  permute, L \, D^{-1}, L' \, inverse permute.
-//  Forward: multifrontal style -- each front gathers b and its children's contribution vectors,
-//  solves its unit-lower diagonal block, and leaves  -L21*y  (plus what passed through) for its
-//  parent: no scatter conflicts, fixed summation order.  Backward: each front gathers the
-//  ancestors' solution entries it needs.
-// =====================================================================================
-template <int BS>
-__global__ __launch_bounds__(BS) void k_fwd(SolveArgs A, int begin)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x;
-    const TreeDev& T = A.T;
-    const int s = T.sched[begin + blockIdx.x];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int64_t rp = T.rowptr[s];
-    const int nb = (int)(T.rowptr[s + 1] - rp);
-    const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + T.front_off[s];
-    double* y = smem;                          // f
-    double* Ld = smem + ((f + 1) & ~1);        // kTriBlock x (kTriBlock+1)
-    constexpr int ldd = kTriBlock + 1;
-
-    for (int i = tid; i < f; i += BS) y[i] = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
-    for (int ce = T.child_ptr[s]; ce < T.child_ptr[s + 1]; ++ce) {
-        const int c = T.child_idx[ce];
-        const int64_t crp = T.rowptr[c];
-        const int nbc = (int)(T.rowptr[c + 1] - crp);
-        __syncthreads();
-        for (int t = tid; t < nbc; t += BS) y[T.rel[crp + t]] += A.uvec[crp + t];
-    }
-    __syncthreads();
-    for (int kb = 0; kb < nc; kb += kTriBlock) {
-        const int w = min(kTriBlock, nc - kb);
-        for (int idx = tid; idx < w * w; idx += BS) {
-            const int j = idx / w, i = idx - j * w;
-            Ld[i + j * ldd] = (i > j) ? F[(kb + i) + (int64_t)(kb + j) * f] : 0.0;
-        }
-        __syncthreads();
-        for (int k = 0; k < w - 1; ++k) {
-            const double yk = y[kb + k];
-            for (int i = k + 1 + tid; i < w; i += BS) y[kb + i] -= Ld[i + k * ldd] * yk;
-            __syncthreads();
-        }
-        // rows below the block: y_i -= sum_k L(i,k) y_k
-        for (int i = kb + w + tid; i < f; i += BS) {
-            double acc = 0.0;
-            for (int k = 0; k < w; ++k) acc = fma(F[i + (int64_t)(kb + k) * f], y[kb + k], acc);
-            y[i] -= acc;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < nc; i += BS) A.xp[c0 + i] = y[i];
-    for (int t = tid; t < nb; t += BS) A.uvec[rp + t] = y[nc + t];
-}
-
-template <int BS>
-__global__ __launch_bounds__(BS) void k_bwd(SolveArgs A, int begin)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = BS / 64;
-    const TreeDev& T = A.T;
-    const int s = T.sched[begin + blockIdx.x];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int64_t rp = T.rowptr[s];
-    const int nb = (int)(T.rowptr[s + 1] - rp);
-    const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + T.front_off[s];
-    double* y = smem;
-    double* Ld = smem + ((f + 1) & ~1);
-    constexpr int ldd = kTriBlock + 1;
-
-    for (int i = tid; i < f; i += BS)
-        y[i] = (i < nc) ? A.xp[c0 + i] * A.Dinv[c0 + i] : A.xp[T.rows[rp + i - nc]];
-    __syncthreads();
-    const int nblk = (nc + kTriBlock - 1) / kTriBlock;
-    for (int bi = nblk - 1; bi >= 0; --bi) {
-        const int kb = bi * kTriBlock;
-        const int w = min(kTriBlock, nc - kb);
-        // y_k -= sum_{i >= kb+w} L(i,k) y_i : one wave per column, lanes over rows
-        for (int k = wave; k < w; k += NW) {
-            const double* __restrict__ col = F + (int64_t)(kb + k) * f;
-            double acc = 0.0;
-            for (int i = kb + w + lane; i < f; i += 64) acc = fma(col[i], y[i], acc);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-            if (lane == 0) y[kb + k] -= acc;
-        }
-        for (int idx = tid; idx < w * w; idx += BS) {
-            const int j = idx / w, i = idx - j * w;
-            Ld[i + j * ldd] = (i > j) ? F[(kb + i) + (int64_t)(kb + j) * f] : 0.0;
-        }
-        __syncthreads();
-        for (int k = w - 1; k > 0; --k) {
-            const double yk = y[kb + k];
-            for (int j = tid; j < k; j += BS) y[kb + j] -= Ld[k + j * ldd] * yk;
-            __syncthreads();
-        }
-    }
-    for (int i = tid; i < nc; i += BS) {
-        const double v = y[i];
-        A.xp[c0 + i] = v;
-        A.out[T.perm[c0 + i]] = v;
-    }
-}
-
-static void init_lds_limits_solve()
-{
-    static bool done = false;
-    if (done) return;
-    done = true;
-    allow_big_lds(k_fwd<64>);
-    allow_big_lds(k_fwd<256>);
-    allow_big_lds(k_bwd<64>);
-    allow_big_lds(k_bwd<256>);
-}
-void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
-{
-    if (count <= 0) return;
-    init_lds_limits_solve();
-    if (bs == 64) hipLaunchKernelGGL(k_fwd<64>, dim3(count), dim3(64), lds, st, a, begin);
-    else hipLaunchKernelGGL(k_fwd<256>, dim3(count), dim3(256), lds, st, a, begin);
-}
-void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
-{
-    if (count <= 0) return;
-    init_lds_limits_solve();
-    if (bs == 64) hipLaunchKernelGGL(k_bwd<64>, dim3(count), dim3(64), lds, st, a, begin);
-    else hipLaunchKernelGGL(k_bwd<256>, dim3(count), dim3(256), lds, st, a, begin);
-}
-
-// =====================================================================================
 //  KKT value updates
 // =====================================================================================
 static inline int grid_for(int64_t n, int bs, int cap = 4096)

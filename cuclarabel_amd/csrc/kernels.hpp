@@ -15,6 +15,16 @@
 
 namespace hipkkt {
 
+struct ExtItem {                 // one child update column (rows a >= b of child c); 32 bytes
+    int64_t uoff;                // offset in the update store of U_c(b, b)
+    int relstart;                // index into rel[] of the child's row b
+    int cnt;                     // rows a = b .. nbc-1
+    int child;
+    int b;
+    int tcol;                    // parent-local column this item lands in
+    int pad;
+};
+
 struct TreeDev {                 // device copies of the symbolic structure
     const int* sn_start;         // nsuper+1
     const int64_t* rowptr;       // nsuper+1
@@ -31,6 +41,22 @@ struct TreeDev {                 // device copies of the symbolic structure
     const int* sched;            // supernodes in launch order (level by level, size class inside)
     const signed char* psign;    // N: expected pivot sign, permuted order
     const int* perm;             // N: perm[new] = old
+    // Extend-add work lists.  Local column j of front s has index lc = sn_start[s] + rowptr[s] + j.
+    // items[item_ptr[lc] .. item_ptr[lc+1]) are the child update columns that land in that column,
+    // in child order: the owner of the column applies them one after the other (deterministic).
+    const int64_t* item_ptr;     // sum_s f_s + 1
+    const ExtItem* items;        // sum_s nb_s
+    // forward-solve gather lists: local row r of front s (same indexing) receives
+    // uvec[gl_src[q]] for q in gl_ptr[lc] .. gl_ptr[lc+1]
+    const int64_t* gl_ptr;
+    const int* gl_src;
+    // per child c: cuts[cut_ptr[c] + t] = first child row index whose parent-local row >= nc_p + 64 t
+    const int64_t* cut_ptr;
+    const int* cuts;
+    // per supernode: 17 item indices splitting its panel items (local columns < nc) into 16 slices
+    // that end on column boundaries: a wave takes whole columns, so no two waves share a target column
+    const int64_t* wave_cut;     // nsuper * 17
+    const int64_t* tinv_off;     // nsuper+1: offset of the two nc x nc copies of T = L11^{-1}
 };
 
 struct FactorArgs {
@@ -43,11 +69,16 @@ struct FactorArgs {
     int* flags;                  // [0] #dynamic regularisations, [1] non-finite pivot seen
     double dyn_eps, dyn_delta;
     int nbk;                     // block-column width (<= 16), chosen so the LDS buffer fits
+    long long* stamps;           // diagnostic only (HIPKKT_STAMPS=1): phase time stamps of block 0, else null
+    int stamp_row;
 };
+#define HIPKKT_STAMP(A, k) do { if ((A).stamps && blockIdx.x == 0 && threadIdx.x == 0) \
+        (A).stamps[(A).stamp_row * 16 + (k)] = wall_clock64(); } while (0)
 
 struct SolveArgs {
     TreeDev T;
     const double* fronts;
+    const double* tinv;          // per supernode: T col-major, then T row-major
     const double* Dinv;
     const double* b;             // original order
     double* out;                 // original order
@@ -55,10 +86,20 @@ struct SolveArgs {
     double* uvec;                // sum nb
 };
 
-constexpr int kTriBlock = 32;    // diagonal-block width of the triangular solves
+constexpr int kSolveChunk = 128;  // diagonal chunk of the triangular solves: one wave, two unknowns per lane
 constexpr int kMaxNbk = 16;
+size_t solve_lds_bytes(int fmax, int ncmax);
+void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
+                 hipStream_t st);
 
-void launch_factor(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
+// factorisation of one level: small fronts (one wave each), panels (one workgroup each), then the
+// update blocks tiled over many workgroups
+constexpr int kSmallFrontMax = 64;         // f <= 64 ...
+constexpr int kSmallSliceMax = 1536;       // ... and f*nc + nb*nb <= this many doubles of LDS per wave
+void launch_front_wave(const FactorArgs& a, int begin, int count, int slice_doubles, hipStream_t st);
+void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
+void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st);
+size_t panel_lds_bytes(int fmax, int panel_max);
 void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
 void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
 

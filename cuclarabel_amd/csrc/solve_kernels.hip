@@ -1,0 +1,394 @@
+// Triangular solves on the supernodal tree (gfx950, wave64).
+//
+// Replaces QDLDL.solve! (call site /root/reference/src/kktsolvers/direct-ldl/directldl_qdldl.jl:
+// 85-96): permute, L \, D^{-1}, L' \, inverse permute.
+//
+// Forward sweep, multifrontal style: each front gathers b and its children's contribution
+// vectors, solves its unit-lower diagonal block, and leaves (what passed through) - L21*y for its
+// parent.  No scatter conflicts, fixed summation order, hence bit-reproducible.  Backward sweep:
+// each front gathers the ancestors' solution entries it needs.
+//
+// Two kernels per direction:
+//   *_wave   fronts with f <= 64: one wave per front, everything in registers / readlane.
+//   *_block  larger fronts: one 256-thread workgroup per front.  The diagonal block is staged in
+//            LDS (packed lower triangle) and solved by ONE wave with v_readlane broadcasts (no
+//            workgroup barrier per column); the off-diagonal panel is a dense GEMV streamed from
+//            HBM/L2 with 8 independent loads in flight per lane.
+#include "kernels.hpp"
+
+namespace hipkkt {
+
+__device__ inline double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double wave_reduce_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ small fronts, one wave each
+__global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int count)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= count) return;
+    const TreeDev& T = A.T;
+    const int s = T.sched[begin + item];
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int64_t rp = T.rowptr[s];
+    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + T.front_off[s];
+
+    // gather: right-hand side entry plus the children's contributions to this row, in child order
+    double y = (lane < nc) ? A.b[T.perm[c0 + lane]] : 0.0;
+    if (lane < f) {
+        const int64_t lc = (int64_t)c0 + rp + lane;
+        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
+        for (int64_t g = g0; g < g1; ++g) y += A.uvec[T.gl_src[g]];
+    }
+    // column sweep: y_l -= L(l,k) y_k
+    for (int k0 = 0; k0 < nc; k0 += 8) {
+        double lv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+            lv[q] = (k < nc && lane > k && lane < f) ? F[lane + (int64_t)k * f] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+            if (k < nc) {
+                const double yk = readlane_f64(y, k);
+                y = fma(-lv[q], yk, y);
+            }
+        }
+    }
+    if (lane < nc) A.xp[c0 + lane] = y;
+    else if (lane < f) A.uvec[rp + lane - nc] = y;
+}
+
+__global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int count)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= count) return;
+    const TreeDev& T = A.T;
+    const int s = T.sched[begin + item];
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int64_t rp = T.rowptr[s];
+    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + T.front_off[s];
+
+    double y = 0.0;
+    if (lane < nc) y = A.xp[c0 + lane] * A.Dinv[c0 + lane];
+    else if (lane < f) y = A.xp[T.rows[rp + lane - nc]];
+    // row sweep from the bottom: y_j -= L(k,j) y_k for j < min(k, nc)
+    for (int k0 = f - 1; k0 >= 1; k0 -= 8) {
+        double lv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 - q;
+            lv[q] = (k >= 1 && lane < k && lane < nc) ? F[k + (int64_t)lane * f] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 - q;
+            if (k >= 1) {
+                const double yk = readlane_f64(y, k);
+                y = fma(-lv[q], yk, y);
+            }
+        }
+    }
+    if (lane < nc) {
+        A.xp[c0 + lane] = y;
+        A.out[T.perm[c0 + lane]] = y;
+    }
+}
+
+// ------------------------------------------------------------------ larger fronts, one block each
+// With T = L11^{-1} precomputed after the factorisation (k_tinv), a front's solve is three streaming
+// phases whose loads are all independent of each other -- no sequential substitution on the
+// critical path:
+//   forward :  y <- gather ;  y_s <- T y_s          ;  y_below <- y_below - L21 y_s
+//   backward:  y <- gather ;  t   <- y_s - L21' y_b ;  x_s     <- T' t
+// Work is cut into items of 8 matrix columns x 64 rows; a wave issues the 8 loads of an item
+// together.  Partial sums go to LDS and are combined in a fixed order (bit-reproducible).
+
+// part[ks * ldp + r] = sum_{q<8} M[(r0 + r) + (k0 + 8 ks + q) * ld] * v[8 ks + q]   (rows r < R, cols k < Kn)
+// lower != 0: M is strictly lower triangular in (r, k) coordinates (k < r only)
+template <int NW>
+__device__ inline void sliced_matvec(const double* __restrict__ M, int64_t ld, int R, int Kn, const double* v,
+                                     double* part, int ldp, bool lower, int wv, int lane)
+{
+    const int nrb = (R + 63) >> 6, nks = (Kn + 7) >> 3;
+    for (int it = wv; it < nrb * nks; it += NW) {
+        const int ks = it / nrb, rb = it - ks * nrb;
+        const int r = rb * 64 + lane, k0 = 8 * ks;
+        if (lower && k0 >= rb * 64 + 63) {            // whole item on or above the diagonal
+            if (r < R) part[ks * ldp + r] = 0.0;
+            continue;
+        }
+        double m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+            const bool ok = r < R && k < Kn && (!lower || k < r);
+            m[q] = ok ? M[r + (int64_t)k * ld] : 0.0;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fma(m[q], (k0 + q < Kn) ? v[k0 + q] : 0.0, acc);
+        if (r < R) part[ks * ldp + r] = acc;
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = BS / 64;
+    const TreeDev& T = A.T;
+    const int s = T.sched[begin + blockIdx.x];
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int64_t rp = T.rowptr[s];
+    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + T.front_off[s];
+    const double* __restrict__ Tcm = A.tinv + T.tinv_off[s];          // T(i,j) at i + j*nc
+    const int fpad = (f + 3) & ~3;
+    double* y = smem;                        // fpad
+    double* part = smem + fpad;              // nks * fpad
+
+    // gather: right-hand side entry plus the children's contributions to each row, in child order
+    for (int i = tid; i < f; i += BS) {
+        double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
+        const int64_t lc = (int64_t)c0 + rp + i;
+        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
+        for (int64_t g = g0; g < g1; g += 4) {
+            int src[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+            double u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? A.uvec[src[q]] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v += u[q];
+        }
+        y[i] = v;
+    }
+    __syncthreads();
+    const int nks = (nc + 7) >> 3;
+    // y_s <- T y_s  (T unit lower: strictly-lower part times y, plus y itself)
+    sliced_matvec<NW>(Tcm, nc, nc, nc, y, part, fpad, true, wv, lane);
+    __syncthreads();
+    for (int i = tid; i < nc; i += BS) {
+        double v = y[i];
+        for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
+        y[i] = v;
+        A.xp[c0 + i] = v;
+    }
+    __syncthreads();
+    // y_below <- y_below - L21 y_s
+    if (nb > 0) {
+        sliced_matvec<NW>(F + nc, f, nb, nc, y, part, fpad, false, wv, lane);
+        __syncthreads();
+        for (int t = tid; t < nb; t += BS) {
+            double v = y[nc + t];
+            for (int ks = 0; ks < nks; ++ks) v -= part[ks * fpad + t];
+            A.uvec[rp + t] = v;
+        }
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = BS / 64;
+    const TreeDev& T = A.T;
+    const int s = T.sched[begin + blockIdx.x];
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int64_t rp = T.rowptr[s];
+    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + T.front_off[s];
+    const double* __restrict__ Trm = A.tinv + T.tinv_off[s] + (int64_t)nc * nc;   // T(i,j) at j + i*nc
+    const int fpad = (f + 3) & ~3;
+    double* y = smem;
+    double* part = smem + fpad;
+
+    for (int i = tid; i < f; i += BS)
+        y[i] = (i < nc) ? A.xp[c0 + i] * A.Dinv[c0 + i] : A.xp[T.rows[rp + i - nc]];
+    __syncthreads();
+    // t_j = y_j - sum_r L21(r,j) y_b(r): a wave takes 8 columns, lanes over rows, then 8 wave reductions
+    if (nb > 0) {
+        const int ncg = (nc + 7) >> 3;
+        for (int cg = wv; cg < ncg; cg += NW) {
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+            for (int r = lane; r < nb; r += 64) {
+                const double yr = y[nc + r];
+                double m[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = (8 * cg + q < nc) ? F[(nc + r) + (int64_t)(8 * cg + q) * f] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fma(m[q], yr, acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double sum = wave_reduce_sum(acc[q]);
+                if (lane == 0 && 8 * cg + q < nc) y[8 * cg + q] -= sum;
+            }
+        }
+        __syncthreads();
+    }
+    // x_s = T' t : x_j = t_j + sum_{i>j} T(i,j) t_i ; Trm is T' column-major, strictly UPPER in (j,i)
+    // -> reuse the sliced kernel on the transposed roles: rows = j, cols = i, keep i > j
+    {
+        const int nrb = (nc + 63) >> 6, nks = (nc + 7) >> 3;
+        for (int it = wv; it < nrb * nks; it += NW) {
+            const int ks = it / nrb, rb = it - ks * nrb;
+            const int j = rb * 64 + lane, i0 = 8 * ks;
+            if (i0 + 7 <= rb * 64) {                   // whole item on or below the diagonal
+                if (j < nc) part[ks * fpad + j] = 0.0;
+                continue;
+            }
+            double m[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 + q;
+                m[q] = (j < nc && i < nc && i > j) ? Trm[j + (int64_t)i * nc] : 0.0;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fma(m[q], (i0 + q < nc) ? y[i0 + q] : 0.0, acc);
+            if (j < nc) part[ks * fpad + j] = acc;
+        }
+        __syncthreads();
+        for (int j = tid; j < nc; j += BS) {
+            double v = y[j];
+            for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + j];
+            A.xp[c0 + j] = v;
+            A.out[T.perm[c0 + j]] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ T = L11^{-1} for every supernode
+// Runs once after the factorisation, all supernodes in parallel (off the critical path of the tree).
+// L11 is staged in LDS and inverted in place row by row: row i of T needs rows < i of T (already
+// there) and row i of L (not yet overwritten).  Thread j owns column j.  The result is written
+// twice, col-major for the forward solve and row-major for the backward solve.
+__global__ __launch_bounds__(256) void k_tinv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ tinv,
+                                              const int* __restrict__ list)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int s = list[blockIdx.x];
+    const int c0 = T.sn_start[s];
+    const int nc = T.sn_start[s + 1] - c0;
+    const int f = nc + (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const double* __restrict__ F = fronts + T.front_off[s];
+    double* __restrict__ Tcm = tinv + T.tinv_off[s];
+    double* __restrict__ Trm = Tcm + (int64_t)nc * nc;
+    const int ldl = nc | 1;
+    double* Ls = smem;                 // entry (i,k), i > k, at i*ldl + k
+    for (int idx = tid; idx < nc * nc; idx += 256) {
+        const int k = idx / nc, i = idx - k * nc;
+        if (i > k) Ls[i * ldl + k] = F[i + (int64_t)k * f];
+    }
+    __syncthreads();
+    for (int i = 1; i < nc; ++i) {
+        // T(i,j) = -( L(i,j) + sum_{k=j+1}^{i-1} L(i,k) T(k,j) ), all j < i at once
+        double t[(256 + 255) / 256];
+        const double* __restrict__ Li = Ls + i * ldl;
+        {
+            const int j = tid;
+            double acc = 0.0;
+            if (j < i) {
+                acc = Li[j];
+                for (int k = j + 1; k < i; ++k) acc = fma(Li[k], Ls[k * ldl + j], acc);
+            }
+            t[0] = -acc;
+        }
+        __syncthreads();
+        if (tid < i) Ls[i * ldl + tid] = t[0];
+        __syncthreads();
+    }
+    for (int idx = tid; idx < nc * nc; idx += 256) {
+        const int a = idx / nc, b = idx - a * nc;
+        // col-major copy: entry (i = b, j = a); row-major copy: entry (i = a, j = b)
+        if (b > a) Tcm[idx] = Ls[b * ldl + a];
+        if (a > b) Trm[idx] = Ls[a * ldl + b];
+    }
+}
+
+constexpr int kSolveBS = 512;
+
+static void init_solve_lds()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_block<kSolveBS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_block<kSolveBS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tinv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+}
+
+size_t solve_lds_bytes(int fmax, int ncmax)
+{
+    const size_t fpad = (size_t)((fmax + 3) & ~3);
+    const size_t nks = (size_t)((ncmax + 7) >> 3);
+    return (fpad + nks * fpad) * sizeof(double);
+}
+
+void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
+{
+    if (count <= 0) return;
+    if (bs == 64) {
+        hipLaunchKernelGGL(k_fwd_wave, dim3((count + 3) / 4), dim3(256), 0, st, a, begin, count);
+    } else {
+        init_solve_lds();
+        hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count), dim3(kSolveBS), lds, st, a, begin);
+    }
+}
+void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
+{
+    if (count <= 0) return;
+    if (bs == 64) {
+        hipLaunchKernelGGL(k_bwd_wave, dim3((count + 3) / 4), dim3(256), 0, st, a, begin, count);
+    } else {
+        init_solve_lds();
+        hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count), dim3(kSolveBS), lds, st, a, begin);
+    }
+}
+void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
+                 hipStream_t st)
+{
+    if (count <= 0) return;
+    init_solve_lds();
+    const size_t lds = (size_t)ncmax * (ncmax | 1) * sizeof(double);
+    hipLaunchKernelGGL(k_tinv, dim3(count), dim3(256), lds, st, T, fronts, tinv, list);
+}
+
+}  // namespace hipkkt

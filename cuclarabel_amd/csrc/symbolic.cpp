@@ -300,6 +300,59 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
         S.rows.resize((size_t)S.rowptr[S.nsuper]);
         for (int s = 0; s < S.nsuper; ++s) std::copy(rws[s].begin(), rws[s].end(), S.rows.begin() + S.rowptr[s]);
     }
+    // ---- 7b. split supernodes whose panel (f x nc doubles) exceeds the LDS-resident cap into a chain
+    //          of narrower ones: chunk i keeps columns [a_i, a_i+1) and gets the later columns as rows
+    if (opt.panel_cap > 0) {
+        std::vector<int> nstart, nparent_old;      // new supernode starts; old id each chunk came from
+        std::vector<int> first_new(S.nsuper), last_new(S.nsuper);
+        std::vector<int64_t> nrowptr(1, 0);
+        std::vector<int> nrows;
+        nrows.reserve(S.rows.size());
+        for (int s0 = 0; s0 < S.nsuper; ++s0) {
+            int c0 = S.sn_start[s0], c1 = S.sn_start[s0 + 1];
+            int64_t nb = S.rowptr[s0 + 1] - S.rowptr[s0];
+            first_new[s0] = (int)nstart.size();
+            int a = c0;
+            while (a < c1) {
+                int64_t fa = (c1 - a) + nb;
+                int64_t wd = std::max<int64_t>(1, std::min<int64_t>(c1 - a, opt.panel_cap / fa));
+                // avoid a sliver at the end: balance the remaining columns over the remaining chunks
+                int64_t rem = c1 - a;
+                if (wd < rem) { int64_t parts = (rem + wd - 1) / wd; wd = (rem + parts - 1) / parts; }
+                nstart.push_back(a);
+                nparent_old.push_back(s0);
+                int e = a + (int)wd;
+                for (int j = e; j < c1; ++j) nrows.push_back(j);
+                nrows.insert(nrows.end(), S.rows.begin() + S.rowptr[s0], S.rows.begin() + S.rowptr[s0 + 1]);
+                nrowptr.push_back((int64_t)nrows.size());
+                a = e;
+            }
+            last_new[s0] = (int)nstart.size() - 1;
+        }
+        int nnew = (int)nstart.size();
+        if (nnew != S.nsuper) {
+            std::vector<int> nparent(nnew, -1);
+            for (int t = 0; t < nnew; ++t) {
+                int s0 = nparent_old[t];
+                if (t < last_new[s0]) nparent[t] = t + 1;
+                else nparent[t] = S.sn_parent[s0] >= 0 ? first_new[S.sn_parent[s0]] : -1;
+            }
+            nstart.push_back(N);
+            S.nsuper = nnew;
+            S.sn_start.swap(nstart);
+            S.sn_parent.swap(nparent);
+            S.rowptr.swap(nrowptr);
+            S.rows.swap(nrows);
+            for (int t = 0; t < nnew; ++t)
+                for (int j = S.sn_start[t]; j < S.sn_start[t + 1]; ++j) S.col2sn[j] = t;
+            S.child_ptr.assign(S.nsuper + 1, 0);
+            for (int t = 0; t < S.nsuper; ++t) if (S.sn_parent[t] >= 0) S.child_ptr[S.sn_parent[t] + 1]++;
+            for (int t = 0; t < S.nsuper; ++t) S.child_ptr[t + 1] += S.child_ptr[t];
+            S.child_idx.resize(S.child_ptr[S.nsuper]);
+            std::vector<int> nxt(S.child_ptr.begin(), S.child_ptr.end() - 1);
+            for (int t = 0; t < S.nsuper; ++t) if (S.sn_parent[t] >= 0) S.child_idx[nxt[S.sn_parent[t]]++] = t;
+        }
+    }
     // sanity: every below-row of a child lies in the parent's columns or rows
     S.rel.assign(S.rows.size(), -1);
     {
