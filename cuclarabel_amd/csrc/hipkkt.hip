@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -63,6 +64,7 @@ struct Launch {
     int bs_panel, nbk, slice;   // panel kernel block size / block-column width; small-front LDS slice
     size_t lds_panel, lds_solve;
     int tile_begin, ntiles;     // Schur tiles of this launch's fronts
+    int tinv_begin, tinv_count, tinv_ncmax;   // this launch's supernodes that need T = L11^{-1}
 };
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
@@ -92,9 +94,87 @@ public:
         upload(dsigns);
     }
 
+    // Both sequences are static (no pivoting, fixed structure), so they can be captured once into
+    // hipGraphs and replayed (HIPKKT_GRAPH=1), with the T = L11^{-1} kernels on a parallel branch.
     void factor(const double* d_Kval, const double* d_eps)
     {
-        flags.zero(stream);
+        static const bool want_stamps = std::getenv("HIPKKT_STAMPS") != nullptr;
+        // measured on MI355X/ROCm 7.2: replay is ~25 % slower than eager launches for these ~100-node
+        // chains (the work is GPU-latency-bound, not host-bound), so graphs are opt-in
+        static const bool no_graph = std::getenv("HIPKKT_GRAPH") == nullptr;
+        if (want_stamps || no_graph || n_factor_calls++ == 0) {
+            enqueue_factor(d_Kval, d_eps, stream, nullptr, want_stamps);
+            return;
+        }
+        auto key = std::make_pair((const void*)d_Kval, (const void*)d_eps);
+        auto it = factor_graphs.find(key);
+        if (it == factor_graphs.end()) {
+            ensure_capture_streams();
+            HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+            enqueue_factor(d_Kval, d_eps, cap_stream, cap_side, false);
+            hipGraph_t g;
+            HIP_CHECK(hipStreamEndCapture(cap_stream, &g));
+            hipGraphExec_t ex;
+            HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            it = factor_graphs.emplace(key, ex).first;
+        }
+        HIP_CHECK(hipGraphLaunch(it->second, stream));
+    }
+
+    // d_b, d_x in the caller's (original) ordering; may alias
+    void solve(const double* d_b, double* d_x)
+    {
+        static const bool no_graph = std::getenv("HIPKKT_GRAPH") == nullptr;
+        if (no_graph || n_solve_calls++ == 0) {
+            enqueue_solve(d_b, d_x, stream);
+            return;
+        }
+        auto key = std::make_pair((const void*)d_b, (const void*)d_x);
+        auto it = solve_graphs.find(key);
+        if (it == solve_graphs.end()) {
+            ensure_capture_streams();
+            HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+            enqueue_solve(d_b, d_x, cap_stream);
+            hipGraph_t g;
+            HIP_CHECK(hipStreamEndCapture(cap_stream, &g));
+            hipGraphExec_t ex;
+            HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            it = solve_graphs.emplace(key, ex).first;
+        }
+        HIP_CHECK(hipGraphLaunch(it->second, stream));
+    }
+
+    ~LDLEngine()
+    {
+        for (auto& kv : factor_graphs) (void)hipGraphExecDestroy(kv.second);
+        for (auto& kv : solve_graphs) (void)hipGraphExecDestroy(kv.second);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (cap_side) (void)hipStreamDestroy(cap_side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
+
+private:
+    std::map<std::pair<const void*, const void*>, hipGraphExec_t> factor_graphs, solve_graphs;
+    hipStream_t cap_stream = nullptr, cap_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    long n_factor_calls = 0, n_solve_calls = 0;
+
+    void ensure_capture_streams()
+    {
+        if (cap_stream) return;
+        HIP_CHECK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&cap_side, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+
+    // side != nullptr: put the T = L11^{-1} kernels on that stream, forked after each level's panels
+    void enqueue_factor(const double* d_Kval, const double* d_eps, hipStream_t st, hipStream_t side, bool want_stamps)
+    {
+        flags.zero(st);
         FactorArgs a;
         a.T = tree();
         a.Kval = d_Kval;
@@ -107,30 +187,42 @@ public:
         a.dyn_delta = dyn_delta;
         a.stamps = nullptr;
         a.stamp_row = 0;
-        static const bool want_stamps = std::getenv("HIPKKT_STAMPS") != nullptr;
         if (want_stamps) {
             if (!stamps.p) { stamps.alloc(launches.size() * 16); }
-            stamps.zero(stream);
+            stamps.zero(st);
             a.stamps = (long long*)stamps.p;
         }
         int li = 0;
+        bool forked = false;
         for (const Launch& L : launches) {
             a.stamp_row = li++;
             if (L.small) {
-                launch_front_wave(a, L.begin, L.count, L.slice, stream);
+                launch_front_wave(a, L.begin, L.count, L.slice, st);
             } else {
                 a.nbk = L.nbk;
-                launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, stream);
-                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, stream);
+                launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, st);
+                if (L.tinv_count > 0) {
+                    if (side) {
+                        HIP_CHECK(hipEventRecord(ev_fork, st));
+                        HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
+                        launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, side);
+                        forked = true;
+                    } else {
+                        launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, st);
+                    }
+                }
+                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, st);
             }
         }
-        // T = L11^{-1} for the block solve kernels: all supernodes at once, off the tree's critical path
-        launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, stream);
+        if (forked) {
+            HIP_CHECK(hipEventRecord(ev_join, side));
+            HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+        }
         HIP_CHECK(hipGetLastError());
         if (want_stamps) {
             std::vector<long long> h(launches.size() * 16);
-            HIP_CHECK(hipMemcpyAsync(h.data(), stamps.p, h.size() * 8, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(hipMemcpyAsync(h.data(), stamps.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
             static int printed = 0;
             if (printed++ == 2) {
                 for (size_t r = 0; r < launches.size(); ++r) {
@@ -146,8 +238,7 @@ public:
         }
     }
 
-    // d_b, d_x in the caller's (original) ordering; may alias
-    void solve(const double* d_b, double* d_x)
+    void enqueue_solve(const double* d_b, double* d_x, hipStream_t st)
     {
         SolveArgs a;
         a.T = tree();
@@ -158,12 +249,13 @@ public:
         a.out = d_x;
         a.xp = xp.p;
         a.uvec = uvec.p;
-        for (const Launch& L : launches) launch_fwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, stream);
+        for (const Launch& L : launches) launch_fwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, st);
         for (auto it = launches.rbegin(); it != launches.rend(); ++it)
-            launch_bwd(a, it->begin, it->count, it->small ? 64 : 256, it->lds_solve, stream);
+            launch_bwd(a, it->begin, it->count, it->small ? 64 : 256, it->lds_solve, st);
         HIP_CHECK(hipGetLastError());
     }
 
+public:
     // synchronises: {#dynamic regularisations, non-finite flag}
     void read_flags(int out[2])
     {
@@ -257,7 +349,14 @@ private:
                 int ncmax = 0;
                 for (int s : v) ncmax = std::max(ncmax, ncols(s));
                 L.lds_solve = L.small ? 0 : solve_lds_bytes(fmax, ncmax);
-                if (!L.small) for (int s : v) if (ncols(s) > 1) { tinv_list.push_back(s); tinv_ncmax = std::max(tinv_ncmax, ncols(s)); }
+                L.tinv_begin = (int)tinv_list.size();
+                L.tinv_ncmax = 1;
+                if (!L.small) for (int s : v) if (ncols(s) > 1) {
+                    tinv_list.push_back(s);
+                    L.tinv_ncmax = std::max(L.tinv_ncmax, ncols(s));
+                    tinv_ncmax = std::max(tinv_ncmax, ncols(s));
+                }
+                L.tinv_count = (int)tinv_list.size() - L.tinv_begin;
                 if (L.lds_solve > kLdsCap) throw std::runtime_error("front too large for the solve kernels");
                 L.tile_begin = (int)tiles.size();
                 if (!L.small) {
@@ -314,11 +413,6 @@ private:
             d_tinv_off.upload(toff);
             tinv.alloc((size_t)toff[S.nsuper]);
             HIP_CHECK(hipMemset(tinv.p, 0, std::max<size_t>(tinv.n, 1) * sizeof(double)));
-            // big ones first: the kernel is one thread per column
-            std::sort(tinv_list.begin(), tinv_list.end(), [&](int a, int b) {
-                int na = S.sn_start[a + 1] - S.sn_start[a], nb2 = S.sn_start[b + 1] - S.sn_start[b];
-                return na != nb2 ? na > nb2 : a < b;
-            });
             d_tinv_list.upload(tinv_list);
         }
         {
