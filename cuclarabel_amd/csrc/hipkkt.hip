@@ -207,8 +207,6 @@ private:
                         HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
                         launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, side);
                         forked = true;
-                    } else {
-                        launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, st);
                     }
                 }
                 launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, st);
@@ -217,6 +215,9 @@ private:
         if (forked) {
             HIP_CHECK(hipEventRecord(ev_join, side));
             HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+        } else {
+            // eager: one launch over every supernode, after the tree (all of them independent)
+            launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st);
         }
         HIP_CHECK(hipGetLastError());
         if (want_stamps) {

@@ -1,0 +1,74 @@
+"""world_size-2 `gloo` test of the N > 1 path: problems are dealt to ranks with no data-path
+collective; only the timing (MAX) and the per-problem records are exchanged."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cuclarabel_amd.distributed import assign_problems, gather_records, reduce_max
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_problems, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuclarabel_amd import problems
+        from tests.oracle_bindings import make_oracle
+        mine = assign_problems(n_problems, world, rank)
+        recs = []
+        for j in mine:
+            # each rank works on its own independent SOCP (cfg4's generator, tiny): the oracle stands
+            # in for the GPU here -- the sharding and the record exchange are what is under test
+            pb = problems.config4(j=j, n=200)
+            o = make_oracle(pb)
+            ok = o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+            o.kktsolver_setrhs(-pb.q, pb.b)
+            ok2, x, _ = o.kktsolver_solve()
+            recs.append([j, float(ok and ok2), o.last_ir_iters, float(np.abs(x).max())])
+        table = gather_records(recs, n_problems, 4)
+        tmax = reduce_max(1.0 + rank)
+        q.put((rank, mine, table.numpy(), tmax))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_record_gather():
+    world, n_problems = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_problems, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    assert out[0][1] == [0, 2, 4] and out[1][1] == [1, 3]
+    # every rank sees every problem's record, identical on both ranks, all solved
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    table = out[0][2]
+    assert list(table[:, 0]) == [0, 1, 2, 3, 4]
+    assert np.all(table[:, 1] == 1.0)
+    assert np.all(np.isfinite(table[:, 3]))
+    assert out[0][3] == out[1][3] == 2.0          # MAX over ranks
+
+
+def test_weighted_assignment_balances_and_is_a_partition():
+    w = [9, 1, 1, 1, 8, 2, 2, 7]
+    parts = [assign_problems(len(w), 3, r, weights=w) for r in range(3)]
+    assert sorted(sum(parts, [])) == list(range(len(w)))
+    loads = [sum(w[j] for j in p) for p in parts]
+    assert max(loads) - min(loads) <= 2
