@@ -1,0 +1,218 @@
+# HipKKTExt.jl -- Clarabel.jl-side binding of libhipkkt.so (include/hipkkt.h).
+#
+# NOT executed in the build container (Julia is not installed there: SURVEY.md F4); written
+# against Clarabel.jl v0.11.0 following the pattern of its own out-of-tree backends
+# (ext/directldl_hsl.jl, ext/directldl_pardiso.jl).  Two bindings:
+#
+#   A.  HipDirectLDLSolver <: AbstractDirectLDLSolver     select with
+#           Clarabel.Settings(direct_solve_method = :hipldl)
+#       smallest glue, solver.jl / kktsystem.jl / kktsolver_directldl.jl untouched.
+#   B.  HipKKTSolver <: AbstractKKTSolver                  moves assembly, regularisation and
+#       iterative refinement to the device as well; needs the one-line dispatch in
+#       src/kktsystem.jl:33 shown at the bottom (that call site hard-codes DirectLDLKKTSolver).
+#
+# Load as a package extension ([weakdeps]/[extensions] in Project.toml, as HSLExt is) or simply
+# `include` it after `using Clarabel`.  ENV["HIPKKT_LIB"] may point at libhipkkt.so.
+
+module HipKKTExt
+
+using SparseArrays, Clarabel
+import Clarabel: DefaultInt, AbstractDirectLDLSolver, AbstractKKTSolver, LinearSolverInfo, Settings
+import Clarabel: ldlsolver_constructor, ldlsolver_matrix_shape, ldlsolver_is_available
+import Clarabel: linear_solver_info, update_values!, scale_values!, refactor!, solve!
+import Clarabel: kktsolver_update!, kktsolver_setrhs!, kktsolver_solve!, kktsolver_update_P!,
+                 kktsolver_update_A!, kktsolver_linear_solver_info
+import Clarabel: CompositeCone, ZeroCone, NonnegativeCone, SecondOrderCone, PSDTriangleCone,
+                 get_Hs!, is_sparse_expandable, numel
+
+const libhipkkt = get(ENV, "HIPKKT_LIB", "libhipkkt.so")
+
+# mirrors hipkkt_settings (include/hipkkt.h); field order and types must match
+struct CSettings
+    static_regularization_constant::Cdouble
+    static_regularization_proportional::Cdouble
+    dynamic_regularization_eps::Cdouble
+    dynamic_regularization_delta::Cdouble
+    iterative_refinement_reltol::Cdouble
+    iterative_refinement_abstol::Cdouble
+    iterative_refinement_stop_ratio::Cdouble
+    iterative_refinement_max_iter::Int32
+    static_regularization_enable::Int32
+    iterative_refinement_enable::Int32
+    ordering::Int32
+    nd_leaf_size::Int32
+    device::Int32
+    user_perm::Ptr{Int64}
+    amd_dense_scale::Cdouble
+end
+
+csettings(s::Settings{Float64}) = CSettings(
+    s.static_regularization_constant, s.static_regularization_proportional,
+    s.dynamic_regularization_eps, s.dynamic_regularization_delta,
+    s.iterative_refinement_reltol, s.iterative_refinement_abstol, s.iterative_refinement_stop_ratio,
+    s.iterative_refinement_max_iter, s.static_regularization_enable, s.iterative_refinement_enable,
+    1 #= HIPKKT_ORDER_ND =#, 1000, -1, C_NULL, 1.5)
+
+struct CInfo
+    n::Int64; m::Int64; p::Int64; N::Int64; nnzK::Int64; nnzL::Int64; nnzL_stored::Int64
+    nsuper::Int64; nlevels::Int64; max_front::Int64; etree_height::Int64; nHs::Int64
+    nsparse_soc::Int64; sparse_soc_len::Int64
+    factor_flops::Cdouble; front_bytes::Cdouble; update_bytes::Cdouble
+end
+
+last_error() = unsafe_string(ccall((:hipkkt_last_error, libhipkkt), Cstring, ()))
+
+# 0 -> true, > 0 (numeric failure) -> false, < 0 -> error   (the reference's Bool convention)
+function check(rc::Cint, what)
+    rc == 0 && return true
+    rc > 0 && return false
+    error("$what failed ($rc): $(last_error())")
+end
+
+# ------------------------------------------------------------------ A. direct LDL backend
+mutable struct HipDirectLDLSolver{T} <: AbstractDirectLDLSolver{T}
+    handle::Ptr{Cvoid}
+    function HipDirectLDLSolver{T}(KKT::SparseMatrixCSC{T}, Dsigns, settings) where {T}
+        T === Float64 || error("hipldl supports Float64 only")
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        cs = Ref(csettings(settings))
+        ds = Vector{Int64}(Dsigns)
+        rc = GC.@preserve KKT ds ccall((:hipkkt_ldl_create, libhipkkt), Cint,
+            (Ref{Ptr{Cvoid}}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ref{CSettings}, Cint),
+            h, KKT.n, KKT.colptr, KKT.rowval, KKT.nzval, ds, cs, 1 #= Julia is 1-based =#)
+        check(rc, "hipkkt_ldl_create") || error("hipkkt_ldl_create: numeric failure")
+        obj = new(h[])
+        finalizer(o -> ccall((:hipkkt_ldl_destroy, libhipkkt), Cvoid, (Ptr{Cvoid},), o.handle), obj)
+        return obj
+    end
+end
+
+ldlsolver_constructor(::Val{:hipldl}) = HipDirectLDLSolver
+ldlsolver_matrix_shape(::Val{:hipldl}) = :triu
+function ldlsolver_is_available(::Val{:hipldl})     # must not throw (directldl_defaults.jl:22-27)
+    try
+        return ccall((:hipkkt_available, libhipkkt), Cint, ()) == 1
+    catch
+        return false
+    end
+end
+
+function linear_solver_info(s::HipDirectLDLSolver{T}) where {T}
+    info = Ref{CInfo}()
+    check(ccall((:hipkkt_ldl_info, libhipkkt), Cint, (Ptr{Cvoid}, Ref{CInfo}), s.handle, info), "hipkkt_ldl_info")
+    LinearSolverInfo(:hipldl, 1, true, info[].nnzK, info[].nnzL)
+end
+
+function update_values!(s::HipDirectLDLSolver{T}, index::AbstractVector{DefaultInt}, values::Vector{T}) where {T}
+    idx = index isa Vector{Int64} ? index : collect(Int64, index)      # views of the data maps are common
+    GC.@preserve idx values check(ccall((:hipkkt_ldl_update_values, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}, Int64), s.handle, idx, values, length(idx)), "hipkkt_ldl_update_values")
+end
+
+function scale_values!(s::HipDirectLDLSolver{T}, index::AbstractVector{DefaultInt}, scale::T) where {T}
+    idx = index isa Vector{Int64} ? index : collect(Int64, index)
+    GC.@preserve idx check(ccall((:hipkkt_ldl_scale_values, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Int64}, Cdouble, Int64), s.handle, idx, scale, length(idx)), "hipkkt_ldl_scale_values")
+end
+
+# K is not needed: the library holds the values pushed through update_values!/scale_values!
+refactor!(s::HipDirectLDLSolver{T}, K::SparseMatrixCSC{T}) where {T} =
+    check(ccall((:hipkkt_ldl_refactor, libhipkkt), Cint, (Ptr{Cvoid},), s.handle), "hipkkt_ldl_refactor")
+
+function solve!(s::HipDirectLDLSolver{T}, K::SparseMatrixCSC{T}, x::Vector{T}, b::Vector{T}) where {T}
+    GC.@preserve x b check(ccall((:hipkkt_ldl_solve, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), s.handle, x, b), "hipkkt_ldl_solve")
+end
+
+# ------------------------------------------------------------------ B. whole KKT solver
+mutable struct HipKKTSolver{T} <: AbstractKKTSolver{T}
+    handle::Ptr{Cvoid}
+    m::DefaultInt
+    n::DefaultInt
+    Hsblocks::Vector{T}          # get_Hs! target, as in DirectLDLKKTSolver
+    soc_u::Vector{T}
+    soc_v::Vector{T}
+    soc_eta2::Vector{T}
+
+    function HipKKTSolver{T}(P::SparseMatrixCSC{T}, A::SparseMatrixCSC{T}, cones::CompositeCone{T},
+                             m::DefaultInt, n::DefaultInt, settings::Settings{T}) where {T}
+        T === Float64 || error("hipkkt supports Float64 only")
+        kinds = Int32[]; dims = Int64[]
+        for c in cones
+            if     c isa ZeroCone         push!(kinds, 0); push!(dims, numel(c))
+            elseif c isa NonnegativeCone  push!(kinds, 1); push!(dims, numel(c))
+            elseif c isa SecondOrderCone  push!(kinds, 2); push!(dims, numel(c))
+            elseif c isa PSDTriangleCone  push!(kinds, 3); push!(dims, c.n)
+            else error("hipkkt: cone type $(typeof(c)) is not supported")
+            end
+        end
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        cs = Ref(csettings(settings))
+        Pt = triu(P)                                # data.P is already triu; harmless otherwise
+        rc = GC.@preserve Pt A kinds dims ccall((:hipkkt_kkt_create, libhipkkt), Cint,
+            (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble},
+             Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Int64, Ptr{Int32}, Ptr{Int64}, Ref{CSettings}, Cint),
+            h, n, m, Pt.colptr, Pt.rowval, Pt.nzval, A.colptr, A.rowval, A.nzval,
+            length(kinds), kinds, dims, cs, 1)
+        check(rc, "hipkkt_kkt_create") || error("hipkkt_kkt_create: numeric failure")
+        info = Ref{CInfo}()
+        check(ccall((:hipkkt_kkt_info, libhipkkt), Cint, (Ptr{Cvoid}, Ref{CInfo}), h[], info), "hipkkt_kkt_info")
+        obj = new(h[], m, n, zeros(T, info[].nHs), zeros(T, info[].sparse_soc_len),
+                  zeros(T, info[].sparse_soc_len), zeros(T, info[].nsparse_soc))
+        finalizer(o -> ccall((:hipkkt_kkt_destroy, libhipkkt), Cvoid, (Ptr{Cvoid},), o.handle), obj)
+        return obj
+    end
+end
+
+function kktsolver_update!(ks::HipKKTSolver{T}, cones::CompositeCone{T}) where {T}
+    # same data the reference reads: get_Hs! (kktsolver_directldl.jl:223) and, per sparse SOC,
+    # u, v, eta^2 (directldl_datamaps.jl:61-79)
+    get_Hs!(cones, ks.Hsblocks)
+    off = 0; k = 0
+    for c in cones
+        if c isa SecondOrderCone && is_sparse_expandable(c)
+            d = numel(c)
+            ks.soc_u[off+1:off+d] .= c.sparse_data.u
+            ks.soc_v[off+1:off+d] .= c.sparse_data.v
+            k += 1; ks.soc_eta2[k] = c.η^2
+            off += d
+        end
+    end
+    GC.@preserve ks check(ccall((:hipkkt_kkt_update_cones, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        ks.handle, ks.Hsblocks, ks.soc_u, ks.soc_v, ks.soc_eta2), "hipkkt_kkt_update_cones")
+end
+
+function kktsolver_setrhs!(ks::HipKKTSolver{T}, rhsx::AbstractVector{T}, rhsz::AbstractVector{T}) where {T}
+    x = rhsx isa Vector{T} ? rhsx : collect(rhsx); z = rhsz isa Vector{T} ? rhsz : collect(rhsz)
+    GC.@preserve x z check(ccall((:hipkkt_kkt_setrhs, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), ks.handle, x, z), "hipkkt_kkt_setrhs")
+    return nothing
+end
+
+function kktsolver_solve!(ks::HipKKTSolver{T}, lhsx::Union{Nothing,AbstractVector{T}},
+                          lhsz::Union{Nothing,AbstractVector{T}}) where {T}
+    px = isnothing(lhsx) ? Ptr{Cdouble}(C_NULL) : pointer(lhsx)
+    pz = isnothing(lhsz) ? Ptr{Cdouble}(C_NULL) : pointer(lhsz)
+    GC.@preserve lhsx lhsz check(ccall((:hipkkt_kkt_solve, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), ks.handle, px, pz), "hipkkt_kkt_solve")
+end
+
+kktsolver_update_P!(ks::HipKKTSolver{T}, P::SparseMatrixCSC{T}) where {T} =
+    (GC.@preserve P check(ccall((:hipkkt_kkt_update_P, libhipkkt), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), ks.handle, P.nzval), "hipkkt_kkt_update_P"); nothing)
+kktsolver_update_A!(ks::HipKKTSolver{T}, A::SparseMatrixCSC{T}) where {T} =
+    (GC.@preserve A check(ccall((:hipkkt_kkt_update_A, libhipkkt), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), ks.handle, A.nzval), "hipkkt_kkt_update_A"); nothing)
+
+function kktsolver_linear_solver_info(ks::HipKKTSolver{T}) where {T}
+    info = Ref{CInfo}()
+    check(ccall((:hipkkt_kkt_info, libhipkkt), Cint, (Ptr{Cvoid}, Ref{CInfo}), ks.handle, info), "hipkkt_kkt_info")
+    LinearSolverInfo(:hipkkt, 1, true, info[].nnzK, info[].nnzL)
+end
+
+end # module
+
+# ---- boundary B only: the one-line dispatch at src/kktsystem.jl:33 ("Always LDL for now")
+#
+#   kktsolver = settings.direct_solve_method === :hipkkt ?
+#       HipKKTExt.HipKKTSolver{T}(data.P, data.A, cones, m, n, settings) :
+#       DirectLDLKKTSolver{T}(data.P, data.A, cones, m, n, settings)
