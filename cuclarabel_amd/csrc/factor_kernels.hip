@@ -403,10 +403,17 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 constexpr int TS = 64;     // tile side
 constexpr int KC = 16;     // k-chunk staged in LDS
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int LDA = TS + 16;    // k-rows 80 doubles apart: consecutive k land 32 banks apart (conflict-free MFMA operand reads)
+
+// The rank-nc update runs on the matrix cores: v_mfma_f64_16x16x4_f64, each of the 4 waves owns a
+// 32 x 32 quadrant of the tile (2 x 2 MFMA tiles, 4 k-steps per staged chunk).  Operand layout
+// (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D: col = lane&15, row = (lane>>4) + 4*reg.
 __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin)
 {
-    __shared__ double As[KC][TS + 4];     // L21 rows of the tile's row range
-    __shared__ double Bs[KC][TS + 4];     // L21 rows of the tile's column range, times d_k
+    __shared__ double As[KC][LDA];        // As[k][r] = L21(r0 + r, k0 + k)
+    __shared__ double Bs[KC][LDA];        // Bs[k][c] = L21(q0 + c, k0 + k) * d_k
     __shared__ double Ct[TS][TS + 1];     // the tile, [col][row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -423,13 +430,15 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
     const int r0 = ti * TS, q0 = tj * TS;                 // tile origin inside U
     const int nr = min(TS, nb - r0), nq = min(TS, nb - q0);
 
-    // thread -> 4x4 micro-tile: rows tx + 16 a, cols 4 ty + b  (rows 16 apart: conflict-free LDS reads)
-    const int tx = tid & 15, ty = tid >> 4;
-    double acc[4][4];
+    const int wr = wv >> 1, wc = wv & 1;                  // this wave's 32 x 32 quadrant
+    // quadrants strictly above the diagonal of a diagonal tile, or wholly outside the front, are idle
+    const bool active = !(ti == tj && wr < wc) && 32 * wr < nr && 32 * wc < nq;
+    d4_t acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    const int ml = lane & 15, mk = lane >> 4;
 
     for (int k0 = 0; k0 < nc; k0 += KC) {
         const int kw = min(KC, nc - k0);
@@ -450,57 +459,54 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
             }
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < KC; ++k) {
-            double av[4], bv[4];
+        if (active) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) av[a] = As[k][tx + 16 * a];
+            for (int kk = 0; kk < KC; kk += 4) {
+                double a[2], b[2];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = Bs[k][4 * ty + b];
+                for (int i = 0; i < 2; ++i) a[i] = As[kk + mk][32 * wr + 16 * i + ml];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int j = 0; j < 2; ++j) b[j] = Bs[kk + mk][32 * wc + 16 * j + ml];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) Ct[4 * ty + b][tx + 16 * a] = -acc[a][b];
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ct[32 * wc + 16 * j + ml][32 * wr + 16 * i + mk + 4 * r] = -acc[i][j][r];
     __syncthreads();
-    // children pass-through: wave wv owns tile columns q = wv (mod 4); items of a column in order
+    // children pass-through: this wave's slice of the tile's sub-items (whole columns, child order),
+    // eight in flight: one round of descriptor loads, one round of (rel, value) loads, then LDS adds
     {
-        const int64_t lbase = (int64_t)c0 + T.rowptr[s] + nc + q0;
+        const int64_t* __restrict__ tc = T.tile_cut + 5 * (int64_t)(tile_begin + blockIdx.x);
+        const int64_t i0 = tc[wv], i1 = tc[wv + 1];
         const int rlo = nc + r0;
-        for (int q = wv; q < nq; q += 4) {
-            const int64_t i0 = T.item_ptr[lbase + q], i1 = T.item_ptr[lbase + q + 1];
-            double* colp = &Ct[q][0];
-            for (int64_t ii = i0; ii < i1; ii += 2) {
-                ExtItem it[2];
-                int alo[2], ahi[2], r[2];
-                double v[2];
+        for (int64_t ii = i0; ii < i1; ii += 8) {
+            SubItem it[8];
+            double v[8];
+            int tg[8];
 #pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    if (ii + z < i1) it[z] = T.items[ii + z];
-                    else { it[z] = it[0]; it[z].cnt = 0; }
-                }
-#pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    const int* __restrict__ cc = T.cuts + T.cut_ptr[it[z].child];
-                    alo[z] = (it[z].cnt > 0) ? max(cc[ti], it[z].b) : 0;
-                    ahi[z] = (it[z].cnt > 0) ? cc[ti + 1] : 0;
-                }
-#pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    const int a = alo[z] + lane;          // at most 64 rows of a tile
-                    const bool ok = a < ahi[z];
-                    const int t = a - it[z].b;
-                    v[z] = ok ? A.upd[it[z].uoff + t] : 0.0;
-                    r[z] = ok ? T.rel[it[z].relstart + t] - rlo : -1;
-                }
-#pragma unroll
-                for (int z = 0; z < 2; ++z) if (r[z] >= 0) colp[r[z]] += v[z];
+            for (int z = 0; z < 8; ++z) {
+                it[z] = T.sitems[min(ii + z, i1 - 1)];
+                if (ii + z >= i1) it[z].cnt = 0;
             }
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const bool ok = lane < (int)it[z].cnt;
+                v[z] = ok ? A.upd[it[z].uoff + lane] : 0.0;
+                tg[z] = ok ? (int)it[z].qcol * (TS + 1) + (T.rel[it[z].relstart + lane] - rlo) : -1;
+            }
+            double* ct = &Ct[0][0];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) if (tg[z] >= 0) ct[tg[z]] += v[z];
         }
     }
     __syncthreads();

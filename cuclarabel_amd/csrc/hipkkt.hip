@@ -283,6 +283,9 @@ private:
     DBuf<int64_t> d_item_ptr;
     DBuf<int64_t> d_items;       // ExtItem = 4 x int64
     DBuf<int64_t> d_wave_cut;
+    DBuf<int64_t> d_sitems;      // SubItem = 2 x int64
+    DBuf<int64_t> d_tile_cut;
+    std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
     DBuf<int> d_gl_src;
     std::vector<Launch> launches;
     std::vector<int> sched;
@@ -297,6 +300,7 @@ private:
         t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
         t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p;
         t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
+        t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p;
         return t;
     }
 
@@ -311,6 +315,7 @@ private:
         launches.clear();
         tiles.clear();
         tinv_list.clear();
+        tile_base.assign(S.nsuper, -1);
         auto ncols = [&](int s) { return S.sn_start[s + 1] - S.sn_start[s]; };
         auto is_small = [&](int s) {
             int f = front_size(s), nc = ncols(s), nb = f - nc;
@@ -364,6 +369,7 @@ private:
                     for (int s : v) {
                         int nb = front_size(s) - ncols(s);
                         int nt = (nb + 63) / 64;
+                        tile_base[s] = (int64_t)tiles.size();
                         for (int ti = 0; ti < nt; ++ti)
                             for (int tj = 0; tj <= ti; ++tj) {
                                 // int2 {x = s, y = ti<<16 | tj}, little endian in one int64
@@ -489,6 +495,66 @@ private:
                 wcut[(size_t)s * 17 + 16] = I1;
             }
             d_wave_cut.upload(wcut);
+            // Schur sub-items: every child update column that lands in a U column, cut at the parent's
+            // 64-row tile boundaries, grouped by (tile, tile column), children in fixed order
+            static_assert(sizeof(SubItem) == 16, "SubItem layout");
+            const int64_t ntile = (int64_t)tiles.size();
+            std::vector<int64_t> cnt((size_t)ntile * 64 + 1, 0);
+            auto for_each_sub = [&](auto&& fn) {
+                for (int p = 0; p < S.nsuper; ++p) {
+                    if (tile_base[p] < 0) continue;
+                    const int pnc = S.sn_start[p + 1] - S.sn_start[p];
+                    for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {
+                        const int c = S.child_idx[e];
+                        const int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
+                        const int* rl = S.rel.data() + S.rowptr[c];
+                        for (int b = 0; b < nbc; ++b) {
+                            if (rl[b] < pnc) continue;
+                            const int j = rl[b] - pnc, tj = j >> 6;
+                            int a = b;
+                            while (a < nbc) {
+                                const int ti = (rl[a] - pnc) >> 6;
+                                int a2 = a;
+                                while (a2 < nbc && ((rl[a2] - pnc) >> 6) == ti) ++a2;
+                                const int64_t tile = tile_base[p] + (int64_t)ti * (ti + 1) / 2 + tj;
+                                fn(tile, j & 63, c, b, a, a2 - a, nbc);
+                                a = a2;
+                            }
+                        }
+                    }
+                }
+            };
+            for_each_sub([&](int64_t tile, int q, int, int, int, int, int) { cnt[tile * 64 + q + 1]++; });
+            for (size_t i = 0; i + 1 < cnt.size(); ++i) cnt[i + 1] += cnt[i];
+            std::vector<SubItem> sit((size_t)cnt.back());
+            {
+                std::vector<int64_t> nx(cnt.begin(), cnt.end() - 1);
+                for_each_sub([&](int64_t tile, int q, int c, int b, int a, int n, int nbc) {
+                    SubItem si;
+                    si.uoff = S.upd_off[c] + (int64_t)b * nbc + a;
+                    si.relstart = (int)(S.rowptr[c] + a);
+                    si.cnt = (unsigned char)n;
+                    si.qcol = (unsigned char)q;
+                    si.pad = 0;
+                    sit[(size_t)nx[tile * 64 + q]++] = si;
+                });
+            }
+            std::vector<int64_t> tcut((size_t)ntile * 5 + 5, 0);
+            for (int64_t t = 0; t < ntile; ++t) {
+                const int64_t* cp = cnt.data() + t * 64;       // 65 column pointers of this tile
+                const int64_t I0 = cp[0], I1 = cp[64];
+                int q = 0;
+                for (int w = 0; w < 4; ++w) {
+                    const int64_t target = I0 + ((I1 - I0) * w) / 4;
+                    while (q < 64 && cp[q] < target) ++q;
+                    tcut[t * 5 + w] = cp[q];
+                }
+                tcut[t * 5 + 4] = I1;
+            }
+            std::vector<int64_t> raw2(sit.size() * 2);
+            std::memcpy(raw2.data(), sit.data(), sit.size() * sizeof(SubItem));
+            d_sitems.upload(raw2);
+            d_tile_cut.upload(tcut);
             d_gl_src.upload(gsrc);
         }
         d_perm.upload(S.perm);

@@ -25,6 +25,14 @@ struct ExtItem {                 // one child update column (rows a >= b of chil
     int pad;
 };
 
+struct SubItem {                 // a child update column restricted to one 64-row tile of the parent's U; 16 bytes
+    int64_t uoff;                // offset in the update store of the first entry
+    int relstart;                // index into rel[] of the first row
+    unsigned char cnt;           // rows (1..64)
+    unsigned char qcol;          // column inside the tile (0..63)
+    unsigned short pad;
+};
+
 struct TreeDev {                 // device copies of the symbolic structure
     const int* sn_start;         // nsuper+1
     const int64_t* rowptr;       // nsuper+1
@@ -57,6 +65,10 @@ struct TreeDev {                 // device copies of the symbolic structure
     // that end on column boundaries: a wave takes whole columns, so no two waves share a target column
     const int64_t* wave_cut;     // nsuper * 17
     const int64_t* tinv_off;     // nsuper+1: offset of the two nc x nc copies of T = L11^{-1}
+    // Schur tiles: sub-items of tile t are sitems[tile_cut[5t] .. tile_cut[5t+4]), sorted by tile column;
+    // wave w of the tile's workgroup takes [tile_cut[5t+w], tile_cut[5t+w+1]) -- whole columns
+    const SubItem* sitems;
+    const int64_t* tile_cut;     // 5 per tile
 };
 
 struct FactorArgs {

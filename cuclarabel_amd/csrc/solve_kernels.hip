@@ -293,9 +293,12 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
 
 // ------------------------------------------------------------------ T = L11^{-1} for every supernode
 // Runs once after the factorisation, all supernodes in parallel (off the critical path of the tree).
-// L11 is staged in LDS and inverted in place row by row: row i of T needs rows < i of T (already
-// there) and row i of L (not yet overwritten).  Thread j owns column j.  The result is written
-// twice, col-major for the forward solve and row-major for the backward solve.
+// L11 (unit lower, nc x nc) is staged in LDS and inverted in place, blocked bottom-up:
+//   1. every 16 x 16 diagonal block is inverted by 16 threads (thread = column, forward substitution);
+//   2. for block sizes 16, 32, 64, ...: adjacent diagonal blocks A (top) and B (bottom) are joined,
+//      T21 = -T_B * (L21 * T_A), two small products whose entries are independent -- two barriers
+//      per doubling instead of two per row.
+// The result is written twice, col-major for the forward solve and row-major for the backward solve.
 __global__ __launch_bounds__(256) void k_tinv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ tinv,
                                               const int* __restrict__ list)
 {
@@ -308,36 +311,83 @@ __global__ __launch_bounds__(256) void k_tinv(TreeDev T, const double* __restric
     const double* __restrict__ F = fronts + T.front_off[s];
     double* __restrict__ Tcm = tinv + T.tinv_off[s];
     double* __restrict__ Trm = Tcm + (int64_t)nc * nc;
-    const int ldl = nc | 1;
-    double* Ls = smem;                 // entry (i,k), i > k, at i*ldl + k
+    const int ld = nc | 1;
+    double* Ls = smem;                 // entry (i,k), i > k, at i*ld + k ; becomes T in place
+    // scratch W(i,c), i > c, lives in the unused upper triangle at the transposed slot c*ld + i
+#define WK(i, c) Ls[(c) * ld + (i)]
     for (int idx = tid; idx < nc * nc; idx += 256) {
         const int k = idx / nc, i = idx - k * nc;
-        if (i > k) Ls[i * ldl + k] = F[i + (int64_t)k * f];
+        if (i > k) Ls[i * ld + k] = F[i + (int64_t)k * f];
     }
     __syncthreads();
-    for (int i = 1; i < nc; ++i) {
-        // T(i,j) = -( L(i,j) + sum_{k=j+1}^{i-1} L(i,k) T(k,j) ), all j < i at once
-        double t[(256 + 255) / 256];
-        const double* __restrict__ Li = Ls + i * ldl;
-        {
-            const int j = tid;
-            double acc = 0.0;
-            if (j < i) {
-                acc = Li[j];
-                for (int k = j + 1; k < i; ++k) acc = fma(Li[k], Ls[k * ldl + j], acc);
+    // ---- 1. diagonal 16 x 16 blocks: thread (block b, column j) solves L_bb t = e_j in registers
+    {
+        const int nblk = (nc + 15) >> 4;
+        for (int item = tid; item < nblk * 16; item += 256) {
+            const int b = item >> 4, j = item & 15;
+            const int o = 16 * b, w = min(16, nc - o);
+            if (j >= w) continue;
+            double t[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = 0.0;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                if (i > j && i < w) {
+                    double acc = Ls[(o + i) * ld + o + j];
+#pragma unroll
+                    for (int k = 1; k < 16; ++k)
+                        if (k > j && k < i) acc = fma(Ls[(o + i) * ld + o + k], t[k], acc);
+                    t[i] = -acc;
+                }
             }
-            t[0] = -acc;
+            // column j of this block is only read by this thread (rows > j, column j): write in place
+#pragma unroll
+            for (int i = 1; i < 16; ++i)
+                if (i > j && i < w) WK(o + i, o + j) = t[i];
         }
         __syncthreads();
-        if (tid < i) Ls[i * ldl + tid] = t[0];
+        for (int item = tid; item < nblk * 256; item += 256) {
+            const int b = item >> 8, i = (item >> 4) & 15, j = item & 15;
+            const int o = 16 * b;
+            if (i > j && o + i < nc) Ls[(o + i) * ld + o + j] = WK(o + i, o + j);
+        }
+        __syncthreads();
+    }
+    // ---- 2. join adjacent blocks of size bs: rows [o+bs, o+2bs) x cols [o, o+bs)
+    for (int bs = 16; bs < nc; bs <<= 1) {
+        const int npair = (nc + 2 * bs - 1) / (2 * bs);
+        // W = L21 * T_A   (T_A unit lower: W(r,c) = L21(r,c) + sum_{k>c} L21(r,k) T_A(k,c))
+        for (int item = tid; item < npair * bs * bs; item += 256) {
+            const int p = item / (bs * bs), rem = item - p * bs * bs;
+            const int r = rem / bs, c = rem - r * bs;
+            const int o = 2 * bs * p;
+            const int gi = o + bs + r, gc = o + c;
+            if (gi >= nc) continue;
+            double acc = Ls[gi * ld + gc];
+            for (int k = c + 1; k < bs; ++k) acc = fma(Ls[gi * ld + o + k], Ls[(o + k) * ld + gc], acc);
+            WK(gi, gc) = acc;
+        }
+        __syncthreads();
+        // T21 = -T_B * W   (T_B unit lower: T21(r,c) = -(W(r,c) + sum_{k<r} T_B(r,k) W(k,c)))
+        for (int item = tid; item < npair * bs * bs; item += 256) {
+            const int p = item / (bs * bs), rem = item - p * bs * bs;
+            const int r = rem / bs, c = rem - r * bs;
+            const int o = 2 * bs * p;
+            const int gi = o + bs + r, gc = o + c;
+            if (gi >= nc) continue;
+            double acc = WK(gi, gc);
+            for (int k = 0; k < r; ++k) acc = fma(Ls[gi * ld + o + bs + k], WK(o + bs + k, gc), acc);
+            Ls[gi * ld + gc] = -acc;
+        }
         __syncthreads();
     }
     for (int idx = tid; idx < nc * nc; idx += 256) {
         const int a = idx / nc, b = idx - a * nc;
         // col-major copy: entry (i = b, j = a); row-major copy: entry (i = a, j = b)
-        if (b > a) Tcm[idx] = Ls[b * ldl + a];
-        if (a > b) Trm[idx] = Ls[a * ldl + b];
+        if (b > a) Tcm[idx] = Ls[b * ld + a];
+        if (a > b) Trm[idx] = Ls[a * ld + b];
     }
+#undef WK
 }
 
 constexpr int kSolveBS = 512;
