@@ -198,8 +198,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     double* sh_d = smem;                          // NB
     double* sh_dinv = smem + NB;                  // NB
     double* Lb = smem + 2 * NB;                   // NB x NB: Lb[j*NB + t] = d_t * L(j,t), t < j
-    double* colb = smem + 2 * NB + NB * NB;       // NB: pivot column broadcast buffer
-    double* Bd = smem + 3 * NB + NB * NB;         // NB x kBdCols: d_k * L(j,k) for the trailing columns
+    double* colb = smem + 2 * NB + NB * NB;       // 4*NB: micro-block broadcast buffer
+    double* Bd = smem + 6 * NB + NB * NB;         // NB x kBdCols: d_k * L(j,k) for the trailing columns
     double* P = Bd + NB * kBdCols;                // f x nc, ld f (+ 256 doubles of slack behind it)
 
     HIPKKT_STAMP(A, 0);
@@ -250,8 +250,11 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         const int w = min(NB, nc - kb);
         __syncthreads();
         if (A.stamps) t0 = wall_clock64();
-        // (i) diagonal block by wave 0, wave-synchronous through LDS: lane (i = lane & 15, g = lane >> 4)
-        //     holds a(i, 4g .. 4g+3); per pivot the column is broadcast through colb
+        // (i) diagonal 16 x 16 block by wave 0, wave-synchronous through LDS, in four micro-steps of four
+        //     pivots.  Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3).  Per micro-step every
+        //     lane redundantly factors the 4 x 4 diagonal micro-block in registers (no second broadcast),
+        //     solves its own row against it, and lanes right of it apply the rank-4 update: two LDS
+        //     round trips per four pivots instead of one per pivot.
         if (wv == 0) {
             const int i = lane & 15, g = lane >> 4;
             const double my_sg = (lane < w) ? (double)T.psign[c0 + kb + lane] : 1.0;
@@ -263,33 +266,84 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 const int j = 4 * g + q;
                 a4[q] = (i < w && j <= i) ? P[(kb + i) + (kb + j) * f] : 0.0;
             }
+            double* mbuf = colb;              // 64 doubles: row i's four values of the current micro column block
+            double* vbuf = Lb;                // 64 doubles: unscaled v(i,t) = l(i,t) d_t, reused before Lb is filled
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                if (k < w) {
-                    // owner lanes of column k publish it (unscaled: v_ik = l_ik d_k; v_kk = raw pivot)
-                    if (g == (k >> 2)) colb[i] = a4[k & 3];
+            for (int m = 0; m < 4; ++m) {
+                if (4 * m < w) {
+                    if (g == m) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) mbuf[i * 4 + q] = a4[q];
+                    }
                     WAVE_FENCE();
-                    double d = colb[k];
-                    const double sg = rl_f64(my_sg, k);
-                    const bool reg = (d * sg < A.dyn_eps);
-                    if (reg) d = sg * A.dyn_delta;
-                    const double dinv = 1.0 / d;
-                    const double lik = colb[i] * dinv;
-                    nreg += reg ? 1 : 0;
-                    bad = bad || !isfinite(dinv);
-                    if (lane == 0) {
-                        sh_d[k] = d;
-                        sh_dinv[k] = dinv;
-                    }
+                    double x[4][4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j = 4 * g + q;
-                        const double vjk = colb[j];
-                        if (j > k && j <= i) a4[q] = fma(-lik, vjk, a4[q]);
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) x[r][c] = mbuf[(4 * m + r) * 4 + c];
+                    double d[4], di[4], v[4][4], l[4][4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        // pivot p of the micro-block: v(r,p) = x(r,p) - sum_{t<p} l(r,t) v(p,t), r >= p
+#pragma unroll
+                        for (int r = p; r < 4; ++r) {
+                            double acc = x[r][p];
+#pragma unroll
+                            for (int t = 0; t < p; ++t) acc = fma(-l[r][t], v[p][t], acc);
+                            v[r][p] = acc;
+                        }
+                        double dd = v[p][p];
+                        const int k = 4 * m + p;
+                        if (k < w) {
+                            const double sg = rl_f64(my_sg, k);
+                            const bool reg = (dd * sg < A.dyn_eps);
+                            if (reg) dd = sg * A.dyn_delta;
+                            nreg += reg ? 1 : 0;
+                        } else {
+                            dd = 1.0;
+                        }
+                        d[p] = dd;
+                        di[p] = 1.0 / dd;
+                        bad = bad || !isfinite(di[p]);
+#pragma unroll
+                        for (int r = p + 1; r < 4; ++r) l[r][p] = v[r][p] * di[p];
                     }
-                    if (g == (k >> 2)) {
-                        if (i > k) a4[k & 3] = lik;           // scaled L(i,k)
-                        else if (i == k) a4[k & 3] = d;
+                    // my own row against the micro-block: vr(t) = r_t - sum_{u<t} lr(u) v(t,u); lr(t) = vr(t)/d_t
+                    double rr[4], vr[4], lr[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) rr[t] = mbuf[i * 4 + t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        double acc = rr[t];
+#pragma unroll
+                        for (int u = 0; u < t; ++u) acc = fma(-lr[u], v[t][u], acc);
+                        vr[t] = acc;
+                        lr[t] = acc * di[t];
+                    }
+                    if (g == m) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            vbuf[i * 4 + t] = vr[t];
+                            const int k = 4 * m + t;
+                            if (i > k) a4[t] = lr[t];          // scaled L(i,k)
+                            else if (i == k) a4[t] = d[t];
+                        }
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { sh_d[4 * m + t] = d[t]; sh_dinv[4 * m + t] = di[t]; }
+                    }
+                    WAVE_FENCE();
+                    // rank-4 update of the columns to the right: a(i,j) -= sum_t l(i,t) v(j,t), j = 4g+q > 4m+3
+                    if (g > m) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int j = 4 * g + q;
+                            double acc = a4[q];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc = fma(-lr[t], vbuf[j * 4 + t], acc);
+                            if (j <= i) a4[q] = acc;
+                        }
                     }
                     WAVE_FENCE();
                 }
@@ -298,6 +352,11 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             for (int q = 0; q < 4; ++q) {
                 const int j = 4 * g + q;
                 if (i < w && j <= i) P[(kb + i) + (kb + j) * f] = a4[q];
+            }
+            WAVE_FENCE();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * g + q;
                 if (i < w && j < i) Lb[i * NB + j] = a4[q] * sh_d[j];
             }
             if (lane < w) A.Dinv[c0 + kb + lane] = sh_dinv[lane];
@@ -520,7 +579,7 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
 size_t panel_lds_bytes(int fmax, int panel_max)
 {
     (void)fmax;
-    return ((size_t)3 * NB + NB * NB + NB * kBdCols + (size_t)panel_max + 256) * sizeof(double);
+    return ((size_t)6 * NB + NB * NB + NB * kBdCols + (size_t)panel_max + 256) * sizeof(double);
 }
 
 static void init_factor_lds()

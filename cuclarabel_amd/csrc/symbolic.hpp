@@ -29,7 +29,7 @@ struct SymbolicOptions {
     double relax_zeros[4] = {1.0, 0.5, 0.15, 0.05};
     // a supernode's panel (f x nc doubles) is kept LDS-resident while it is factorised: wider
     // supernodes are split into a chain so that f*nc <= panel_cap (0 = no splitting)
-    int64_t panel_cap = 17408;
+    int64_t panel_cap = 17344;
     const int64_t* user_perm = nullptr;
 };
 
