@@ -357,7 +357,7 @@ private:
                 L.lds_solve = L.small ? 0 : solve_lds_bytes(fmax, ncmax);
                 L.tinv_begin = (int)tinv_list.size();
                 L.tinv_ncmax = 1;
-                if (!L.small) for (int s : v) if (ncols(s) > 1) {
+                if (!L.small) for (int s : v) {
                     tinv_list.push_back(s);
                     L.tinv_ncmax = std::max(L.tinv_ncmax, ncols(s));
                     tinv_ncmax = std::max(tinv_ncmax, ncols(s));
@@ -415,7 +415,8 @@ private:
             for (int s : tinv_list) in_list[s] = 1;
             for (int s = 0; s < S.nsuper; ++s) {
                 int64_t nc = S.sn_start[s + 1] - S.sn_start[s];
-                toff[s + 1] = toff[s] + (in_list[s] ? 2 * nc * nc : 0);
+                int64_t fs = nc + (S.rowptr[s + 1] - S.rowptr[s]);
+                toff[s + 1] = toff[s] + (in_list[s] ? fs * nc : 0);
             }
             d_tinv_off.upload(toff);
             tinv.alloc((size_t)toff[S.nsuper]);

@@ -64,7 +64,7 @@ struct TreeDev {                 // device copies of the symbolic structure
     // per supernode: 17 item indices splitting its panel items (local columns < nc) into 16 slices
     // that end on column boundaries: a wave takes whole columns, so no two waves share a target column
     const int64_t* wave_cut;     // nsuper * 17
-    const int64_t* tinv_off;     // nsuper+1: offset of the two nc x nc copies of T = L11^{-1}
+    const int64_t* tinv_off;     // nsuper+1: offset of the solve matrix W = [L11^{-1}; L21 L11^{-1}] (f x nc)
     // Schur tiles: sub-items of tile t are sitems[tile_cut[5t] .. tile_cut[5t+4]), sorted by tile column;
     // wave w of the tile's workgroup takes [tile_cut[5t+w], tile_cut[5t+w+1]) -- whole columns
     const SubItem* sitems;
@@ -90,7 +90,7 @@ struct FactorArgs {
 struct SolveArgs {
     TreeDev T;
     const double* fronts;
-    const double* tinv;          // per supernode: T col-major, then T row-major
+    const double* tinv;          // per supernode: W = [T; M], f x nc col-major
     const double* Dinv;
     const double* b;             // original order
     double* out;                 // original order

@@ -116,42 +116,15 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
 }
 
 // ------------------------------------------------------------------ larger fronts, one block each
-// With T = L11^{-1} precomputed after the factorisation (k_tinv), a front's solve is three streaming
-// phases whose loads are all independent of each other -- no sequential substitution on the
-// critical path:
-//   forward :  y <- gather ;  y_s <- T y_s          ;  y_below <- y_below - L21 y_s
-//   backward:  y <- gather ;  t   <- y_s - L21' y_b ;  x_s     <- T' t
-// Work is cut into items of 8 matrix columns x 64 rows; a wave issues the 8 loads of an item
-// together.  Partial sums go to LDS and are combined in a fixed order (bit-reproducible).
-
-// part[ks * ldp + r] = sum_{q<8} M[(r0 + r) + (k0 + 8 ks + q) * ld] * v[8 ks + q]   (rows r < R, cols k < Kn)
-// lower != 0: M is strictly lower triangular in (r, k) coordinates (k < r only)
-template <int NW>
-__device__ inline void sliced_matvec(const double* __restrict__ M, int64_t ld, int R, int Kn, const double* v,
-                                     double* part, int ldp, bool lower, int wv, int lane)
-{
-    const int nrb = (R + 63) >> 6, nks = (Kn + 7) >> 3;
-    for (int it = wv; it < nrb * nks; it += NW) {
-        const int ks = it / nrb, rb = it - ks * nrb;
-        const int r = rb * 64 + lane, k0 = 8 * ks;
-        if (lower && k0 >= rb * 64 + 63) {            // whole item on or above the diagonal
-            if (r < R) part[ks * ldp + r] = 0.0;
-            continue;
-        }
-        double m[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + q;
-            const bool ok = r < R && k < Kn && (!lower || k < r);
-            m[q] = ok ? M[r + (int64_t)k * ld] : 0.0;
-        }
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = fma(m[q], (k0 + q < Kn) ? v[k0 + q] : 0.0, acc);
-        if (r < R) part[ks * ldp + r] = acc;
-    }
-}
-
+// After the factorisation k_winv forms, per supernode, the "solve matrix"
+//        W = [ T ; M ],   T = L11^{-1} (unit lower, nc x nc),   M = L21 * T  (nb x nc),
+// stored f x nc col-major.  With it a front's solve is ONE streaming matrix-vector phase per
+// sweep (no substitution, no second dependent phase):
+//   forward :  y <- gather ;  [x_s ; w] = W y_s ;           contribution = y_below - w
+//   backward:  z = [D^{-1} y_s ; -x_below] ;  x_s = W' z
+// (L^{-1} restricted to a front is [T 0; -M I], and its transpose gives the backward form.)
+// Work is cut into items of 8 columns x 64 rows, 8 independent loads per lane in flight; partial
+// sums are combined in a fixed order (bit-reproducible).
 template <int BS>
 __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
 {
@@ -166,8 +139,7 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
     const int64_t rp = T.rowptr[s];
     const int nb = (int)(T.rowptr[s + 1] - rp);
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + T.front_off[s];
-    const double* __restrict__ Tcm = A.tinv + T.tinv_off[s];          // T(i,j) at i + j*nc
+    const double* __restrict__ W = A.tinv + T.tinv_off[s];             // f x nc, ld f
     const int fpad = (f + 3) & ~3;
     double* y = smem;                        // fpad
     double* part = smem + fpad;              // nks * fpad
@@ -190,26 +162,28 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
         y[i] = v;
     }
     __syncthreads();
-    const int nks = (nc + 7) >> 3;
-    // y_s <- T y_s  (T unit lower: strictly-lower part times y, plus y itself)
-    sliced_matvec<NW>(Tcm, nc, nc, nc, y, part, fpad, true, wv, lane);
-    __syncthreads();
-    for (int i = tid; i < nc; i += BS) {
-        double v = y[i];
-        for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
-        y[i] = v;
-        A.xp[c0 + i] = v;
+    const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6;
+    for (int it = wv; it < nrb * nks; it += NW) {
+        const int ks = it / nrb, rb = it - ks * nrb;
+        const int r = rb * 64 + lane, k0 = 8 * ks;
+        if (rb * 64 + 63 < k0) {                      // wholly above T's diagonal: zeros
+            if (r < f) part[ks * fpad + r] = 0.0;
+            continue;
+        }
+        double m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = (r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fma(m[q], (k0 + q < nc) ? y[k0 + q] : 0.0, acc);
+        if (r < f) part[ks * fpad + r] = acc;
     }
     __syncthreads();
-    // y_below <- y_below - L21 y_s
-    if (nb > 0) {
-        sliced_matvec<NW>(F + nc, f, nb, nc, y, part, fpad, false, wv, lane);
-        __syncthreads();
-        for (int t = tid; t < nb; t += BS) {
-            double v = y[nc + t];
-            for (int ks = 0; ks < nks; ++ks) v -= part[ks * fpad + t];
-            A.uvec[rp + t] = v;
-        }
+    for (int i = tid; i < f; i += BS) {
+        double v = 0.0;
+        for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
+        if (i < nc) A.xp[c0 + i] = v;
+        else A.uvec[rp + i - nc] = y[i] - v;
     }
 }
 
@@ -227,79 +201,49 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
     const int64_t rp = T.rowptr[s];
     const int nb = (int)(T.rowptr[s + 1] - rp);
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + T.front_off[s];
-    const double* __restrict__ Trm = A.tinv + T.tinv_off[s] + (int64_t)nc * nc;   // T(i,j) at j + i*nc
-    const int fpad = (f + 3) & ~3;
-    double* y = smem;
-    double* part = smem + fpad;
+    const double* __restrict__ W = A.tinv + T.tinv_off[s];
+    double* z = smem;
 
+    // z = [D^{-1} y_s ; -x_below]
     for (int i = tid; i < f; i += BS)
-        y[i] = (i < nc) ? A.xp[c0 + i] * A.Dinv[c0 + i] : A.xp[T.rows[rp + i - nc]];
+        z[i] = (i < nc) ? A.xp[c0 + i] * A.Dinv[c0 + i] : -A.xp[T.rows[rp + i - nc]];
     __syncthreads();
-    // t_j = y_j - sum_r L21(r,j) y_b(r): a wave takes 8 columns, lanes over rows, then 8 wave reductions
-    if (nb > 0) {
-        const int ncg = (nc + 7) >> 3;
-        for (int cg = wv; cg < ncg; cg += NW) {
-            double acc[8];
+    // x_j = sum_{r >= j} W(r,j) z_r : a wave takes 8 columns, lanes over rows, then 8 wave reductions
+    const int ncg = (nc + 7) >> 3;
+    for (int cg = wv; cg < ncg; cg += NW) {
+        double acc[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-            for (int r = lane; r < nb; r += 64) {
-                const double yr = y[nc + r];
-                double m[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) m[q] = (8 * cg + q < nc) ? F[(nc + r) + (int64_t)(8 * cg + q) * f] : 0.0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = fma(m[q], yr, acc[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double sum = wave_reduce_sum(acc[q]);
-                if (lane == 0 && 8 * cg + q < nc) y[8 * cg + q] -= sum;
-            }
-        }
-        __syncthreads();
-    }
-    // x_s = T' t : x_j = t_j + sum_{i>j} T(i,j) t_i ; Trm is T' column-major, strictly UPPER in (j,i)
-    // -> reuse the sliced kernel on the transposed roles: rows = j, cols = i, keep i > j
-    {
-        const int nrb = (nc + 63) >> 6, nks = (nc + 7) >> 3;
-        for (int it = wv; it < nrb * nks; it += NW) {
-            const int ks = it / nrb, rb = it - ks * nrb;
-            const int j = rb * 64 + lane, i0 = 8 * ks;
-            if (i0 + 7 <= rb * 64) {                   // whole item on or below the diagonal
-                if (j < nc) part[ks * fpad + j] = 0.0;
-                continue;
-            }
+        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+        const int rstart = (8 * cg) & ~63;            // rows above the column group's diagonal are zero
+        for (int r = rstart + lane; r < f; r += 64) {
+            const double zr = z[r];
             double m[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = i0 + q;
-                m[q] = (j < nc && i < nc && i > j) ? Trm[j + (int64_t)i * nc] : 0.0;
-            }
-            double acc = 0.0;
+            for (int q = 0; q < 8; ++q) m[q] = (8 * cg + q < nc) ? W[r + (int64_t)(8 * cg + q) * f] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = fma(m[q], (i0 + q < nc) ? y[i0 + q] : 0.0, acc);
-            if (j < nc) part[ks * fpad + j] = acc;
+            for (int q = 0; q < 8; ++q) acc[q] = fma(m[q], zr, acc[q]);
         }
-        __syncthreads();
-        for (int j = tid; j < nc; j += BS) {
-            double v = y[j];
-            for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + j];
-            A.xp[c0 + j] = v;
-            A.out[T.perm[c0 + j]] = v;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double sum = wave_reduce_sum(acc[q]);
+            const int j = 8 * cg + q;
+            if (lane == 0 && j < nc) {
+                A.xp[c0 + j] = sum;
+                A.out[T.perm[c0 + j]] = sum;
+            }
         }
     }
 }
 
-// ------------------------------------------------------------------ T = L11^{-1} for every supernode
+// ------------------------------------------------------------------ W = [L11^{-1} ; L21 L11^{-1}]
 // Runs once after the factorisation, all supernodes in parallel (off the critical path of the tree).
 // L11 (unit lower, nc x nc) is staged in LDS and inverted in place, blocked bottom-up:
 //   1. every 16 x 16 diagonal block is inverted by 16 threads (thread = column, forward substitution);
 //   2. for block sizes 16, 32, 64, ...: adjacent diagonal blocks A (top) and B (bottom) are joined,
 //      T21 = -T_B * (L21 * T_A), two small products whose entries are independent -- two barriers
 //      per doubling instead of two per row.
-// The result is written twice, col-major for the forward solve and row-major for the backward solve.
-__global__ __launch_bounds__(256) void k_tinv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ tinv,
+// Then M = L21 * T, one thread per row, 8 columns at a time against T in LDS.
+__global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ wst,
                                               const int* __restrict__ list)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -307,10 +251,10 @@ __global__ __launch_bounds__(256) void k_tinv(TreeDev T, const double* __restric
     const int s = list[blockIdx.x];
     const int c0 = T.sn_start[s];
     const int nc = T.sn_start[s + 1] - c0;
-    const int f = nc + (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const int f = nc + nb;
     const double* __restrict__ F = fronts + T.front_off[s];
-    double* __restrict__ Tcm = tinv + T.tinv_off[s];
-    double* __restrict__ Trm = Tcm + (int64_t)nc * nc;
+    double* __restrict__ W = wst + T.tinv_off[s];
     const int ld = nc | 1;
     double* Ls = smem;                 // entry (i,k), i > k, at i*ld + k ; becomes T in place
     // scratch W(i,c), i > c, lives in the unused upper triangle at the transposed slot c*ld + i
@@ -340,7 +284,6 @@ __global__ __launch_bounds__(256) void k_tinv(TreeDev T, const double* __restric
                     t[i] = -acc;
                 }
             }
-            // column j of this block is only read by this thread (rows > j, column j): write in place
 #pragma unroll
             for (int i = 1; i < 16; ++i)
                 if (i > j && i < w) WK(o + i, o + j) = t[i];
@@ -381,13 +324,31 @@ __global__ __launch_bounds__(256) void k_tinv(TreeDev T, const double* __restric
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < nc * nc; idx += 256) {
-        const int a = idx / nc, b = idx - a * nc;
-        // col-major copy: entry (i = b, j = a); row-major copy: entry (i = a, j = b)
-        if (b > a) Tcm[idx] = Ls[b * ld + a];
-        if (a > b) Trm[idx] = Ls[a * ld + b];
-    }
 #undef WK
+    // ---- 3. T part of W (unit diagonal, zeros above)
+    for (int idx = tid; idx < nc * nc; idx += 256) {
+        const int j = idx / nc, i = idx - j * nc;
+        W[i + (int64_t)j * f] = (i > j) ? Ls[i * ld + j] : (i == j ? 1.0 : 0.0);
+    }
+    // ---- 4. M = L21 * T: thread = row, 8 columns at a time; T(k,c) broadcast from LDS
+    for (int r = tid; r < nb; r += 256) {
+        const double* __restrict__ Lr = F + nc + r;
+        for (int cb = 0; cb < nc; cb += 8) {
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = (cb + q < nc) ? Lr[(int64_t)(cb + q) * f] : 0.0;   // k = c term
+            for (int k = cb + 1; k < nc; ++k) {
+                const double l = Lr[(int64_t)k * f];
+                const double* __restrict__ Tk = Ls + k * ld + cb;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (cb + q < k) acc[q] = fma(l, Tk[q], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (cb + q < nc) W[(nc + r) + (int64_t)(cb + q) * f] = acc[q];
+        }
+    }
 }
 
 constexpr int kSolveBS = 512;
@@ -401,7 +362,7 @@ static void init_solve_lds()
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_block<kSolveBS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tinv), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_winv), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
 }
 
@@ -438,7 +399,7 @@ void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int
     if (count <= 0) return;
     init_solve_lds();
     const size_t lds = (size_t)ncmax * (ncmax | 1) * sizeof(double);
-    hipLaunchKernelGGL(k_tinv, dim3(count), dim3(256), lds, st, T, fronts, tinv, list);
+    hipLaunchKernelGGL(k_winv, dim3(count), dim3(256), lds, st, T, fronts, tinv, list);
 }
 
 }  // namespace hipkkt
