@@ -330,23 +330,44 @@ __global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restric
         const int j = idx / nc, i = idx - j * nc;
         W[i + (int64_t)j * f] = (i > j) ? Ls[i * ld + j] : (i == j ? 1.0 : 0.0);
     }
-    // ---- 4. M = L21 * T: thread = row, 8 columns at a time; T(k,c) broadcast from LDS
-    for (int r = tid; r < nb; r += 256) {
-        const double* __restrict__ Lr = F + nc + r;
-        for (int cb = 0; cb < nc; cb += 8) {
-            double acc[8];
+    // ---- 4. M = L21 * T on the matrix cores (v_mfma_f64_16x16x4_f64): a wave owns a strip of 16 rows
+    //         and all column tiles; A = L21 straight from global (16 contiguous rows per k), B = T from LDS
+    //         with its unit diagonal / zero upper part generated on the fly; column tiles right of k are skipped.
+    {
+        typedef double d4_t __attribute__((ext_vector_type(4)));
+        const int lane = tid & 63, wvi = tid >> 6;
+        const int ml = lane & 15, mk = lane >> 4;
+        const int nct = (nc + 15) >> 4;                 // column tiles (<= 9 for nc <= 144)
+        for (int strip = wvi; strip * 16 < nb; strip += 4) {
+            const int r = strip * 16 + ml;
+            const double* __restrict__ Lr = F + nc + r;
+            d4_t acc[9];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = (cb + q < nc) ? Lr[(int64_t)(cb + q) * f] : 0.0;   // k = c term
-            for (int k = cb + 1; k < nc; ++k) {
-                const double l = Lr[(int64_t)k * f];
-                const double* __restrict__ Tk = Ls + k * ld + cb;
+            for (int jt = 0; jt < 9; ++jt) acc[jt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < nc; k0 += 4) {
+                const int k = k0 + mk;
+                const double a = (r < nb && k < nc) ? Lr[(int64_t)k * f] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (cb + q < k) acc[q] = fma(l, Tk[q], acc[q]);
+                for (int jt = 0; jt < 9; ++jt) {
+                    if (jt < nct && 16 * jt <= k0 + 3) {
+                        const int j = 16 * jt + ml;
+                        double bv = 0.0;
+                        if (k < nc && j < nc) bv = (k > j) ? Ls[k * ld + j] : (k == j ? 1.0 : 0.0);
+                        acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[jt], 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (cb + q < nc) W[(nc + r) + (int64_t)(cb + q) * f] = acc[q];
+            for (int jt = 0; jt < 9; ++jt) {
+                if (jt < nct) {
+                    const int j = 16 * jt + ml;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr = strip * 16 + mk + 4 * q;
+                        if (rr < nb && j < nc) W[(nc + rr) + (int64_t)j * f] = acc[jt][q];
+                    }
+                }
+            }
         }
     }
 }
