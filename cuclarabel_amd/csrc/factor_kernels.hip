@@ -54,21 +54,19 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
     const int item = blockIdx.x * 4 + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
-    const int s = T.sched[begin + item];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const FrontDesc fd = T.desc[begin + item];
+    const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int f = nc + nb;
-    double* __restrict__ F = A.fronts + T.front_off[s];
-    double* __restrict__ U = A.upd + T.upd_off[s];
+    double* __restrict__ F = A.fronts + fd.front_off;
+    double* __restrict__ U = A.upd + fd.upd_off;
     double* P = smem + (size_t)wv * slice;       // f x nc, ld f
     double* Us = P + f * nc;                     // nb x nb, ld nb
 
     for (int i = lane; i < f * nc + nb * nb; i += 64) P[i] = 0.0;
     WAVE_FENCE();
     {   // K entries
-        const int64_t e0 = T.kptr[s];
-        const int ne = (int)(T.kptr[s + 1] - e0);
+        const int64_t e0 = fd.kptr;
+        const int ne = fd.nk;
         for (int e = lane; e < ne; e += 64) P[T.kdst[e0 + e]] = A.Kval[T.ksrc[e0 + e]];
     }
     WAVE_FENCE();
@@ -188,12 +186,10 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const int s = T.sched[begin + blockIdx.x];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int f = nc + nb;
-    double* __restrict__ F = A.fronts + T.front_off[s];
+    double* __restrict__ F = A.fronts + fd.front_off;
 
     double* sh_d = smem;                          // NB
     double* sh_dinv = smem + NB;                  // NB
@@ -210,8 +206,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     HIPKKT_STAMP(A, 1);
     // ---- 2. scatter K, four entries per thread in flight
     {
-        const int64_t e0 = T.kptr[s];
-        const int ne = (int)(T.kptr[s + 1] - e0);
+        const int64_t e0 = fd.kptr;
+        const int ne = fd.nk;
         for (int base = 0; base < ne; base += 4 * BS) {
             int src[4], dst[4];
             double v[4];

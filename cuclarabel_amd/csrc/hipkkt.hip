@@ -285,6 +285,7 @@ private:
     DBuf<int64_t> d_wave_cut;
     DBuf<int64_t> d_sitems;      // SubItem = 2 x int64
     DBuf<int64_t> d_tile_cut;
+    DBuf<int64_t> d_desc;        // FrontDesc = 8 x int64
     std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
     DBuf<int> d_gl_src;
     std::vector<Launch> launches;
@@ -300,7 +301,7 @@ private:
         t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
         t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p;
         t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
-        t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p;
+        t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p; t.desc = (const FrontDesc*)d_desc.p;
         return t;
     }
 
@@ -419,6 +420,19 @@ private:
                 toff[s + 1] = toff[s] + (in_list[s] ? fs * nc : 0);
             }
             d_tinv_off.upload(toff);
+            static_assert(sizeof(FrontDesc) == 64, "FrontDesc layout");
+            std::vector<FrontDesc> desc(sched.size());
+            for (size_t q = 0; q < sched.size(); ++q) {
+                const int s = sched[q];
+                FrontDesc d;
+                d.front_off = S.front_off[s]; d.upd_off = S.upd_off[s]; d.w_off = toff[s]; d.rp = S.rowptr[s];
+                d.kptr = S.kptr[s]; d.s = s; d.c0 = S.sn_start[s]; d.nc = S.sn_start[s + 1] - S.sn_start[s];
+                d.nb = (int)(S.rowptr[s + 1] - S.rowptr[s]); d.nk = (int)(S.kptr[s + 1] - S.kptr[s]); d.pad = 0;
+                desc[q] = d;
+            }
+            std::vector<int64_t> rawd(desc.size() * 8);
+            std::memcpy(rawd.data(), desc.data(), desc.size() * sizeof(FrontDesc));
+            d_desc.upload(rawd);
             tinv.alloc((size_t)toff[S.nsuper]);
             HIP_CHECK(hipMemset(tinv.p, 0, std::max<size_t>(tinv.n, 1) * sizeof(double)));
             d_tinv_list.upload(tinv_list);

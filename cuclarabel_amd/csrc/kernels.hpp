@@ -33,6 +33,20 @@ struct SubItem {                 // a child update column restricted to one 64-r
     unsigned short pad;
 };
 
+struct FrontDesc {               // everything a kernel needs to know about one front, in launch order; 64 bytes
+    int64_t front_off;           // panel store offset
+    int64_t upd_off;             // update store offset
+    int64_t w_off;               // solve-matrix store offset
+    int64_t rp;                  // rowptr[s]
+    int64_t kptr;                // first K entry
+    int s;                       // supernode id
+    int c0;                      // first column
+    int nc;                      // columns
+    int nb;                      // rows below
+    int nk;                      // K entries
+    int pad;
+};
+
 struct TreeDev {                 // device copies of the symbolic structure
     const int* sn_start;         // nsuper+1
     const int64_t* rowptr;       // nsuper+1
@@ -47,6 +61,8 @@ struct TreeDev {                 // device copies of the symbolic structure
     const int* ksrc;
     const int* kdst;
     const int* sched;            // supernodes in launch order (level by level, size class inside)
+    const FrontDesc* desc;       // same order: one 64-byte record per launch slot (one scalar load instead of a
+                                 // chain of dependent index loads at the head of every kernel)
     const signed char* psign;    // N: expected pivot sign, permuted order
     const int* perm;             // N: perm[new] = old
     // Extend-add work lists.  Local column j of front s has index lc = sn_start[s] + rowptr[s] + j.

@@ -39,13 +39,11 @@ __global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int co
     const int item = blockIdx.x * 4 + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
-    const int s = T.sched[begin + item];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int64_t rp = T.rowptr[s];
-    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const FrontDesc fd = T.desc[begin + item];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + T.front_off[s];
+    const double* __restrict__ F = A.fronts + fd.front_off;
 
     // gather: right-hand side entry plus the children's contributions to this row, in child order
     double y = (lane < nc) ? A.b[T.perm[c0 + lane]] : 0.0;
@@ -81,13 +79,11 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
     const int item = blockIdx.x * 4 + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
-    const int s = T.sched[begin + item];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int64_t rp = T.rowptr[s];
-    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const FrontDesc fd = T.desc[begin + item];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + T.front_off[s];
+    const double* __restrict__ F = A.fronts + fd.front_off;
 
     double y = 0.0;
     if (lane < nc) y = A.xp[c0 + lane] * A.Dinv[c0 + lane];
@@ -133,13 +129,11 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const int s = T.sched[begin + blockIdx.x];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int64_t rp = T.rowptr[s];
-    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
     const int f = nc + nb;
-    const double* __restrict__ W = A.tinv + T.tinv_off[s];             // f x nc, ld f
+    const double* __restrict__ W = A.tinv + fd.w_off;                  // f x nc, ld f
     const int fpad = (f + 3) & ~3;
     double* y = smem;                        // fpad
     double* part = smem + fpad;              // nks * fpad
@@ -195,13 +189,11 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const int s = T.sched[begin + blockIdx.x];
-    const int c0 = T.sn_start[s];
-    const int nc = T.sn_start[s + 1] - c0;
-    const int64_t rp = T.rowptr[s];
-    const int nb = (int)(T.rowptr[s + 1] - rp);
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
     const int f = nc + nb;
-    const double* __restrict__ W = A.tinv + T.tinv_off[s];
+    const double* __restrict__ W = A.tinv + fd.w_off;
     double* z = smem;
 
     // z = [D^{-1} y_s ; -x_below]
