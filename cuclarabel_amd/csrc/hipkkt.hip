@@ -250,10 +250,32 @@ private:
         a.out = d_x;
         a.xp = xp.p;
         a.uvec = uvec.p;
-        for (const Launch& L : launches) launch_fwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, st);
-        for (auto it = launches.rbegin(); it != launches.rend(); ++it)
-            launch_bwd(a, it->begin, it->count, it->small ? 64 : 256, it->lds_solve, st);
+        static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
+        const size_t nl = launches.size();
+        const size_t ntl = no_top ? 0 : top_launches;            // the last ntl launches form the persistent top
+        for (size_t q = 0; q + ntl < nl; ++q) {
+            const Launch& L = launches[q];
+            launch_fwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, st);
+        }
+        if (ntl > 0) {
+            const Launch& L0 = launches[nl - ntl];
+            launch_top_solve(a, L0.begin, top_count, top_lds, top_flags.p, ++top_epoch, st);
+        }
+        for (size_t q = nl - ntl; q-- > 0;) {
+            const Launch& L = launches[q];
+            launch_bwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, st);
+        }
         HIP_CHECK(hipGetLastError());
+    }
+
+    // synchronises; true if the persistent top kernel gave up on a flag (never expected)
+    bool top_aborted()
+    {
+        if (!top_flags.p || top_launches == 0) return false;
+        int v = 0;
+        HIP_CHECK(hipMemcpyAsync(&v, top_flags.p + 2 * top_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return v != 0;
     }
 
 public:
@@ -286,6 +308,9 @@ private:
     DBuf<int64_t> d_sitems;      // SubItem = 2 x int64
     DBuf<int64_t> d_tile_cut;
     DBuf<int64_t> d_desc;        // FrontDesc = 8 x int64
+    DBuf<int> d_spos, d_sn_parent, top_flags;
+    size_t top_launches = 0, top_lds = 0;
+    int top_count = 0, top_epoch = 0;
     std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
     DBuf<int> d_gl_src;
     std::vector<Launch> launches;
@@ -302,6 +327,7 @@ private:
         t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p;
         t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
         t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p; t.desc = (const FrontDesc*)d_desc.p;
+        t.spos = d_spos.p; t.sn_parent = d_sn_parent.p;
         return t;
     }
 
@@ -433,6 +459,22 @@ private:
             std::vector<int64_t> rawd(desc.size() * 8);
             std::memcpy(rawd.data(), desc.data(), desc.size() * sizeof(FrontDesc));
             d_desc.upload(rawd);
+            std::vector<int> spos(S.nsuper, -1);
+            for (size_t q = 0; q < sched.size(); ++q) spos[sched[q]] = (int)q;
+            d_spos.upload(spos);
+            d_sn_parent.upload(S.sn_parent);
+            // persistent top: the longest suffix of block-class launches with <= kTopMaxFronts fronts
+            top_launches = 0; top_count = 0; top_lds = 0;
+            for (size_t q = launches.size(); q-- > 0;) {
+                const Launch& L = launches[q];
+                if (L.small || top_count + L.count > kTopMaxFronts) break;
+                top_count += L.count;
+                top_lds = std::max(top_lds, L.lds_solve);
+                ++top_launches;
+            }
+            if (top_launches < 3) { top_launches = 0; top_count = 0; }     // not worth a special kernel
+            top_flags.alloc((size_t)2 * std::max(top_count, 1) + 4);
+            HIP_CHECK(hipMemset(top_flags.p, 0, top_flags.n * sizeof(int)));
             tinv.alloc((size_t)toff[S.nsuper]);
             HIP_CHECK(hipMemset(tinv.p, 0, std::max<size_t>(tinv.n, 1) * sizeof(double)));
             d_tinv_list.upload(tinv_list);

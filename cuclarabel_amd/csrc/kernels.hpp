@@ -61,6 +61,8 @@ struct TreeDev {                 // device copies of the symbolic structure
     const int* ksrc;
     const int* kdst;
     const int* sched;            // supernodes in launch order (level by level, size class inside)
+    const int* spos;             // supernode -> position in sched
+    const int* sn_parent;        // assembly tree
     const FrontDesc* desc;       // same order: one 64-byte record per launch slot (one scalar load instead of a
                                  // chain of dependent index loads at the head of every kernel)
     const signed char* psign;    // N: expected pivot sign, permuted order
@@ -117,6 +119,9 @@ struct SolveArgs {
 constexpr int kSolveChunk = 128;  // diagonal chunk of the triangular solves: one wave, two unknowns per lane
 constexpr int kMaxNbk = 16;
 size_t solve_lds_bytes(int fmax, int ncmax);
+// persistent kernel over the top `count` fronts (schedule positions begin ..): forward then backward sweep
+constexpr int kTopMaxFronts = 480;
+void launch_top_solve(const SolveArgs& a, int begin, int count, size_t lds, int* flags, int epoch, hipStream_t st);
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st);
 

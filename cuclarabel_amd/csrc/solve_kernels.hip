@@ -227,6 +227,166 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
     }
 }
 
+// ------------------------------------------------------------------ top of the tree, persistent
+// The top levels of the assembly tree hold few fronts each (a chain of separators), so a launch per
+// level is pure latency: ~10 us per level against ~3 us of work.  One launch covers them all:
+// a workgroup per front, every workgroup resident (host guarantees count <= kTopMaxFronts), forward
+// sweep then backward sweep inside the same kernel.  Fronts hand over through agent-scope flags
+// (cdna_hip_programming.md Guideline 16, form R1 without fences): the payload (uvec / xp entries)
+// is stored write-through (sc1 = relaxed agent-scope atomic stores), every storing wave drains
+// vmcnt, the workgroup barriers, ONE lane stores the flag; the consumer polls the flag with
+// relaxed agent-scope loads and reads the payload with agent-scope (L1-bypassing) loads only.
+// Flags carry an epoch (a kernel argument, incremented per call), so nothing is re-zeroed.
+// Every spin is bounded by wall clock; on expiry the abort word is set and everyone leaves.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) int gint;
+#define LD_AGENT_F64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ST_AGENT_F64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long long t0, long long limit)
+{
+    for (;;) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (wall_clock64() - t0 > limit) {
+            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int sh_ok;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = BS / 64;
+    const TreeDev& T = A.T;
+    const int me = blockIdx.x;
+    const FrontDesc fd = T.desc[begin + me];
+    const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ W = A.tinv + fd.w_off;
+    const int fpad = (f + 3) & ~3;
+    double* y = smem;
+    double* part = smem + fpad;
+    int* flag_f = flags;                 // forward done
+    int* flag_b = flags + ntop;          // backward done
+    int* abort_word = flags + 2 * ntop;
+    const long long t0 = wall_clock64();
+    const long long limit = 5000000;     // 50 ms at 100 MHz: far beyond any real sweep
+
+    // ================= forward =================
+    if (tid == 0) sh_ok = 1;
+    __syncthreads();
+    if (wv == 0) {
+        // children inside the persistent set: poll their forward flags, lanes over children
+        bool ok = true;
+        for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
+            const int pos = T.spos[T.child_idx[e]] - begin;
+            if (pos >= 0) ok = wait_flag(flag_f + pos, epoch, abort_word, t0, limit) && ok;
+        }
+        if (!ok) sh_ok = 0;
+    }
+    __syncthreads();
+    if (!sh_ok) return;
+    for (int i = tid; i < f; i += BS) {
+        double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
+        const int64_t lc = (int64_t)c0 + rp + i;
+        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
+        for (int64_t g = g0; g < g1; g += 4) {
+            int src[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+            double u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? LD_AGENT_F64(A.uvec + src[q]) : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v += u[q];
+        }
+        y[i] = v;
+    }
+    __syncthreads();
+    {
+        const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6;
+        for (int it = wv; it < nrb * nks; it += NW) {
+            const int ks = it / nrb, rb = it - ks * nrb;
+            const int r = rb * 64 + lane, k0 = 8 * ks;
+            if (rb * 64 + 63 < k0) {
+                if (r < f) part[ks * fpad + r] = 0.0;
+                continue;
+            }
+            double m[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = (r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fma(m[q], (k0 + q < nc) ? y[k0 + q] : 0.0, acc);
+            if (r < f) part[ks * fpad + r] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < f; i += BS) {
+            double v = 0.0;
+            for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
+            if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
+            else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag_f + me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ================= backward =================
+    if (wv == 0) {
+        bool ok = true;
+        const int par = T.sn_parent[s];
+        if (lane == 0 && par >= 0) {
+            const int pos = T.spos[par] - begin;       // the parent of a top front is a top front
+            ok = wait_flag(flag_b + pos, epoch, abort_word, t0, limit);
+        }
+        if (!ok) sh_ok = 0;
+    }
+    __syncthreads();
+    if (!sh_ok) return;
+    double* z = smem;
+    for (int i = tid; i < f; i += BS)
+        z[i] = (i < nc) ? LD_AGENT_F64(A.xp + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
+    __syncthreads();
+    {
+        const int ncg = (nc + 7) >> 3;
+        for (int cg = wv; cg < ncg; cg += NW) {
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+            const int rstart = (8 * cg) & ~63;
+            for (int r = rstart + lane; r < f; r += 64) {
+                const double zr = z[r];
+                double m[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = (8 * cg + q < nc) ? W[r + (int64_t)(8 * cg + q) * f] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fma(m[q], zr, acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double sum = wave_reduce_sum(acc[q]);
+                const int j = 8 * cg + q;
+                if (lane == 0 && j < nc) {
+                    ST_AGENT_F64(A.xp + c0 + j, sum);
+                    A.out[T.perm[c0 + j]] = sum;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag_b + me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ W = [L11^{-1} ; L21 L11^{-1}]
 // Runs once after the factorisation, all supernodes in parallel (off the critical path of the tree).
 // L11 (unit lower, nc x nc) is staged in LDS and inverted in place, blocked bottom-up:
@@ -377,6 +537,10 @@ static void init_solve_lds()
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_winv), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
+    // this kernel also has a static LDS word: leave room for it
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    (void)hipGetLastError();
 }
 
 size_t solve_lds_bytes(int fmax, int ncmax)
@@ -405,6 +569,12 @@ void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
         init_solve_lds();
         hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count), dim3(kSolveBS), lds, st, a, begin);
     }
+}
+void launch_top_solve(const SolveArgs& a, int begin, int count, size_t lds, int* flags, int epoch, hipStream_t st)
+{
+    if (count <= 0) return;
+    init_solve_lds();
+    hipLaunchKernelGGL(k_top_solve<512>, dim3(count), dim3(512), lds, st, a, begin, flags, epoch, count);
 }
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st)
