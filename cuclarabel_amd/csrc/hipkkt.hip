@@ -443,7 +443,7 @@ private:
             for (int s = 0; s < S.nsuper; ++s) {
                 int64_t nc = S.sn_start[s + 1] - S.sn_start[s];
                 int64_t fs = nc + (S.rowptr[s + 1] - S.rowptr[s]);
-                toff[s + 1] = toff[s] + (in_list[s] ? fs * nc : 0);
+                toff[s + 1] = toff[s] + (in_list[s] ? 2 * fs * nc : 0);
             }
             d_tinv_off.upload(toff);
             static_assert(sizeof(FrontDesc) == 64, "FrontDesc layout");
@@ -471,6 +471,19 @@ private:
                 top_count += L.count;
                 top_lds = std::max(top_lds, L.lds_solve);
                 ++top_launches;
+            }
+            {
+                // every workgroup of the persistent kernel must be resident: shrink the set to what the
+                // device admits for this LDS size (dropping whole levels from the bottom of the set)
+                int cap = std::min(kTopMaxFronts, top_solve_capacity(top_lds));
+                size_t first = launches.size() - top_launches;
+                while (top_launches > 0 && top_count > cap) {
+                    top_count -= launches[first].count;
+                    ++first;
+                    --top_launches;
+                }
+                top_lds = 0;
+                for (size_t q = first; q < launches.size(); ++q) top_lds = std::max(top_lds, launches[q].lds_solve);
             }
             if (top_launches < 3) { top_launches = 0; top_count = 0; }     // not worth a special kernel
             top_flags.alloc((size_t)2 * std::max(top_count, 1) + 4);

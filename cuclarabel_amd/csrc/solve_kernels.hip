@@ -181,6 +181,28 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
     }
 }
 
+// backward items: 64 columns (lanes) x 8 rows of W' (= Wt, nc x f col-major), partial sums per row slice
+__device__ inline void bwd_items(const double* __restrict__ Wt, int nc, int f, const double* z, double* part, int ncpad,
+                                 int wv, int NW, int lane)
+{
+    const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3;
+    for (int it = wv; it < ncb * nrs; it += NW) {
+        const int rs = it / ncb, cb = it - rs * ncb;
+        const int j = cb * 64 + lane, r0 = 8 * rs;
+        if (r0 + 7 < cb * 64) {                        // rows above the column block's diagonal: zeros
+            if (j < nc) part[rs * ncpad + j] = 0.0;
+            continue;
+        }
+        double m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = (j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fma(m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+        if (j < nc) part[rs * ncpad + j] = acc;
+    }
+}
+
 template <int BS>
 __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
 {
@@ -193,38 +215,37 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
-    const double* __restrict__ W = A.tinv + fd.w_off;
+    const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;       // W'(j, r) at j + r*nc
+    const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
     double* z = smem;
+    double* part = smem + fpad;
 
     // z = [D^{-1} y_s ; -x_below]
     for (int i = tid; i < f; i += BS)
         z[i] = (i < nc) ? A.xp[c0 + i] * A.Dinv[c0 + i] : -A.xp[T.rows[rp + i - nc]];
     __syncthreads();
-    // x_j = sum_{r >= j} W(r,j) z_r : a wave takes 8 columns, lanes over rows, then 8 wave reductions
-    const int ncg = (nc + 7) >> 3;
-    for (int cg = wv; cg < ncg; cg += NW) {
-        double acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-        const int rstart = (8 * cg) & ~63;            // rows above the column group's diagonal are zero
-        for (int r = rstart + lane; r < f; r += 64) {
-            const double zr = z[r];
-            double m[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = (8 * cg + q < nc) ? W[r + (int64_t)(8 * cg + q) * f] : 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = fma(m[q], zr, acc[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double sum = wave_reduce_sum(acc[q]);
-            const int j = 8 * cg + q;
-            if (lane == 0 && j < nc) {
-                A.xp[c0 + j] = sum;
-                A.out[T.perm[c0 + j]] = sum;
-            }
-        }
+    bwd_items(Wt, nc, f, z, part, ncpad, wv, NW, lane);
+    __syncthreads();
+    const int nrs = (f + 7) >> 3;
+    for (int j = tid; j < nc; j += BS) {
+        double v = 0.0;
+        for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
+        A.xp[c0 + j] = v;
+        A.out[T.perm[c0 + j]] = v;
     }
+}
+
+struct ItemRegs { double m[8]; };
+// part[ks*ldp + r] = sum_q R.m[q] * v[8 ks + q]  for the item (row block rb, column slice ks)
+__device__ inline void item_apply(const ItemRegs& R, const double* v, int Rn, int Kn, double* part, int ldp, int it,
+                                  int nrb, int lane)
+{
+    const int ks = it / nrb, rb = it - ks * nrb;
+    const int r = rb * 64 + lane, k0 = 8 * ks;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = fma(R.m[q], (k0 + q < Kn) ? v[k0 + q] : 0.0, acc);
+    if (r < Rn) part[ks * ldp + r] = acc;
 }
 
 // ------------------------------------------------------------------ top of the tree, persistent
@@ -256,8 +277,14 @@ __device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long lon
     }
 }
 
+// Everything that does not depend on other fronts is fetched BEFORE the flag wait and parked in
+// registers: the wave's matrix items (up to PF per sweep), the row's gather-list indices, b, D^{-1},
+// the ancestors' row indices.  After the flag only the handed-over values themselves are loaded.
+constexpr int kTopPF = 4;        // forward items per wave kept in registers (8 doubles each)
+constexpr int kTopPB = 5;        // backward items per wave
+
 template <int BS>
-__global__ __launch_bounds__(BS) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop)
+__global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int sh_ok;
@@ -271,7 +298,8 @@ __global__ __launch_bounds__(BS) void k_top_solve(SolveArgs A, int begin, int* f
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ W = A.tinv + fd.w_off;
-    const int fpad = (f + 3) & ~3;
+    const double* __restrict__ Wt = W + (int64_t)f * nc;
+    const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
     double* y = smem;
     double* part = smem + fpad;
     int* flag_f = flags;                 // forward done
@@ -280,7 +308,29 @@ __global__ __launch_bounds__(BS) void k_top_solve(SolveArgs A, int begin, int* f
     const long long t0 = wall_clock64();
     const long long limit = 5000000;     // 50 ms at 100 MHz: far beyond any real sweep
 
-    // ================= forward =================
+    // ================= forward: preload =================
+    const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6, nitF = nrb * nks;
+    ItemRegs rf[kTopPF];
+#pragma unroll
+    for (int p = 0; p < kTopPF; ++p) {
+        const int it = wv + p * NW;
+        const int ks = it / nrb, rb = it - ks * nrb;
+        const int r = rb * 64 + lane, k0 = 8 * ks;
+        const bool live = it < nitF && !(rb * 64 + 63 < k0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+    }
+    int gsrc[4] = {-1, -1, -1, -1};
+    int64_t g0 = 0, g1 = 0;
+    double bmine = 0.0;
+    if (tid < f) {
+        const int64_t lc = (int64_t)c0 + rp + tid;
+        g0 = T.gl_ptr[lc];
+        g1 = T.gl_ptr[lc + 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
+        if (tid < nc) bmine = A.b[T.perm[c0 + tid]];
+    }
     if (tid == 0) sh_ok = 1;
     __syncthreads();
     if (wv == 0) {
@@ -294,53 +344,65 @@ __global__ __launch_bounds__(BS) void k_top_solve(SolveArgs A, int begin, int* f
     }
     __syncthreads();
     if (!sh_ok) return;
-    for (int i = tid; i < f; i += BS) {
+    // ---- gather (only the handed-over values are loaded now)
+    if (tid < f) {
+        double u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
+        double v = bmine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v += u[q];
+        for (int64_t g = g0 + 4; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+        y[tid] = v;
+    }
+    for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
         double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
         const int64_t lc = (int64_t)c0 + rp + i;
-        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; g += 4) {
-            int src[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
-            double u[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? LD_AGENT_F64(A.uvec + src[q]) : 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v += u[q];
-        }
+        for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
         y[i] = v;
     }
     __syncthreads();
-    {
-        const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6;
-        for (int it = wv; it < nrb * nks; it += NW) {
-            const int ks = it / nrb, rb = it - ks * nrb;
-            const int r = rb * 64 + lane, k0 = 8 * ks;
-            if (rb * 64 + 63 < k0) {
-                if (r < f) part[ks * fpad + r] = 0.0;
-                continue;
-            }
-            double m[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = (r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
-            double acc = 0.0;
+    for (int p = 0; p < kTopPF; ++p) {
+        const int it = wv + p * NW;
+        if (it < nitF) item_apply(rf[p], y, f, nc, part, fpad, it, nrb, lane);
+    }
+    for (int it = wv + kTopPF * NW; it < nitF; it += NW) {
+        const int ks = it / nrb, rb = it - ks * nrb;
+        const int r = rb * 64 + lane, k0 = 8 * ks;
+        ItemRegs rr;
+        const bool live = !(rb * 64 + 63 < k0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = fma(m[q], (k0 + q < nc) ? y[k0 + q] : 0.0, acc);
-            if (r < f) part[ks * fpad + r] = acc;
-        }
-        __syncthreads();
-        for (int i = tid; i < f; i += BS) {
-            double v = 0.0;
-            for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
-            if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
-            else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
-        }
+        for (int q = 0; q < 8; ++q) rr.m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+        item_apply(rr, y, f, nc, part, fpad, it, nrb, lane);
+    }
+    __syncthreads();
+    for (int i = tid; i < f; i += BS) {
+        double v = 0.0;
+        for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
+        if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
+        else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flag_f + me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // ================= backward =================
+    // ================= backward: preload =================
+    const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3, nitB = ncb * nrs;
+    ItemRegs rbk[kTopPB];
+#pragma unroll
+    for (int p = 0; p < kTopPB; ++p) {
+        const int it = wv + p * NW;
+        const int rs = it / ncb, cb = it - rs * ncb;
+        const int j = cb * 64 + lane, r0 = 8 * rs;
+        const bool live = it < nitB && !(r0 + 7 < cb * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rbk[p].m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+    }
+    int ridx = -1;
+    double dinv = 0.0;
+    if (tid < nc) dinv = A.Dinv[c0 + tid];
+    else if (tid < f) ridx = T.rows[rp + tid - nc];
     if (wv == 0) {
         bool ok = true;
         const int par = T.sn_parent[s];
@@ -353,34 +415,41 @@ __global__ __launch_bounds__(BS) void k_top_solve(SolveArgs A, int begin, int* f
     __syncthreads();
     if (!sh_ok) return;
     double* z = smem;
-    for (int i = tid; i < f; i += BS)
+    if (tid < nc) z[tid] = LD_AGENT_F64(A.xp + c0 + tid) * dinv;
+    else if (tid < f) z[tid] = -LD_AGENT_F64(A.xp + ridx);
+    for (int i = tid + BS; i < f; i += BS)
         z[i] = (i < nc) ? LD_AGENT_F64(A.xp + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
     __syncthreads();
-    {
-        const int ncg = (nc + 7) >> 3;
-        for (int cg = wv; cg < ncg; cg += NW) {
-            double acc[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-            const int rstart = (8 * cg) & ~63;
-            for (int r = rstart + lane; r < f; r += 64) {
-                const double zr = z[r];
-                double m[8];
+    for (int p = 0; p < kTopPB; ++p) {
+        const int it = wv + p * NW;
+        if (it < nitB) {
+            const int rs = it / ncb, cb = it - rs * ncb;
+            const int j = cb * 64 + lane, r0 = 8 * rs;
+            double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) m[q] = (8 * cg + q < nc) ? W[r + (int64_t)(8 * cg + q) * f] : 0.0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = fma(m[q], zr, acc[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double sum = wave_reduce_sum(acc[q]);
-                const int j = 8 * cg + q;
-                if (lane == 0 && j < nc) {
-                    ST_AGENT_F64(A.xp + c0 + j, sum);
-                    A.out[T.perm[c0 + j]] = sum;
-                }
-            }
+            for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+            if (j < nc) part[rs * ncpad + j] = acc;
         }
+    }
+    for (int it = wv + kTopPB * NW; it < nitB; it += NW) {
+        const int rs = it / ncb, cb = it - rs * ncb;
+        const int j = cb * 64 + lane, r0 = 8 * rs;
+        const bool live = !(r0 + 7 < cb * 64);
+        double acc = 0.0;
+        double m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fma(m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+        if (j < nc) part[rs * ncpad + j] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < nc; j += BS) {
+        double v = 0.0;
+        for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
+        ST_AGENT_F64(A.xp + c0 + j, v);
+        A.out[T.perm[c0 + j]] = v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -477,10 +546,15 @@ __global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restric
         __syncthreads();
     }
 #undef WK
-    // ---- 3. T part of W (unit diagonal, zeros above)
+    // ---- 3. T part of W (unit diagonal, zeros above), and of its transpose copy Wt (nc x f)
+    double* __restrict__ Wt = W + (int64_t)f * nc;
     for (int idx = tid; idx < nc * nc; idx += 256) {
         const int j = idx / nc, i = idx - j * nc;
         W[i + (int64_t)j * f] = (i > j) ? Ls[i * ld + j] : (i == j ? 1.0 : 0.0);
+    }
+    for (int idx = tid; idx < nc * nc; idx += 256) {
+        const int i = idx / nc, j = idx - i * nc;
+        Wt[j + (int64_t)i * nc] = (i > j) ? Ls[i * ld + j] : (i == j ? 1.0 : 0.0);
     }
     // ---- 4. M = L21 * T on the matrix cores (v_mfma_f64_16x16x4_f64): a wave owns a strip of 16 rows
     //         and all column tiles; A = L21 straight from global (16 contiguous rows per k), B = T from LDS
@@ -516,7 +590,10 @@ __global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restric
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int rr = strip * 16 + mk + 4 * q;
-                        if (rr < nb && j < nc) W[(nc + rr) + (int64_t)j * f] = acc[jt][q];
+                        if (rr < nb && j < nc) {
+                            W[(nc + rr) + (int64_t)j * f] = acc[jt][q];
+                            Wt[j + (int64_t)(nc + rr) * nc] = acc[jt][q];
+                        }
                     }
                 }
             }
@@ -545,9 +622,10 @@ static void init_solve_lds()
 
 size_t solve_lds_bytes(int fmax, int ncmax)
 {
-    const size_t fpad = (size_t)((fmax + 3) & ~3);
-    const size_t nks = (size_t)((ncmax + 7) >> 3);
-    return (fpad + nks * fpad) * sizeof(double);
+    const size_t fpad = (size_t)((fmax + 3) & ~3), ncpad = (size_t)((ncmax + 3) & ~3);
+    const size_t nks = (size_t)((ncmax + 7) >> 3), nrs = (size_t)((fmax + 7) >> 3);
+    const size_t fwd = fpad + nks * fpad, bwd = fpad + nrs * ncpad;
+    return (fwd > bwd ? fwd : bwd) * sizeof(double);
 }
 
 void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
@@ -569,6 +647,18 @@ void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
         init_solve_lds();
         hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count), dim3(kSolveBS), lds, st, a, begin);
     }
+}
+int top_solve_capacity(size_t lds)
+{
+    init_solve_lds();
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<512>, 512, lds) != hipSuccess) return 0;
+    // the occupancy API can over-report by one block per CU for SGPR-heavy kernels
+    // (MI355X_MICROARCH.md, residency): keep one block per CU of margin
+    per_cu = per_cu > 1 ? per_cu - 1 : 0;
+    return per_cu * prop.multiProcessorCount;
 }
 void launch_top_solve(const SolveArgs& a, int begin, int count, size_t lds, int* flags, int epoch, hipStream_t st)
 {
