@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
 //               rows below by one thread per row (TRSM against the d*L copy in LDS), trailing
 //               update by 4x4 register tiles whose rows are 64 apart (bank-conflict free).
 // =====================================================================================
+typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int NB = 16;
 constexpr int kBdCols = 128;       // trailing columns per block whose d*L copy is kept (nc - 16 <= 128 enforced by host)
 
@@ -363,7 +364,9 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         }
         __syncthreads();
         if (A.stamps) { long long t1 = wall_clock64(); t_i += t1 - t0; t0 = t1; }
-        // (ii) rows below the block: L(i,j) = (A(i,j) - sum_{t<j} L(i,t) * [d_t L(j,t)]) / d_j
+        // (ii) rows below the block: L(i,j) = (A(i,j) - sum_{t<j} L(i,t) * [d_t L(j,t)]) / d_j, a thread per row.
+        //      (An MFMA form X = A * (L_bb^{-T} D^{-1}) was tried: the GEMM itself is 3x faster, but forming the
+        //      16 x 16 inverse in the serial diagonal step costs more than it saves.)
         for (int i = kb + w + tid; i < f; i += BS) {
             double l[NB];
 #pragma unroll
@@ -382,50 +385,37 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         }
         __syncthreads();
         if (A.stamps) { long long t1 = wall_clock64(); t_ii += t1 - t0; t0 = t1; }
-        // (iii) trailing update of the remaining panel columns: wave tiles of (4 x 64 rows) x 4 cols.
-        //       Bd[k][c] = d_k L(g0 + c, k) is built once per block so the inner loop is 8 LDS reads
-        //       per 16 FMAs; rows past f read the slack behind the panel and are masked at the store.
+        // (iii) trailing update of the remaining panel columns on the matrix cores: 16 x 16 tiles,
+        //       C(i,j) -= sum_k L(i,k) * Bd(k,j) with Bd(k,c) = d_k L(g0 + c, k) built once per block.
         const int g0 = kb + w;
         const int Tc = nc - g0, Tr = f - g0;
         if (Tc > 0) {
-            for (int idx = tid; idx < NB * Tc; idx += BS) {
-                const int k = idx / Tc, c = idx - k * Tc;
-                Bd[k * kBdCols + c] = (k < w) ? P[(g0 + c) + (kb + k) * f] * sh_d[k] : 0.0;
+            const int Tcp = (Tc + 15) & ~15;
+            for (int idx = tid; idx < NB * Tcp; idx += BS) {
+                const int k = idx / Tcp, c = idx - k * Tcp;
+                Bd[k * kBdCols + c] = (k < w && c < Tc) ? P[(g0 + c) + (kb + k) * f] * sh_d[k] : 0.0;
             }
             __syncthreads();
-            const int ncg = (Tc + 3) >> 2, nrb = (Tr + 255) >> 8;
-            for (int wt = wv; wt < ncg * nrb; wt += NW) {
-                const int cg = wt / nrb, rb = wt - cg * nrb;
-                const int cb = 4 * cg;                          // column offset from g0
-                const int ib = g0 + 256 * rb + lane;            // rows ib + 64 a
-                if (256 * rb + 255 < cb) continue;              // wholly above the diagonal
-                double acc[4][4];
+            const int ml = lane & 15, mk = lane >> 4;
+            const int ntr = (Tr + 15) >> 4, ntc = Tcp >> 4;
+            for (int t = wv; t < ntr * ntc; t += NW) {
+                const int tc = t / ntr, tr = t - tc * ntr;
+                if (tr < tc) continue;                           // wholly above the diagonal
+                const int i0 = g0 + 16 * tr, j0 = 16 * tc;
+                double av[4], bv[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 4
-                for (int k = 0; k < NB; ++k) {
-                    const double* __restrict__ col = P + (kb + k) * f + ib;
-                    const double* __restrict__ bd = Bd + k * kBdCols + cb;
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) av[a] = col[64 * a];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) bv[b] = bd[b];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 4 * kk + mk;
+                    av[kk] = (i0 + ml < f && k < w) ? P[(i0 + ml) + (kb + k) * f] : 0.0;
+                    bv[kk] = Bd[k * kBdCols + j0 + ml];
                 }
+                d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int j = g0 + cb + b;
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int i = ib + 64 * a;
-                        if (j < nc && i < f && i >= j) P[i + j * f] -= acc[a][b];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + mk + 4 * r, col = g0 + j0 + ml;
+                    if (row < f && col < nc && row >= col) P[row + col * f] -= acc[r];
                 }
             }
         }
@@ -458,7 +448,6 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 constexpr int TS = 64;     // tile side
 constexpr int KC = 16;     // k-chunk staged in LDS
 
-typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int LDA = TS + 16;    // k-rows 80 doubles apart: consecutive k land 32 banks apart (conflict-free MFMA operand reads)
 
 // The rank-nc update runs on the matrix cores: v_mfma_f64_16x16x4_f64, each of the 4 waves owns a
