@@ -16,8 +16,11 @@
  *     K, b (tests/test_oracle_ldl.py), (2) the reference's cone-algebra unit tests
  *     (test/UnitTests/test_coneops_secondordercone.jl:31-66,
  *     test_coneops_psdtrianglecone.jl:213-251) restated in tests/test_oracle_cones.py,
- *     (3) the reference's end-to-end known answers (test/OptTests/basic_*.jl,
- *     linear_solvers.jl) through the IPM test driver in tests/ipm_driver.py.
+ *     (3) the reference's end-to-end known answers (test/OptTests/basic_qp.jl, basic_lp.jl,
+ *     basic_socp.jl, basic_eq_constrained.jl incl. the redundant-row and dual-infeasible cases,
+ *     typed in as tests/golden/reference_fixtures.py) through the IPM test driver
+ *     cuclarabel_amd/ipm.py with this oracle as its KKT backend (tests/test_ipm_fixtures.py):
+ *     all reproduced at the reference's own tolerance (atol 1e-3).
  *
  * All indices are 0-based int64 here (the reference is 1-based Int64).
  */

@@ -1,0 +1,78 @@
+"""Known-answer fixtures typed in from the reference's own tests (data and expected values
+only).  Each entry: (P, q, A, b, cones, expected) with cones as (kind, dim)."""
+import numpy as np
+import scipy.sparse as sp
+
+from cuclarabel_amd.cones import (ZeroConeT, NonnegativeConeT, SecondOrderConeT, cones_new_collapsed)
+
+
+def basic_qp():
+    # test/OptTests/basic_qp.jl:6-19 ; expected :70-73
+    P = sp.csc_matrix(np.array([[4.0, 1.0], [1.0, 2.0]]))
+    c = np.array([1.0, 1.0])
+    A0 = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]])
+    l, u = np.array([1.0, 0.0, 0.0]), np.array([1.0, 0.7, 0.7])
+    A = sp.csc_matrix(np.vstack([-A0, A0]))
+    b = np.concatenate([-l, u])
+    cones = cones_new_collapsed([NonnegativeConeT(3), NonnegativeConeT(3)])
+    return P, c, A, b, cones, dict(status="SOLVED", x=np.array([0.3, 0.7]), obj=1.8800000298331538)
+
+
+def basic_qp_dualinf():
+    # basic_qp.jl:22-32 ; expected status :103-116
+    P = sp.csc_matrix(np.array([[1.0, 1.0], [1.0, 1.0]]))
+    c = np.array([1.0, -1.0])
+    A = sp.csc_matrix(np.array([[1.0, 1.0], [1.0, 0.0]]))
+    b = np.array([1.0, 1.0])
+    return P, c, A, b, [NonnegativeConeT(2)], dict(status="DUAL_INFEASIBLE")
+
+
+def basic_lp():
+    # test/OptTests/basic_lp.jl:6-16 ; expected :32-35
+    P = sp.csc_matrix((3, 3))
+    A = sp.csc_matrix(np.vstack([np.eye(3), -np.eye(3)]) * 2.0)
+    c = np.array([3.0, -2.0, 1.0])
+    b = np.ones(6)
+    cones = cones_new_collapsed([NonnegativeConeT(3), NonnegativeConeT(3)])
+    return P, c, A, b, cones, dict(status="SOLVED", x=np.array([-0.5, 0.5, -0.5]), obj=-3.0)
+
+
+def basic_socp():
+    # test/OptTests/basic_socp.jl:6-30 ; expected :47-53
+    P = np.array([[1.4652521089139698, 0.6137176286085666, -1.1527861771130112],
+                  [0.6137176286085666, 2.219109946678485, -1.4400420548730628],
+                  [-1.1527861771130112, -1.4400420548730628, 1.6014483534926371]])
+    A1 = np.vstack([np.eye(3), -np.eye(3)]) * 2.0
+    A = sp.csc_matrix(np.vstack([A1, np.eye(3)]))
+    c = np.array([0.1, -2.0, 1.0])
+    b = np.concatenate([np.ones(6), np.zeros(3)])
+    cones = cones_new_collapsed([NonnegativeConeT(3), NonnegativeConeT(3), SecondOrderConeT(3)])
+    return sp.csc_matrix(P), c, A, b, cones, dict(status="SOLVED", x=np.array([-0.5, 0.435603, -0.245459]),
+                                                 obj=-8.4590e-01)
+
+
+def eq_constrained(which):
+    # test/OptTests/basic_eq_constrained.jl:14-63
+    P = sp.identity(3, format="csc")
+    if which == 1:
+        c = np.zeros(3); A = np.array([[0.0, 1.0, 1.0], [0.0, 1.0, -1.0]]); b = np.array([2.0, 0.0])
+        cones = [ZeroConeT(2)]; x = np.array([0.0, 1.0, 1.0])
+    elif which == 2:
+        c = np.array([1.0, 2.0, 3.0]); A = np.array([[1.0, 1.0, 1.0], [0.0, 1.0, -1.0]]); b = np.array([2.0, 0.0])
+        cones = [ZeroConeT(2)]; x = np.array([10.0, 1.0, 1.0]) / 6
+    else:   # redundant rows: K is singular without the static regularisation
+        c = np.zeros(3); A0 = np.array([[0.0, 1.0, 1.0], [0.0, 1.0, -1.0]])
+        A = np.vstack([A0, A0]); b = np.array([2.0, 0.0, 2.0, 0.0]); cones = [ZeroConeT(2), ZeroConeT(2)]
+        x = np.array([0.0, 1.0, 1.0])
+    return P, c, sp.csc_matrix(A), b, cones, dict(status="SOLVED", x=x)
+
+
+ALL = {
+    "basic_qp": basic_qp,
+    "basic_qp_dualinf": basic_qp_dualinf,
+    "basic_lp": basic_lp,
+    "basic_socp": basic_socp,
+    "eq_constrained_1": lambda: eq_constrained(1),
+    "eq_constrained_2": lambda: eq_constrained(2),
+    "eq_constrained_redundant": lambda: eq_constrained(3),
+}
