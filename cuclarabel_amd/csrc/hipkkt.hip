@@ -759,8 +759,11 @@ struct hipkkt_kkt_s {
     DBuf<int64_t> c_boff;
     DBuf<double> w, eta, soc_u, soc_v, soc_eta2, Hs;
     DBuf<int> fail;
-    int nsoc = 0;
-    bool has_psd = false, scaling_valid = false;
+    int nsoc = 0, npsd = 0, psd_kmax = 1;
+    DBuf<int> c_psdlist, c_psddim;
+    DBuf<int64_t> c_psdaoff;
+    DBuf<double> psdA;
+    bool has_psd = false, psd_too_big = false, scaling_valid = false;
     double last_eps = 0;
     int64_t last_ir = 0;
     Profiler prof;
@@ -772,12 +775,14 @@ struct hipkkt_kkt_s {
         C.ncones = (int)K.cones.size();
         C.kind = c_kind.p; C.off = c_off.p; C.numel = c_numel.p; C.boff = c_boff.p; C.sidx = c_sidx.p;
         C.soff = c_soff.p; C.elem_cone = c_elem.p; C.soc_list = c_soclist.p; C.nsoc = nsoc;
+        C.psd_list = c_psdlist.p; C.psd_dim = c_psddim.p; C.psd_aoff = c_psdaoff.p; C.npsd = npsd; C.psd_kmax = psd_kmax;
         return C;
     }
     ConeState cone_state()
     {
         ConeState S;
         S.w = w.p; S.eta = eta.p; S.u = soc_u.p; S.v = soc_v.p; S.eta2 = soc_eta2.p; S.Hs = Hs.p; S.fail = fail.p;
+        S.psdA = psdA.p;
         return S;
     }
 };
@@ -1097,10 +1102,30 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
                 soff[c] = ci.sparse ? ci.soff : -1;
                 for (int t = 0; t < ci.numel; ++t) elem[ci.off + t] = (int)c;
                 if (ci.kind == HIPKKT_CONE_SOC) soclist.push_back((int)c);
-                if (ci.kind == HIPKKT_CONE_PSD) h->has_psd = true;
+                if (ci.kind == HIPKKT_CONE_PSD) {
+                    h->has_psd = true;
+                    if (ci.dim > kPsdMaxDim) h->psd_too_big = true;
+                }
                 if (ci.sparse) for (int t = 0; t < ci.numel; ++t) soc_of[ci.soff + t] = ci.sidx;
             }
             h->nsoc = (int)soclist.size();
+            {
+                std::vector<int> plist, pdim(nc, 0);
+                std::vector<int64_t> paoff(nc, 0);
+                int64_t ao = 0;
+                for (size_t c = 0; c < nc; ++c) {
+                    const ConeInfo& ci = K.cones[c];
+                    if (ci.kind != HIPKKT_CONE_PSD) continue;
+                    plist.push_back((int)c);
+                    pdim[c] = ci.dim;
+                    paoff[c] = ao;
+                    ao += (int64_t)ci.dim * ci.dim;
+                    h->psd_kmax = std::max(h->psd_kmax, ci.dim);
+                }
+                h->npsd = (int)plist.size();
+                h->c_psdlist.upload(plist); h->c_psddim.upload(pdim); h->c_psdaoff.upload(paoff);
+                h->psdA.alloc((size_t)ao);
+            }
             h->c_kind.upload(kind); h->c_off.upload(off); h->c_numel.upload(numel); h->c_boff.upload(boff);
             h->c_sidx.upload(sidx); h->c_soff.upload(soff); h->c_elem.upload(elem); h->c_soclist.upload(soclist);
             h->soc_of_entry.upload(soc_of);
@@ -1191,8 +1216,8 @@ int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double* d_s, const doubl
 {
     return guarded([&]() {
         if (!h || (h->K.m > 0 && (!d_s || !d_z))) throw ArgError("hipkkt_kkt_update_from_sz: bad argument");
-        if (h->has_psd)
-            throw ArgError("update_from_sz: PSD cones are scaled by the caller in this version; use hipkkt_kkt_update_cones");
+        if (h->psd_too_big)
+            throw ArgError("update_from_sz: PSD cones with side > 48 are scaled by the caller; use hipkkt_kkt_update_cones");
         HIP_CHECK(hipSetDevice(h->device));
         HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
         int pu = h->prof.begin(0, h->stream);
@@ -1366,7 +1391,7 @@ int hipkkt_kkt_mul_Hs(hipkkt_kkt_t h, double* y, const double* x)
 {
     return guarded([&]() {
         if (!h || !y || !x) throw ArgError("hipkkt_kkt_mul_Hs: bad argument");
-        if (!h->scaling_valid || h->has_psd) throw ArgError("mul_Hs needs a device-side scaling (update_from_sz) without PSD cones");
+        if (!h->scaling_valid) throw ArgError("mul_Hs needs a device-side scaling (hipkkt_kkt_update_from_sz)");
         HIP_CHECK(hipSetDevice(h->device));
         size_t bytes = (size_t)h->K.m * sizeof(double);
         HIP_CHECK(hipMemcpyAsync(h->sbuf.p, x, bytes, hipMemcpyHostToDevice, h->stream));

@@ -219,7 +219,7 @@ void launch_check_finite(const double* v, int n, int* flag, hipStream_t st)
 //    nonnegative      w = sqrt(s/z), Hs = w^2         coneops_nncone.jl:77-101
 //    second-order     eta, w (NT point), sparse (d, u, v) or dense 2ww' - J
 //                                                     coneops_socone.jl:75-192
-//  PSD cones are scaled by the caller (hipkkt_kkt_update_cones) in this version.
+//    PSD (side <= 48)  A = R R' via Cholesky + Jacobi eigen, Hs = A (x)_s A   coneops_psdtrianglecone.jl:78-161
 // =====================================================================================
 __global__ void k_cone_elementwise(ConeDev C, ConeState S, const double* __restrict__ s,
                                    const double* __restrict__ z, int m)
@@ -323,11 +323,217 @@ __global__ __launch_bounds__(64) void k_cone_soc(ConeDev C, ConeState S, const d
     }
 }
 
+// -------------------------------------------------------------------------------------
+//  PSD cones (coneops_psdtrianglecone.jl:78-161): one workgroup per cone, everything in LDS.
+//    S, Z from svec;  L1 = chol(S), L2 = chol(Z)  (failure => not interior);
+//    the reference takes the SVD of L2'L1 = U Lam V' and sets R = L1 V Lam^{-1/2}; only
+//    A = R R' = L1 V Lam^{-1} V' L1' enters Hs, and V Lam^2 V' = (L2'L1)'(L2'L1) = L1' Z L1 =: G, so
+//    A = L1 G^{-1/2} L1' with G^{-1/2} from a cyclic Jacobi eigen-decomposition of G (k <= 48).
+//    Hs = A (x)_s A (skron!, :502-540) is written straight into its packed upper triangle by a
+//    flat map over the t(t+1)/2 entries, t = k(k+1)/2.
+// -------------------------------------------------------------------------------------
+__device__ inline void svec_index(int idx, int& row, int& col)     // idx = col(col+1)/2 + row, row <= col
+{
+    int c = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+    while (c * (c + 1) / 2 > idx) --c;
+    while ((c + 1) * (c + 2) / 2 <= idx) ++c;
+    col = c;
+    row = idx - c * (c + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void k_cone_psd(ConeDev C, ConeState S, const double* __restrict__ s,
+                                                  const double* __restrict__ z)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int sh_fail;
+    const int tid = threadIdx.x;
+    const int c = C.psd_list[blockIdx.x];
+    const int k = C.psd_dim[c], off = C.off[c];
+    const int kk = k * k, t = k * (k + 1) / 2;
+    double* Sm = smem;            // S -> L1 (lower)
+    double* Zm = smem + kk;       // Z
+    double* G = smem + 2 * kk;    // L1' Z L1 -> eigen work
+    double* V = smem + 3 * kk;    // eigenvectors
+    double* Tm = smem + 4 * kk;   // temporaries
+    double* Am = smem + 5 * kk;   // A = R R'
+    const double is2 = 0.70710678118654752440;
+    if (tid == 0) sh_fail = 0;
+    for (int idx = tid; idx < t; idx += 256) {
+        int r, cl;
+        svec_index(idx, r, cl);
+        const double sv = s[off + idx], zv = z[off + idx];
+        if (r == cl) { Sm[r + cl * k] = sv; Zm[r + cl * k] = zv; }
+        else {
+            Sm[r + cl * k] = Sm[cl + r * k] = sv * is2;
+            Zm[r + cl * k] = Zm[cl + r * k] = zv * is2;
+        }
+    }
+    __syncthreads();
+    // Cholesky of S (in place -> L1) and a PD check of Z (its factor is not needed afterwards), right-looking
+    for (int pass = 0; pass < 2; ++pass) {
+        double* M = pass == 0 ? Sm : Tm;
+        if (pass == 1) { for (int i = tid; i < kk; i += 256) Tm[i] = Zm[i]; __syncthreads(); }
+        for (int j = 0; j < k; ++j) {
+            const double d = M[j + j * k];
+            if (!(d > 0.0)) { if (tid == 0) sh_fail = 1; }
+            __syncthreads();
+            if (sh_fail) break;
+            const double sd = sqrt(d);
+            for (int i = j + 1 + tid; i < k; i += 256) M[i + j * k] /= sd;
+            if (tid == 0) M[j + j * k] = sd;
+            __syncthreads();
+            for (int idx = tid; idx < (k - j - 1) * (k - j - 1); idx += 256) {
+                const int a = j + 1 + idx / (k - j - 1), b = j + 1 + idx % (k - j - 1);
+                if (a >= b) M[a + b * k] -= M[a + j * k] * M[b + j * k];
+            }
+            __syncthreads();
+        }
+        if (sh_fail) break;
+    }
+    if (sh_fail) { if (tid == 0) *S.fail = 1; return; }
+    for (int idx = tid; idx < kk; idx += 256) { const int r = idx % k, cl = idx / k; if (r < cl) Sm[idx] = 0.0; }
+    __syncthreads();
+    // G = L1' Z L1
+    for (int idx = tid; idx < kk; idx += 256) {          // Tm = Z L1
+        const int r = idx % k, cl = idx / k;
+        double acc = 0.0;
+        for (int q = cl; q < k; ++q) acc = fma(Zm[r + q * k], Sm[q + cl * k], acc);
+        Tm[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kk; idx += 256) {
+        const int r = idx % k, cl = idx / k;
+        double acc = 0.0;
+        for (int q = r; q < k; ++q) acc = fma(Sm[q + r * k], Tm[q + cl * k], acc);
+        G[idx] = acc;
+        V[idx] = (r == cl) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // cyclic Jacobi on G (symmetric): round-robin would parallelise rotations; k <= 48 keeps the plain
+    // cyclic order cheap enough (each rotation is applied by the whole workgroup)
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double offn = 0.0;
+        for (int p = 0; p < k - 1; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                const double apq = G[p + q * k];
+                const double app = G[p + p * k], aqq = G[q + q * k];
+                const double scale = sqrt(fabs(app * aqq));
+                if (!(fabs(apq) > 1e-17 * scale)) continue;            // uniform: all threads read the same LDS
+                offn = fmax(offn, fabs(apq) / (scale > 0 ? scale : 1.0));
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
+                const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                __syncthreads();
+                for (int i = tid; i < k; i += 256) {                      // columns p, q of G and V
+                    const double gp = G[i + p * k], gq = G[i + q * k];
+                    G[i + p * k] = cs * gp - sn * gq;
+                    G[i + q * k] = sn * gp + cs * gq;
+                    const double vp = V[i + p * k], vq = V[i + q * k];
+                    V[i + p * k] = cs * vp - sn * vq;
+                    V[i + q * k] = sn * vp + cs * vq;
+                }
+                __syncthreads();
+                for (int i = tid; i < k; i += 256) {                      // rows p, q of G
+                    const double gp = G[p + i * k], gq = G[q + i * k];
+                    G[p + i * k] = cs * gp - sn * gq;
+                    G[q + i * k] = sn * gp + cs * gq;
+                }
+                __syncthreads();
+            }
+        if (offn < 1e-15) break;
+    }
+    // B = L1 V diag(g^{-1/4});  A = B B'
+    for (int idx = tid; idx < kk; idx += 256) {
+        const int r = idx % k, cl = idx / k;
+        double acc = 0.0;
+        for (int q = 0; q <= r; ++q) acc = fma(Sm[r + q * k], V[q + cl * k], acc);
+        const double g = G[cl + cl * k];
+        Tm[idx] = acc / sqrt(sqrt(g));
+    }
+    __syncthreads();
+    double* Aout = S.psdA + C.psd_aoff[c];
+    for (int idx = tid; idx < kk; idx += 256) {
+        const int r = idx % k, cl = idx / k;
+        double acc = 0.0;
+        for (int q = 0; q < k; ++q) acc = fma(Tm[r + q * k], Tm[cl + q * k], acc);
+        Am[idx] = acc;
+        Aout[idx] = acc;
+    }
+    __syncthreads();
+    // Hs = A (x)_s A, packed upper triangle (column-major over (row, col) with row <= col)
+    double* Hs = S.Hs + C.boff[c];
+    const double s2 = 1.41421356237309504880;
+    const int nh = t * (t + 1) / 2;
+    for (int e = tid; e < nh; e += 256) {
+        int row, col;
+        svec_index(e, row, col);
+        int i, j, kq, l;
+        svec_index(row, i, j);          // row <-> (i, j), i <= j
+        svec_index(col, kq, l);         // col <-> (k, l), k <= l
+        double v;
+        const bool ij = (i == j), kl = (kq == l);
+        if (!ij && !kl) v = Am[i + kq * k] * Am[j + l * k] + Am[i + l * k] * Am[j + kq * k];
+        else if (ij && !kl) v = s2 * Am[j + l * k] * Am[j + kq * k];
+        else if (!ij && kl) v = s2 * Am[i + l * k] * Am[j + kq * k];
+        else v = Am[j + l * k] * Am[j + l * k];
+        Hs[e] = v;
+    }
+}
+
+// y = (A (x)_s A) x = svec(A X A) for PSD cones
+__global__ __launch_bounds__(256) void k_mul_Hs_psd(ConeDev C, ConeState S, double* __restrict__ y,
+                                                    const double* __restrict__ x)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int c = C.psd_list[blockIdx.x];
+    const int k = C.psd_dim[c], off = C.off[c], kk = k * k, t = k * (k + 1) / 2;
+    double* X = smem;
+    double* Am = smem + kk;
+    double* Tm = smem + 2 * kk;
+    const double is2 = 0.70710678118654752440;
+    const double* A = S.psdA + C.psd_aoff[c];
+    for (int idx = tid; idx < kk; idx += 256) Am[idx] = A[idx];
+    for (int idx = tid; idx < t; idx += 256) {
+        int r, cl;
+        svec_index(idx, r, cl);
+        const double v = x[off + idx];
+        if (r == cl) X[r + cl * k] = v;
+        else X[r + cl * k] = X[cl + r * k] = v * is2;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kk; idx += 256) {
+        const int r = idx % k, cl = idx / k;
+        double acc = 0.0;
+        for (int q = 0; q < k; ++q) acc = fma(X[r + q * k], Am[q + cl * k], acc);
+        Tm[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < t; idx += 256) {
+        int r, cl;
+        svec_index(idx, r, cl);
+        double a1 = 0.0, a2 = 0.0;
+        for (int q = 0; q < k; ++q) { a1 = fma(Am[r + q * k], Tm[q + cl * k], a1); a2 = fma(Am[cl + q * k], Tm[q + r * k], a2); }
+        y[off + idx] = (r == cl) ? a1 : (a1 + a2) * is2;
+    }
+}
+
 void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, const double* z, int m,
                          hipStream_t st)
 {
     if (m > 0) hipLaunchKernelGGL(k_cone_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, s, z, m);
     if (C.nsoc > 0) hipLaunchKernelGGL(k_cone_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, s, z);
+    if (C.npsd > 0) {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cone_psd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      150 * 1024);
+            (void)hipGetLastError();
+        }
+        const size_t lds = (size_t)6 * C.psd_kmax * C.psd_kmax * sizeof(double);
+        hipLaunchKernelGGL(k_cone_psd, dim3(C.npsd), dim3(256), lds, st, C, S, s, z);
+    }
 }
 
 // y = W'W x : zero -> 0, NN -> w*(w*x), SOC -> eta^2 (2 w (w'x) - J x)   (mul_Hs!)
@@ -358,6 +564,10 @@ void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double
 {
     if (m > 0) hipLaunchKernelGGL(k_mul_Hs_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, y, x, m);
     if (C.nsoc > 0) hipLaunchKernelGGL(k_mul_Hs_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, y, x);
+    if (C.npsd > 0) {
+        const size_t lds = (size_t)3 * C.psd_kmax * C.psd_kmax * sizeof(double);
+        hipLaunchKernelGGL(k_mul_Hs_psd, dim3(C.npsd), dim3(256), lds, st, C, S, y, x);
+    }
 }
 
 }  // namespace hipkkt

@@ -178,6 +178,12 @@ struct ConeDev {
     // list of second-order cones
     const int* soc_list;
     int nsoc;
+    // list of PSD cones; psd_dim = matrix side k, psd_aoff = offset of the cone's k x k matrix R R' in psdA
+    const int* psd_list;
+    const int* psd_dim;          // per cone (0 for non-PSD)
+    const int64_t* psd_aoff;     // per cone
+    int npsd;
+    int psd_kmax;
 };
 struct ConeState {
     double* w;                   // m: NN: sqrt(s/z); SOC: normalised w
@@ -186,8 +192,10 @@ struct ConeState {
     double* v;                   // sparse_len
     double* eta2;                // nsparse
     double* Hs;                  // |Hs| positive blocks
+    double* psdA;                // per PSD cone: A = R R' (k x k col-major), Hs = A (x)_s A
     int* fail;                   // set to 1 when a point is not interior
 };
+constexpr int kPsdMaxDim = 48;   // largest PSD side handled by the in-LDS scaling kernel
 void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, const double* z, int m,
                          hipStream_t st);
 void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st);
