@@ -173,9 +173,23 @@ def main():
                                 algorithmic_bytes=byt, achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
         dominant = max(("factor", "trisolve"), key=lambda k: phases[k]["total_ms"])
         d = phases[dominant]
+        # HBM traffic per launch of that phase from the committed PMC passes of this same command
+        # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs: scripts/profile_bench.sh -> profiles/)
+        traffic, traffic_src = None, None
+        import glob
+        summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_summary.json")))
+        if summaries and pb.n == 100_000:
+            try:
+                ts = json.load(open(summaries[-1]))
+                key = "trisolve_hbm_MB_per_solve" if dominant == "trisolve" else "factor_hbm_MB_per_factorisation"
+                traffic = ts[key] * 1024.0 * 1024.0
+                traffic_src = os.path.basename(summaries[-1])
+            except Exception:
+                traffic = None
         roofline = dict(kernel=dominant, bound="hbm", achieved=d["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=d["frac"], traffic=None,
-                        note="phase = all kernel launches of one %s; algorithmic bytes per SURVEY.md 8(d)" % dominant)
+                        frac=d["frac"], traffic=traffic, traffic_source=traffic_src,
+                        note="phase = all kernel launches of one %s; algorithmic bytes per SURVEY.md 8(d); "
+                             "traffic = FETCH_SIZE+WRITE_SIZE bytes per launch of the phase" % dominant)
         out = {
             "metric": "KKT factorize+solve/sec (fp64) per IPM iter, 100k-var SOCP",
             "value": world * args.steps / elapsed,
