@@ -194,20 +194,34 @@ private:
         }
         int li = 0;
         bool forked = false;
-        for (const Launch& L : launches) {
+        // eager mode: once the tree narrows to its top levels most CUs idle, so the solve matrices
+        // W = [T; M] of everything below are formed on a side stream meanwhile (HIPKKT_NO_OVERLAP=1 disables)
+        static const bool no_overlap = std::getenv("HIPKKT_NO_OVERLAP") != nullptr;
+        const size_t nl = launches.size();
+        const size_t first_top = (!side && !no_overlap && !want_stamps && top_launches > 0 && top_launches < nl)
+                                     ? nl - top_launches : nl;
+        bool eager_fork = false;
+        for (size_t q = 0; q < nl; ++q) {
+            const Launch& L = launches[q];
             a.stamp_row = li++;
+            if (q == first_top && launches[q].tinv_begin > 0) {
+                ensure_capture_streams();
+                HIP_CHECK(hipEventRecord(ev_fork, st));
+                HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
+                launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, launches[q].tinv_begin, tinv_ncmax, cap_side);
+                HIP_CHECK(hipEventRecord(ev_join, cap_side));
+                eager_fork = true;
+            }
             if (L.small) {
                 launch_front_wave(a, L.begin, L.count, L.slice, st);
             } else {
                 a.nbk = L.nbk;
                 launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, st);
-                if (L.tinv_count > 0) {
-                    if (side) {
-                        HIP_CHECK(hipEventRecord(ev_fork, st));
-                        HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
-                        launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, side);
-                        forked = true;
-                    }
+                if (L.tinv_count > 0 && side) {
+                    HIP_CHECK(hipEventRecord(ev_fork, st));
+                    HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
+                    launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, side);
+                    forked = true;
                 }
                 launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, st);
             }
@@ -215,8 +229,12 @@ private:
         if (forked) {
             HIP_CHECK(hipEventRecord(ev_join, side));
             HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+        } else if (eager_fork) {
+            const int done = launches[first_top].tinv_begin;
+            launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, st);
+            HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
         } else {
-            // eager: one launch over every supernode, after the tree (all of them independent)
+            // one launch over every supernode, after the tree (all of them independent)
             launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st);
         }
         HIP_CHECK(hipGetLastError());
