@@ -173,6 +173,10 @@ def main():
                                 algorithmic_bytes=byt, achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
         dominant = max(("factor", "trisolve"), key=lambda k: phases[k]["total_ms"])
         d = phases[dominant]
+        # flop-side view of the factorisation (dense Schur / panel work on v_mfma_f64_16x16x4_f64)
+        phases["factor"]["flops"] = info["factor_flops"]
+        phases["factor"]["achieved_TFLOPs"] = info["factor_flops"] / (phases["factor"]["avg_ms"] * 1e-3) / 1e12
+        phases["factor"]["frac_fp64_mfma_peak_78.6TF"] = phases["factor"]["achieved_TFLOPs"] / 78.6
         # HBM traffic per launch of that phase from the committed PMC passes of this same command
         # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs: scripts/profile_bench.sh -> profiles/)
         traffic, traffic_src = None, None

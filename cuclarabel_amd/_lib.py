@@ -72,6 +72,8 @@ SYMBOLS = {
     "hipkkt_ldl_refactor": (C.c_int, [_P]),
     "hipkkt_ldl_solve": (C.c_int, [_P, _P, _P]),
     "hipkkt_ldl_solve_dev": (C.c_int, [_P, _P, _P]),
+    "hipkkt_ldl_solve_multi": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "hipkkt_ldl_solve_multi_dev": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64]),
     "hipkkt_ldl_info": (C.c_int, [_P, _P]),
     "hipkkt_ldl_get_perm": (C.c_int, [_P, _P]),
     "hipkkt_kkt_create": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, C.c_int]),
@@ -86,6 +88,8 @@ SYMBOLS = {
     "hipkkt_kkt_solve": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_setrhs_dev": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_solve_dev": (C.c_int, [_P, _P, _P]),
+    "hipkkt_kkt_solve_multi": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "hipkkt_kkt_solve_multi_dev": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "hipkkt_kkt_mul_Hs": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_get_pattern": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_get_values": (C.c_int, [_P, _P]),

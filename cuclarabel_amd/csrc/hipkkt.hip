@@ -63,6 +63,7 @@ struct Launch {
     bool small;                 // one wave per front
     int bs_panel, nbk, slice;   // panel kernel block size / block-column width; small-front LDS slice
     size_t lds_panel, lds_solve;
+    int fmax, ncmax;            // largest front / column count in the launch
     int tile_begin, ntiles;     // Schur tiles of this launch's fronts
     int tinv_begin, tinv_count, tinv_ncmax;   // this launch's supernodes that need T = L11^{-1}
 };
@@ -144,6 +145,42 @@ public:
             it = solve_graphs.emplace(key, ex).first;
         }
         HIP_CHECK(hipGraphLaunch(it->second, stream));
+    }
+
+    // nrhs right-hand sides at once: column j of d_B at stride ldb, of d_X at stride ldx (may alias d_B).
+    // Every level is one launch (grid.y = block of 16 columns, 8 for the one-wave fronts): the per-level latency
+    // that bounds a single solve is paid once for all columns, and every entry of the solve matrices a workgroup
+    // fetches is used for all of its columns (solve_kernels.hip, "several right-hand sides").
+    void solve_multi(const double* d_B, int64_t ldb, double* d_X, int64_t ldx, int nrhs)
+    {
+        if (nrhs <= 0) return;
+        if (nrhs == 1) { solve(d_B, d_X); return; }
+        const int KP = (nrhs + 15) & ~15;
+        if (KP / 8 > 65535) throw ArgError("solve_multi: too many right-hand sides per call");
+        if ((size_t)KP > multi_cap) {
+            xp_m.alloc((size_t)S.N * KP);
+            uvec_m.alloc(std::max<size_t>(S.rows.size(), 1) * KP);
+            multi_cap = (size_t)KP;
+        }
+        SolveArgs a;
+        a.T = tree();
+        a.fronts = fronts.p;
+        a.tinv = tinv.p;
+        a.Dinv = Dinv.p;
+        a.b = nullptr;
+        a.out = nullptr;
+        a.xp = xp_m.p;
+        a.uvec = uvec_m.p;
+        a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
+        if (!d_iperm.p) d_iperm.upload(S.iperm);
+        launch_permute_in(d_B, ldb, xp_m.p, KP, d_iperm.p, S.N, nrhs, stream);
+        for (const Launch& L : launches) launch_fwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
+        for (size_t q = launches.size(); q-- > 0;) {
+            const Launch& L = launches[q];
+            launch_bwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
+        }
+        launch_permute_out(d_X, ldx, xp_m.p, KP, d_iperm.p, S.N, nrhs, stream);
+        HIP_CHECK(hipGetLastError());
     }
 
     ~LDLEngine()
@@ -268,6 +305,7 @@ private:
         a.out = d_x;
         a.xp = xp.p;
         a.uvec = uvec.p;
+        a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         const size_t nl = launches.size();
         const size_t ntl = no_top ? 0 : top_launches;            // the last ntl launches form the persistent top
@@ -311,6 +349,9 @@ private:
     DBuf<int64_t> d_rowptr, d_front_off, d_upd_off, d_kptr;
     DBuf<signed char> d_psign;
     DBuf<double> fronts, upd, Dinv, xp, uvec, tinv;
+    DBuf<double> xp_m, uvec_m;   // work vectors of solve_multi, row-major N x cap and sum(nb) x cap
+    DBuf<int> d_iperm;
+    size_t multi_cap = 0;
     DBuf<int64_t> d_tinv_off;
     DBuf<int> d_tinv_list;
     std::vector<int> tinv_list;
@@ -330,7 +371,7 @@ private:
     size_t top_launches = 0, top_lds = 0;
     int top_count = 0, top_epoch = 0;
     std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
-    DBuf<int> d_gl_src;
+    DBuf<int> d_gl_src, d_udst;
     std::vector<Launch> launches;
     std::vector<int> sched;
     std::vector<int64_t> tiles;
@@ -342,7 +383,7 @@ private:
         t.ncolpar = d_ncolpar.p; t.front_off = d_front_off.p; t.upd_off = d_upd_off.p;
         t.child_ptr = d_child_ptr.p; t.child_idx = d_child_idx.p; t.kptr = d_kptr.p;
         t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
-        t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p;
+        t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p; t.udst = d_udst.p;
         t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
         t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p; t.desc = (const FrontDesc*)d_desc.p;
         t.spos = d_spos.p; t.sn_parent = d_sn_parent.p;
@@ -400,6 +441,8 @@ private:
                 int ncmax = 0;
                 for (int s : v) ncmax = std::max(ncmax, ncols(s));
                 L.lds_solve = L.small ? 0 : solve_lds_bytes(fmax, ncmax);
+                L.fmax = fmax;
+                L.ncmax = ncmax;
                 L.tinv_begin = (int)tinv_list.size();
                 L.tinv_ncmax = 1;
                 if (!L.small) for (int s : v) {
@@ -644,6 +687,10 @@ private:
             d_sitems.upload(raw2);
             d_tile_cut.upload(tcut);
             d_gl_src.upload(gsrc);
+            // where each contribution entry sits in its receiver's gather list (solve_multi's layout)
+            std::vector<int> ud(std::max<size_t>(S.rows.size(), 1), 0);
+            for (size_t g = 0; g < gsrc.size(); ++g) ud[(size_t)gsrc[g]] = (int)g;
+            d_udst.upload(ud);
         }
         d_perm.upload(S.perm);
         std::vector<signed char> ps(S.N);
@@ -749,6 +796,8 @@ struct hipkkt_ldl_s {
     int base = 0;
     std::unique_ptr<LDLEngine> eng;
     DBuf<double> Kval, vals, b, x;
+    DBuf<double> mB;             // host-pointer solve_multi staging, N x mcap
+    size_t mcap = 0;
     DBuf<int> idx;
     ~hipkkt_ldl_s() { if (stream) (void)hipStreamDestroy(stream); }
 };
@@ -784,6 +833,10 @@ struct hipkkt_kkt_s {
     bool has_psd = false, psd_too_big = false, scaling_valid = false;
     double last_eps = 0;
     int64_t last_ir = 0;
+    // solve_multi work space, N x mcap each (grown on demand)
+    DBuf<double> mB, mX, mC, mE, mE2, mpartial, mnorms;
+    DBuf<int> mmask;
+    size_t mcap = 0;
     Profiler prof;
     ~hipkkt_kkt_s() { if (stream && own_stream) (void)hipStreamDestroy(stream); }
 
@@ -989,6 +1042,33 @@ int hipkkt_ldl_solve(hipkkt_ldl_t h, double* x, const double* b)
         HIP_CHECK(hipMemcpyAsync(h->b.p, b, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
         h->eng->solve(h->b.p, h->x.p);
         HIP_CHECK(hipMemcpyAsync(x, h->x.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_solve_multi_dev(hipkkt_ldl_t h, int64_t nrhs, double* d_X, int64_t ldx, const double* d_B, int64_t ldb)
+{
+    return guarded([&]() {
+        if (!h || nrhs < 0 || (nrhs > 0 && (!d_X || !d_B || ldx < h->N || ldb < h->N)))
+            throw ArgError("hipkkt_ldl_solve_multi_dev: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        h->eng->solve_multi(d_B, ldb, d_X, ldx, (int)nrhs);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_solve_multi(hipkkt_ldl_t h, int64_t nrhs, double* X, const double* B)
+{
+    return guarded([&]() {
+        if (!h || nrhs < 0 || (nrhs > 0 && (!X || !B))) throw ArgError("hipkkt_ldl_solve_multi: bad argument");
+        if (nrhs == 0) return HIPKKT_OK;
+        HIP_CHECK(hipSetDevice(h->device));
+        if ((size_t)nrhs > h->mcap) { h->mB.alloc((size_t)h->N * nrhs); h->mcap = (size_t)nrhs; }
+        const size_t bytes = (size_t)h->N * nrhs * sizeof(double);
+        HIP_CHECK(hipMemcpyAsync(h->mB.p, B, bytes, hipMemcpyHostToDevice, h->stream));
+        h->eng->solve_multi(h->mB.p, h->N, h->mB.p, h->N, (int)nrhs);     // in place: every entry is read before its slot is written
+        HIP_CHECK(hipMemcpyAsync(X, h->mB.p, bytes, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return HIPKKT_OK;
     });
@@ -1400,6 +1480,148 @@ int hipkkt_kkt_solve(hipkkt_kkt_t h, double* lhsx, double* lhsz)
             HIP_CHECK(hipMemcpyAsync(lhsx, h->cur_x, (size_t)h->K.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (lhsz && h->K.m)
             HIP_CHECK(hipMemcpyAsync(lhsz, h->cur_x + h->K.n, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+// ---- several right-hand sides against one factorisation (SURVEY.md 8b "solve_multi", 8e(ii)).
+// Per column exactly the sequence of kkt_solve_core: the refinement rounds run in lockstep over the
+// columns that still need them; a column that has met its stopping rule is frozen (its candidate is
+// not accepted any more), so every column ends where its own single solve would.
+static void kkt_multi_reserve(hipkkt_kkt_t h, size_t k)
+{
+    if (k <= h->mcap) return;
+    const size_t N = (size_t)h->K.N;
+    h->mB.alloc(N * k); h->mX.alloc(N * k); h->mC.alloc(N * k); h->mE.alloc(N * k); h->mE2.alloc(N * k);
+    h->mpartial.alloc((size_t)kNormParts * k);
+    h->mnorms.alloc(2 * k);
+    h->mmask.alloc(k);
+    h->mcap = k;
+}
+
+static int kkt_solve_multi_core(hipkkt_kkt_t h, int k, int64_t* ir_out)
+{
+    const hipkkt_settings& st = h->st;
+    const int N = (int)h->K.N;
+    const int64_t ld = N;
+    std::vector<int64_t> ir((size_t)k, 0);
+    auto trisolve = [&](const double* rhs, double* out) {
+        int ps = h->prof.begin(2, h->stream);
+        h->eng->solve_multi(rhs, ld, out, ld, k);
+        h->prof.end(ps, h->stream);
+    };
+    trisolve(h->mB.p, h->mX.p);
+    if (!st.iterative_refinement_enable) {
+        int bad = 0;
+        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        for (int j = 0; j < k; ++j) launch_check_finite(h->mX.p + (size_t)j * N, N, h->fail.p, h->stream);
+        HIP_CHECK(hipMemcpyAsync(&bad, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (ir_out) std::copy(ir.begin(), ir.end(), ir_out);
+        return bad ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
+    }
+    SpmvDev A;
+    A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.N = N; A.lanes_per_row = h->lanes_per_row;
+    std::vector<double> hn(2 * (size_t)k), norme((size_t)k), normb((size_t)k);
+    std::vector<int> active((size_t)k, 1), mask((size_t)k, 0);
+    {
+        int pr = h->prof.begin(3, h->stream);
+        launch_residual(A, h->Kval.p, h->mB.p, h->mX.p, h->mE.p, h->mpartial.p, h->mnorms.p, h->stream, k, ld);
+        launch_norm_inf(h->mB.p, N, h->mpartial.p, h->mnorms.p + k, h->stream, k, ld);
+        h->prof.end(pr, h->stream);
+        HIP_CHECK(hipMemcpyAsync(hn.data(), h->mnorms.p, 2 * (size_t)k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    for (int j = 0; j < k; ++j) {
+        norme[j] = hn[j];
+        normb[j] = hn[k + j];
+        if (!std::isfinite(norme[j])) return HIPKKT_NUMERIC_FAILURE;
+    }
+    for (int i = 0; i < st.iterative_refinement_max_iter; ++i) {
+        bool any = false;
+        for (int j = 0; j < k; ++j) {
+            if (active[j] && norme[j] <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb[j]) active[j] = 0;
+            any = any || active[j];
+        }
+        if (!any) break;
+        trisolve(h->mE.p, h->mC.p);                                            // dx_j = K^{-1} e_j
+        launch_axpby_sum(h->mC.p, h->mC.p, h->mX.p, (int64_t)N * k, h->stream); // prospective x_j + dx_j
+        int pr = h->prof.begin(3, h->stream);
+        launch_residual(A, h->Kval.p, h->mB.p, h->mC.p, h->mE2.p, h->mpartial.p, h->mnorms.p, h->stream, k, ld);
+        h->prof.end(pr, h->stream);
+        HIP_CHECK(hipMemcpyAsync(hn.data(), h->mnorms.p, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        for (int j = 0; j < k; ++j) {
+            mask[j] = 0;
+            if (!active[j]) continue;
+            ir[j]++;
+            h->prof.acc.ir_iterations++;
+            if (!std::isfinite(hn[j])) return HIPKKT_NUMERIC_FAILURE;
+            const double ratio = norme[j] / hn[j];
+            if (ratio < st.iterative_refinement_stop_ratio) {
+                if (ratio > 1.0) mask[j] = 1;
+                active[j] = 0;
+            } else {
+                mask[j] = 1;
+            }
+            if (mask[j]) norme[j] = hn[j];
+        }
+        HIP_CHECK(hipMemcpyAsync(h->mmask.p, mask.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        launch_accept_columns(h->mX.p, h->mC.p, h->mE.p, h->mE2.p, h->mmask.p, N, k, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));      // `mask` (pageable) must outlive the copy
+    }
+    h->last_ir = 0;
+    for (int j = 0; j < k; ++j) h->last_ir += ir[j];
+    if (ir_out) std::copy(ir.begin(), ir.end(), ir_out);
+    return HIPKKT_OK;
+}
+
+static void kkt_multi_unpack(hipkkt_kkt_t h, int k, double* lhsx, double* lhsz, hipMemcpyKind kind)
+{
+    const size_t n = (size_t)h->K.n, m = (size_t)h->K.m, N = (size_t)h->K.N;
+    if (lhsx && n)
+        HIP_CHECK(hipMemcpy2DAsync(lhsx, n * sizeof(double), h->mX.p, N * sizeof(double), n * sizeof(double), (size_t)k, kind, h->stream));
+    if (lhsz && m)
+        HIP_CHECK(hipMemcpy2DAsync(lhsz, m * sizeof(double), h->mX.p + n, N * sizeof(double), m * sizeof(double), (size_t)k, kind, h->stream));
+}
+
+int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double* d_rhsx, const double* d_rhsz, double* d_lhsx,
+                               double* d_lhsz, int64_t* ir_iterations)
+{
+    return guarded([&]() {
+        if (!h || nrhs < 0 || nrhs > 65535 || (nrhs > 0 && ((h->K.n && !d_rhsx) || (h->K.m && !d_rhsz))))
+            throw ArgError("hipkkt_kkt_solve_multi_dev: bad argument");
+        if (nrhs == 0) return HIPKKT_OK;
+        HIP_CHECK(hipSetDevice(h->device));
+        kkt_multi_reserve(h, (size_t)nrhs);
+        launch_pack_rhs(h->mB.p, d_rhsx, d_rhsz, h->K.n, h->K.m, h->K.p, h->stream, (int)nrhs);
+        int rc = kkt_solve_multi_core(h, (int)nrhs, ir_iterations);
+        if (rc != HIPKKT_OK) return rc;
+        kkt_multi_unpack(h, (int)nrhs, d_lhsx, d_lhsz, hipMemcpyDeviceToDevice);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_solve_multi(hipkkt_kkt_t h, int64_t nrhs, const double* rhsx, const double* rhsz, double* lhsx,
+                           double* lhsz, int64_t* ir_iterations)
+{
+    return guarded([&]() {
+        if (!h || nrhs < 0 || nrhs > 65535 || (nrhs > 0 && ((h->K.n && !rhsx) || (h->K.m && !rhsz))))
+            throw ArgError("hipkkt_kkt_solve_multi: bad argument");
+        if (nrhs == 0) return HIPKKT_OK;
+        HIP_CHECK(hipSetDevice(h->device));
+        kkt_multi_reserve(h, (size_t)nrhs);
+        const size_t n = (size_t)h->K.n, m = (size_t)h->K.m, k = (size_t)nrhs;
+        // stage [rhsx | rhsz] in the candidate buffer (N k >= (n + m) k doubles, not needed before the first round)
+        double* sx = h->mC.p;
+        double* sz = h->mC.p + n * k;
+        if (n) HIP_CHECK(hipMemcpyAsync(sx, rhsx, n * k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(sz, rhsz, m * k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_pack_rhs(h->mB.p, sx, sz, h->K.n, h->K.m, h->K.p, h->stream, (int)nrhs);
+        int rc = kkt_solve_multi_core(h, (int)nrhs, ir_iterations);
+        if (rc != HIPKKT_OK) return rc;
+        kkt_multi_unpack(h, (int)nrhs, lhsx, lhsz, hipMemcpyDeviceToHost);
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return HIPKKT_OK;
     });

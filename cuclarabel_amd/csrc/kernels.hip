@@ -116,9 +116,13 @@ void launch_regularizer(const double* K, const int* diag, int N, double c0, doub
 template <int G>
 __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __restrict__ K,
                                                   const double* __restrict__ b, const double* __restrict__ x,
-                                                  double* __restrict__ e, double* __restrict__ partial)
+                                                  double* __restrict__ e, double* __restrict__ partial, int64_t ld)
 {
     __shared__ double sh[4];
+    b += blockIdx.y * ld;
+    x += blockIdx.y * ld;
+    e += blockIdx.y * ld;
+    partial += blockIdx.y * gridDim.x;
     const int sub = threadIdx.x % G;
     const int rows_per_block = 256 / G;
     double vmax = 0.0;
@@ -143,6 +147,8 @@ __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, do
 {
     __shared__ double sh[4];
     double v = 0.0;
+    partial += blockIdx.x * nparts;
+    out += blockIdx.x;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) v = fmax(v, partial[i]);
     v = block_max_256(v, sh);
     // norm(e, Inf) of a vector holding Inf or NaN is not finite either way; the caller only
@@ -150,19 +156,23 @@ __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, do
     if (threadIdx.x == 0) out[0] = v;
 }
 void launch_residual(const SpmvDev& A, const double* K, const double* b, const double* x, double* e,
-                     double* partial, double* norm_out, hipStream_t st)
+                     double* partial, double* norm_out, hipStream_t st, int nrhs, int64_t ld)
 {
     int rows_per_block = 256 / A.lanes_per_row;
     int g = (A.N + rows_per_block - 1) / rows_per_block;
-    if (g > 2048) g = 2048;
+    if (g > kNormParts) g = kNormParts;
     if (g < 1) g = 1;
-    if (A.lanes_per_row == 8) hipLaunchKernelGGL(k_residual<8>, dim3(g), dim3(256), 0, st, A, K, b, x, e, partial);
-    else hipLaunchKernelGGL(k_residual<64>, dim3(g), dim3(256), 0, st, A, K, b, x, e, partial);
-    hipLaunchKernelGGL(k_finish_norm, dim3(1), dim3(256), 0, st, partial, g, norm_out);
+    if (A.lanes_per_row == 8)
+        hipLaunchKernelGGL(k_residual<8>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
+    else
+        hipLaunchKernelGGL(k_residual<64>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
+    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, norm_out);
 }
-__global__ void k_absmax(const double* __restrict__ v, int n, double* __restrict__ partial)
+__global__ void k_absmax(const double* __restrict__ v, int n, double* __restrict__ partial, int64_t ld)
 {
     __shared__ double sh[4];
+    v += blockIdx.y * ld;
+    partial += blockIdx.y * gridDim.x;
     double m = 0.0;
     bool bad = false;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -174,17 +184,18 @@ __global__ void k_absmax(const double* __restrict__ v, int n, double* __restrict
     m = block_max_256(m, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = m;
 }
-void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st)
+void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st, int nrhs, int64_t ld)
 {
     int g = grid_for(n, 256, kRedBlocks);
-    hipLaunchKernelGGL(k_absmax, dim3(g), dim3(256), 0, st, v, n, partial);
-    hipLaunchKernelGGL(k_finish_norm, dim3(1), dim3(256), 0, st, partial, g, out);
+    hipLaunchKernelGGL(k_absmax, dim3(g, nrhs), dim3(256), 0, st, v, n, partial, ld);
+    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, out);
 }
-__global__ void k_sum2(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int n)
+__global__ void k_sum2(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int64_t n)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = a[i] + b[i];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a[i] + b[i];
 }
-void launch_axpby_sum(double* y, const double* a, const double* b, int n, hipStream_t st)
+void launch_axpby_sum(double* y, const double* a, const double* b, int64_t n, hipStream_t st)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_sum2, dim3(grid_for(n, 256)), dim3(256), 0, st, y, a, b, n);
@@ -193,12 +204,31 @@ __global__ void k_pack_rhs(double* __restrict__ b, const double* __restrict__ rx
                            int n, int m, int p)
 {
     const int N = n + m + p;
+    b += (int64_t)blockIdx.y * N;
+    rx += (int64_t)blockIdx.y * n;
+    rz += (int64_t)blockIdx.y * m;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
         b[i] = i < n ? rx[i] : (i < n + m ? rz[i - n] : 0.0);      // kktsolver_directldl.jl:313-327
 }
-void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m, int p, hipStream_t st)
+void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m, int p, hipStream_t st, int nrhs)
 {
-    hipLaunchKernelGGL(k_pack_rhs, dim3(grid_for(n + m + p, 256)), dim3(256), 0, st, b, rx, rz, n, m, p);
+    hipLaunchKernelGGL(k_pack_rhs, dim3(grid_for(n + m + p, 256), nrhs), dim3(256), 0, st, b, rx, rz, n, m, p);
+}
+__global__ void k_accept_columns(double* __restrict__ x, const double* __restrict__ cand, double* __restrict__ e,
+                                 const double* __restrict__ e2, const int* __restrict__ mask, int N)
+{
+    if (!mask[blockIdx.y]) return;
+    const int64_t o = (int64_t)blockIdx.y * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        x[o + i] = cand[o + i];
+        e[o + i] = e2[o + i];
+    }
+}
+void launch_accept_columns(double* x, const double* cand, double* e, const double* e2, const int* mask, int N,
+                           int nrhs, hipStream_t st)
+{
+    if (N <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_accept_columns, dim3(grid_for(N, 256, 1024), nrhs), dim3(256), 0, st, x, cand, e, e2, mask, N);
 }
 __global__ void k_check_finite(const double* __restrict__ v, int n, int* __restrict__ flag)
 {

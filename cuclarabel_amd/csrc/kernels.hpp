@@ -76,6 +76,9 @@ struct TreeDev {                 // device copies of the symbolic structure
     // uvec[gl_src[q]] for q in gl_ptr[lc] .. gl_ptr[lc+1]
     const int64_t* gl_ptr;
     const int* gl_src;
+    // inverse of gl_src: contribution entry e of the tree (index into uvec) is gather-list entry udst[e] of its
+    // receiver.  The multi-column solve stores contributions in THAT order, so a receiver reads a contiguous run.
+    const int* udst;
     // per child c: cuts[cut_ptr[c] + t] = first child row index whose parent-local row >= nc_p + 64 t
     const int64_t* cut_ptr;
     const int* cuts;
@@ -114,6 +117,8 @@ struct SolveArgs {
     double* out;                 // original order
     double* xp;                  // N, permuted work vector
     double* uvec;                // sum nb
+    // several right-hand sides in one launch: column blockIdx.y lives at these strides (0 for one column)
+    int64_t ld_b, ld_out, ld_xp, ld_uvec;
 };
 
 constexpr int kSolveChunk = 128;  // diagonal chunk of the triangular solves: one wave, two unknowns per lane
@@ -134,8 +139,16 @@ void launch_front_wave(const FactorArgs& a, int begin, int count, int slice_doub
 void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st);
 size_t panel_lds_bytes(int fmax, int panel_max);
-void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
-void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
+// nrhs > 1: grid.y = right-hand side column, strides in SolveArgs::ld_*
+void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
+void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
+
+// several right-hand sides: work vectors row-major N x KP / sum(nb) x KP (KP = columns rounded up to 16)
+// iperm[caller's index] = permuted index
+void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
+void launch_permute_out(double* X, int64_t ldx, const double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
+void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
+void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
 
 // ---- KKT value updates (kktsolver_directldl.jl:130-188, 211-245, 374-386)
 void launch_scatter(double* Kval, const int* idx, const double* vals, int64_t n, double scale, hipStream_t st);
@@ -156,12 +169,20 @@ struct SpmvDev {
     int N;
     int lanes_per_row;           // 8 or 64
 };
-// norm_out[0] = ||e||_inf (NaN if any entry is non-finite)
+// norm_out[j] = ||e_j||_inf (not finite if any entry is non-finite).  nrhs > 1: column j of b, x, e
+// at stride ld; `partial` then needs nrhs * kNormParts doubles
+constexpr int kNormParts = 2048;
 void launch_residual(const SpmvDev& A, const double* Kval, const double* b, const double* x, double* e,
-                     double* partial, double* norm_out, hipStream_t st);
-void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st);
-void launch_axpby_sum(double* y, const double* a, const double* b, int n, hipStream_t st);   // y = a + b
-void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m, int p, hipStream_t st);
+                     double* partial, double* norm_out, hipStream_t st, int nrhs = 1, int64_t ld = 0);
+void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st, int nrhs = 1,
+                     int64_t ld = 0);
+void launch_axpby_sum(double* y, const double* a, const double* b, int64_t n, hipStream_t st);   // y = a + b
+// b_j = [rx_j; rz_j; 0]: rx is n x nrhs (ld n), rz is m x nrhs (ld m), b is N x nrhs (ld N)
+void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m, int p, hipStream_t st,
+                     int nrhs = 1);
+// columns j with mask[j] != 0: x_j = cand_j, e_j = e2_j  (N x nrhs, ld N)
+void launch_accept_columns(double* x, const double* cand, double* e, const double* e2, const int* mask, int N,
+                           int nrhs, hipStream_t st);
 void launch_check_finite(const double* v, int n, int* flag, hipStream_t st);
 
 // ---- cone scalings on the device (update_scaling! + get_Hs!, src/cones/coneops_*.jl)

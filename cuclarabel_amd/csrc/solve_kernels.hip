@@ -15,6 +15,7 @@
 //            workgroup barrier per column); the off-diagonal panel is a dense GEMV streamed from
 //            HBM/L2 with 8 independent loads in flight per lane.
 #include "kernels.hpp"
+#include <algorithm>
 
 namespace hipkkt {
 
@@ -44,13 +45,16 @@ __global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int co
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
+    const double* __restrict__ bcol = A.b + blockIdx.y * A.ld_b;          // right-hand side column blockIdx.y
+    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
+    double* __restrict__ uvec = A.uvec + blockIdx.y * A.ld_uvec;
 
     // gather: right-hand side entry plus the children's contributions to this row, in child order
-    double y = (lane < nc) ? A.b[T.perm[c0 + lane]] : 0.0;
+    double y = (lane < nc) ? bcol[T.perm[c0 + lane]] : 0.0;
     if (lane < f) {
         const int64_t lc = (int64_t)c0 + rp + lane;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; ++g) y += A.uvec[T.gl_src[g]];
+        for (int64_t g = g0; g < g1; ++g) y += uvec[T.gl_src[g]];
     }
     // column sweep: y_l -= L(l,k) y_k
     for (int k0 = 0; k0 < nc; k0 += 8) {
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int co
             }
         }
     }
-    if (lane < nc) A.xp[c0 + lane] = y;
-    else if (lane < f) A.uvec[rp + lane - nc] = y;
+    if (lane < nc) xp[c0 + lane] = y;
+    else if (lane < f) uvec[rp + lane - nc] = y;
 }
 
 __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int count)
@@ -84,11 +88,13 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
+    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
+    double* __restrict__ out = A.out + blockIdx.y * A.ld_out;
 
     // lane = row: y_r = D^{-1} x_r for the front's own columns, the ancestors' solution below
     double y = 0.0;
-    if (lane < nc) y = A.xp[c0 + lane] * A.Dinv[c0 + lane];
-    else if (lane < f) y = A.xp[T.rows[rp + lane - nc]];
+    if (lane < nc) y = xp[c0 + lane] * A.Dinv[c0 + lane];
+    else if (lane < f) y = xp[T.rows[rp + lane - nc]];
     // x_j = y_j - sum_{r > j} L(r,j) x_r, j = nc-1 .. 0: column loads (coalesced over lanes) issued eight
     // at a time up front; one wave reduction per column
     for (int j1 = nc; j1 > 0; j1 -= 8) {
@@ -108,8 +114,8 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
         }
     }
     if (lane < nc) {
-        A.xp[c0 + lane] = y;
-        A.out[T.perm[c0 + lane]] = y;
+        xp[c0 + lane] = y;
+        out[T.perm[c0 + lane]] = y;
     }
 }
 
@@ -139,10 +145,13 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
     const int fpad = (f + 3) & ~3;
     double* y = smem;                        // fpad
     double* part = smem + fpad;              // nks * fpad
+    const double* __restrict__ bcol = A.b + blockIdx.y * A.ld_b;          // right-hand side column blockIdx.y
+    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
+    double* __restrict__ uvec = A.uvec + blockIdx.y * A.ld_uvec;
 
     // gather: right-hand side entry plus the children's contributions to each row, in child order
     for (int i = tid; i < f; i += BS) {
-        double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
+        double v = (i < nc) ? bcol[T.perm[c0 + i]] : 0.0;
         const int64_t lc = (int64_t)c0 + rp + i;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
         for (int64_t g = g0; g < g1; g += 4) {
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
             for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
             double u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? A.uvec[src[q]] : 0.0;
+            for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? uvec[src[q]] : 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) v += u[q];
         }
@@ -178,8 +187,8 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
     for (int i = tid; i < f; i += BS) {
         double v = 0.0;
         for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
-        if (i < nc) A.xp[c0 + i] = v;
-        else A.uvec[rp + i - nc] = y[i] - v;
+        if (i < nc) xp[c0 + i] = v;
+        else uvec[rp + i - nc] = y[i] - v;
     }
 }
 
@@ -221,10 +230,12 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
     const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
     double* z = smem;
     double* part = smem + fpad;
+    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
+    double* __restrict__ out = A.out + blockIdx.y * A.ld_out;
 
     // z = [D^{-1} y_s ; -x_below]
     for (int i = tid; i < f; i += BS)
-        z[i] = (i < nc) ? A.xp[c0 + i] * A.Dinv[c0 + i] : -A.xp[T.rows[rp + i - nc]];
+        z[i] = (i < nc) ? xp[c0 + i] * A.Dinv[c0 + i] : -xp[T.rows[rp + i - nc]];
     __syncthreads();
     bwd_items(Wt, nc, f, z, part, ncpad, wv, NW, lane);
     __syncthreads();
@@ -232,8 +243,8 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
     for (int j = tid; j < nc; j += BS) {
         double v = 0.0;
         for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
-        A.xp[c0 + j] = v;
-        A.out[T.perm[c0 + j]] = v;
+        xp[c0 + j] = v;
+        out[T.perm[c0 + j]] = v;
     }
 }
 
@@ -630,26 +641,421 @@ size_t solve_lds_bytes(int fmax, int ncmax)
     return (fwd > bwd ? fwd : bwd) * sizeof(double);
 }
 
-void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
+void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
 {
-    if (count <= 0) return;
+    if (count <= 0 || nrhs <= 0) return;
     if (bs == 64) {
-        hipLaunchKernelGGL(k_fwd_wave, dim3((count + 3) / 4), dim3(256), 0, st, a, begin, count);
+        hipLaunchKernelGGL(k_fwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
     } else {
         init_solve_lds();
-        hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count), dim3(kSolveBS), lds, st, a, begin);
+        hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
     }
 }
-void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st)
+void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
 {
-    if (count <= 0) return;
+    if (count <= 0 || nrhs <= 0) return;
     if (bs == 64) {
-        hipLaunchKernelGGL(k_bwd_wave, dim3((count + 3) / 4), dim3(256), 0, st, a, begin, count);
+        hipLaunchKernelGGL(k_bwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
     } else {
         init_solve_lds();
-        hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count), dim3(kSolveBS), lds, st, a, begin);
+        hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
     }
 }
+// ------------------------------------------------------------------ several right-hand sides
+// The single-column kernels above are latency-bound; with many columns the cost is fetching the
+// solve matrices, so these variants use every entry they load for a whole block of columns:
+//   * the work vectors are ROW-major, N x KP and sum(nb) x KP (KP = column count rounded up to 16,
+//     padding columns zero), so that one row of a column block is contiguous -- every gather moves
+//     full cache lines; contribution rows are stored in the order of their receiver's gather list
+//     (TreeDev::udst), so a receiver sums a contiguous run without the gl_src[] indirection;
+//   * k_permute_in / k_permute_out convert from / to the caller's column-major vectors, coalesced
+//     on the caller's side and sector-sized on the permuted side;
+//   * block fronts: [x_s; w] = W y_s and x_s = W' z are GEMMs with 16 columns -> v_mfma_f64_16x16x4_f64,
+//     A operand (W, 16 consecutive rows per k) straight from global, B operand from LDS (forward) or
+//     straight from the row-major work vector (backward);
+//   * small fronts (one wave each): lane = column, substitution with wave-uniform matrix entries.
+constexpr int kMultiCB = 16;         // columns per block-kernel workgroup (one MFMA tile wide)
+typedef double d4m_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_permute_in(const double* __restrict__ B, int64_t ldb, double* __restrict__ Xp,
+                                                    int KP, const int* __restrict__ iperm, int N, int nrhs)
+{
+    // thread = (caller's row o, group of 8 columns): column reads coalesced over o, one 64-byte write per thread
+    const int groups = KP >> 3;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)N * groups;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % N), gq = (int)(idx / N);
+        const int i = iperm[o];
+        double v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (gq * 8 + c < nrhs) ? B[(int64_t)(gq * 8 + c) * ldb + o] : 0.0;
+        double2* dst = reinterpret_cast<double2*>(Xp + (int64_t)i * KP + gq * 8);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[c] = make_double2(v[2 * c], v[2 * c + 1]);
+    }
+}
+__global__ __launch_bounds__(256) void k_permute_out(double* __restrict__ X, int64_t ldx, const double* __restrict__ Xp,
+                                                     int KP, const int* __restrict__ iperm, int N, int nrhs)
+{
+    const int groups = KP >> 3;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)N * groups;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % N), gq = (int)(idx / N);
+        const int i = iperm[o];
+        const double2* src = reinterpret_cast<const double2*>(Xp + (int64_t)i * KP + gq * 8);
+        double2 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = src[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (gq * 8 + 2 * c < nrhs) X[(int64_t)(gq * 8 + 2 * c) * ldx + o] = v[c].x;
+            if (gq * 8 + 2 * c + 1 < nrhs) X[(int64_t)(gq * 8 + 2 * c + 1) * ldx + o] = v[c].y;
+        }
+    }
+}
+
+// One-wave fronts (f <= 64): lane = right-hand-side column (64 per wave, grid.y = KP / 64), so every row
+// of the work vectors is one coalesced 512-byte access and all lanes work whatever the front's size; the
+// entries of L, the gather lists and the row indices are wave-uniform (scalar loads).  The first kWC own
+// unknowns stay in registers; beyond that they are re-read from the work vector (same lane wrote them).
+constexpr int kWC = 16;
+
+// xp (N x KP) holds the permuted right-hand sides on entry of the forward sweep
+__global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int count, int KP)
+{
+    const int lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= count) return;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + item];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + fd.front_off;
+    const int col = blockIdx.y * 64 + lane;
+    const bool act = col < KP;
+    const int cc = act ? col : KP - 1;
+    double* __restrict__ xp = A.xp + cc;
+    double* __restrict__ uvec = A.uvec + cc;
+
+    double yk[kWC];
+#pragma unroll
+    for (int k = 0; k < kWC; ++k) yk[k] = 0.0;
+    for (int i = 0; i < f; ++i) {
+        double v = (i < nc) ? xp[(int64_t)(c0 + i) * KP] : 0.0;
+        const int64_t lc = (int64_t)c0 + rp + i;
+        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
+        for (int64_t g = g0; g < g1; g += 4) {
+            double u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = (g + q < g1) ? uvec[(g + q) * KP] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v += u[q];
+        }
+        const int km = min(i, nc);
+        const double* __restrict__ Li = F + i;                 // L(i, k) = Li[k * f]
+#pragma unroll
+        for (int k = 0; k < kWC; ++k)
+            if (k < km) v = fma(-Li[(int64_t)k * f], yk[k], v);
+        for (int k = kWC; k < km; ++k) v = fma(-Li[(int64_t)k * f], xp[(int64_t)(c0 + k) * KP], v);
+        if (i < nc) {
+#pragma unroll
+            for (int k = 0; k < kWC; ++k)
+                if (k == i) yk[k] = v;
+            if (act) xp[(int64_t)(c0 + i) * KP] = v;
+        } else if (act) {
+            uvec[(int64_t)T.udst[rp + i - nc] * KP] = v;
+        }
+    }
+}
+
+// own columns in chunks of kWC from the last one up: acc_j = D^{-1} y_j - sum over the rows below the chunk,
+// each such row loaded once; then the triangle inside the chunk from registers
+__global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int count, int KP)
+{
+    const int lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= count) return;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + item];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + fd.front_off;
+    const int col = blockIdx.y * 64 + lane;
+    const bool act = col < KP;
+    const int cc = act ? col : KP - 1;
+    double* __restrict__ xp = A.xp + cc;
+
+    for (int jhi = nc; jhi > 0; jhi -= kWC) {
+        const int jlo = max(0, jhi - kWC);
+        const int w = jhi - jlo;
+        double acc[kWC];
+#pragma unroll
+        for (int q = 0; q < kWC; ++q) acc[q] = (q < w) ? xp[(int64_t)(c0 + jlo + q) * KP] * A.Dinv[c0 + jlo + q] : 0.0;
+        for (int r0 = jhi; r0 < f; r0 += 4) {
+            double xr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e;
+                xr[e] = 0.0;
+                if (r < f) xr[e] = xp[(int64_t)(r < nc ? c0 + r : T.rows[rp + r - nc]) * KP];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e;
+                if (r < f) {
+                    const double* __restrict__ Lr = F + r + (int64_t)jlo * f;      // L(r, jlo + q) = Lr[q * f]
+#pragma unroll
+                    for (int q = 0; q < kWC; ++q)
+                        if (q < w) acc[q] = fma(-Lr[(int64_t)q * f], xr[e], acc[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = kWC - 1; q >= 0; --q) {
+            if (q < w) {
+                const double xj = acc[q];
+                if (act) xp[(int64_t)(c0 + jlo + q) * KP] = xj;
+                const double* __restrict__ Lj = F + (jlo + q) + (int64_t)jlo * f;   // L(jlo + q, jlo + q2) = Lj[q2 * f]
+#pragma unroll
+                for (int q2 = 0; q2 < kWC; ++q2)
+                    if (q2 < q) acc[q2] = fma(-Lj[(int64_t)q2 * f], xj, acc[q2]);
+            }
+        }
+    }
+}
+
+// forward, block fronts: Ys = gathered own rows (nc x 16, LDS); every wave takes 16-row tiles of W,
+// out = W Ys on the matrix cores; rows below the diagonal block gather their children's contributions
+// in the epilogue (they are only needed there).
+__global__ __launch_bounds__(512, 6) void k_fwd_block_m(SolveArgs A, int begin, int KP)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ml = lane & 15, mk = lane >> 4;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ W = A.tinv + fd.w_off;                  // f x nc, ld f
+    double* __restrict__ xp = A.xp + blockIdx.y * kMultiCB;
+    double* __restrict__ uvec = A.uvec + blockIdx.y * kMultiCB;
+    const int ncp = (nc + 3) & ~3;
+    double* Ys = smem;                       // ncp x 16 row-major
+
+    // own rows: thread = (row, column); four rows per thread in flight so that the dependent chain
+    // gather-list bounds -> sources -> values is paid once per four rows
+    for (int base = 0; base < ncp * 16; base += 4 * 512) {
+        int64_t pg0[4], pg1[4];
+        double pv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = base + p * 512 + tid;
+            const int i = idx >> 4;
+            pg0[p] = pg1[p] = 0;
+            pv[p] = 0.0;
+            if (i < nc) {
+                const int64_t lc = (int64_t)c0 + rp + i;
+                pg0[p] = T.gl_ptr[lc];
+                pg1[p] = T.gl_ptr[lc + 1];
+                pv[p] = xp[(int64_t)(c0 + i) * KP + (idx & 15)];
+            }
+        }
+        for (int e = 0;; e += 2) {
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) any = any || pg0[p] + e < pg1[p];
+            if (!any) break;
+            double u[4][2];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    u[p][d] = (pg0[p] + e + d < pg1[p]) ? uvec[(pg0[p] + e + d) * KP + (tid & 15)] : 0.0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) pv[p] = (pv[p] + u[p][0]) + u[p][1];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = base + p * 512 + tid;
+            if (idx < ncp * 16) Ys[idx] = pv[p];
+        }
+    }
+    __syncthreads();
+    const int ntile = (f + 15) >> 4;
+    for (int t = wv; t < ntile; t += 8) {
+        const int r0 = t * 16;
+        // gather lists of this lane's four output rows (r0 + mk + 4q), fetched ahead of the product
+        int64_t g0[4], g1[4];
+        int ud[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = r0 + mk + 4 * q;
+            g0[q] = g1[q] = 0;
+            ud[q] = 0;
+            if (i >= nc && i < f) {
+                const int64_t lc = (int64_t)c0 + rp + i;
+                g0[q] = T.gl_ptr[lc];
+                g1[q] = T.gl_ptr[lc + 1];
+                ud[q] = T.udst[rp + i - nc];
+            }
+        }
+        d4m_t acc = {0.0, 0.0, 0.0, 0.0};
+        const int kend = min(nc, r0 + 16);               // T = L11^{-1} is lower triangular
+        const bool rowok = r0 + ml < f;
+        const double* __restrict__ Wr = W + r0 + ml;
+        for (int k0 = 0; k0 < kend; k0 += 32) {
+            double a[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int k = k0 + 4 * s + mk;
+                a[s] = (rowok && k < kend) ? Wr[(int64_t)k * f] : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (k0 + 4 * s < kend) {
+                    const int k = k0 + 4 * s + mk;       // < ncp
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Ys[k * 16 + ml], acc, 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: the four rows' gather lists advance together (one dependent chain for all of them)
+        double gv[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int e = 0;; e += 2) {
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) any = any || g0[q] + e < g1[q];
+            if (!any) break;
+            double u[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    u[q][d] = (g0[q] + e + d < g1[q]) ? uvec[(g0[q] + e + d) * KP + ml] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gv[q] = (gv[q] + u[q][0]) + u[q][1];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = r0 + mk + 4 * q;
+            if (i < nc) xp[(int64_t)(c0 + i) * KP + ml] = acc[q];
+            else if (i < f) uvec[(int64_t)ud[q] * KP + ml] = gv[q] - acc[q];
+        }
+    }
+}
+
+// backward, block fronts: x_s = W' z, z = [D^{-1} y_s ; -x_below].  Items = (16-column tile of W', slice of
+// the rows); the B operand z is read straight from the row-major work vector (16 lanes = 128 contiguous
+// bytes per row); partial tiles are combined through LDS in slice order.
+__device__ inline int bwd_multi_slices(int nt, int f)
+{
+    int ns = 8 / nt;
+    const int cap = (f + 31) >> 5;
+    if (ns > cap) ns = cap;
+    return ns < 1 ? 1 : ns;
+}
+__global__ __launch_bounds__(512) void k_bwd_block_m(SolveArgs A, int begin, int KP)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ml = lane & 15, mk = lane >> 4;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;       // W'(j, r) at j + r*nc
+    double* __restrict__ xp = A.xp + blockIdx.y * kMultiCB;
+    const int nt = (nc + 15) >> 4;
+    const int ns = bwd_multi_slices(nt, f);
+    const int sl = ((((f + ns - 1) / ns) + 3) >> 2) << 2;
+    double* part = smem;                     // (ns * nt) tiles of 16 x 16
+
+    for (int it = wv; it < nt * ns; it += 8) {
+        const int s = it / nt, jt = it - s * nt;
+        const int j0 = 16 * jt;
+        const int rbeg = max(s * sl, j0 & ~3);           // W'(j, r) = 0 for r < j
+        const int rend = min(f, (s + 1) * sl);
+        const bool colok = j0 + ml < nc;
+        const double* __restrict__ Wc = Wt + j0 + ml;
+        d4m_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int r0 = rbeg; r0 < rend; r0 += 32) {
+            int ri[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + 4 * q + mk;
+                ri[q] = -1;
+                if (r < rend) ri[q] = (r < nc) ? c0 + r : T.rows[rp + r - nc];
+            }
+            double a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + 4 * q + mk;
+                a[q] = (colok && r < rend) ? Wc[(int64_t)r * nc] : 0.0;
+                b[q] = ri[q] >= 0 ? xp[(int64_t)ri[q] * KP + ml] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + 4 * q + mk;
+                if (r < nc) b[q] *= A.Dinv[c0 + r];
+                else b[q] = -b[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + 4 * q < rend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[it * 256 + (mk + 4 * q) * 16 + ml] = acc[q];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nc * 16; idx += 512) {
+        const int j = idx >> 4, n = idx & 15;
+        const int jt = j >> 4;
+        double v = 0.0;
+        for (int s = 0; s < ns; ++s) v += part[(s * nt + jt) * 256 + (j & 15) * 16 + n];
+        xp[(int64_t)(c0 + j) * KP + n] = v;
+    }
+}
+
+void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st)
+{
+    const int64_t work = (int64_t)N * (KP >> 3);
+    int g = (int)std::min<int64_t>((work + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_permute_in, dim3(g < 1 ? 1 : g), dim3(256), 0, st, B, ldb, Xp, KP, iperm, N, nrhs);
+}
+void launch_permute_out(double* X, int64_t ldx, const double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st)
+{
+    const int64_t work = (int64_t)N * (KP >> 3);
+    int g = (int)std::min<int64_t>((work + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_permute_out, dim3(g < 1 ? 1 : g), dim3(256), 0, st, X, ldx, Xp, KP, iperm, N, nrhs);
+}
+void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st)
+{
+    if (count <= 0) return;
+    if (small) {
+        hipLaunchKernelGGL(k_fwd_wave_m, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
+        return;
+    }
+    const size_t lds = (size_t)((ncmax + 3) & ~3) * 16 * sizeof(double);
+    hipLaunchKernelGGL(k_fwd_block_m, dim3(count, KP / kMultiCB), dim3(512), lds, st, a, begin, KP);
+}
+void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st)
+{
+    if (count <= 0) return;
+    if (small) {
+        hipLaunchKernelGGL(k_bwd_wave_m, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
+        return;
+    }
+    // at most max(8, nt) partial tiles of 16 x 16
+    const int nt = (ncmax + 15) >> 4;
+    const size_t lds = (size_t)std::max(8, nt) * 256 * sizeof(double);
+    hipLaunchKernelGGL(k_bwd_block_m, dim3(count, KP / kMultiCB), dim3(512), lds, st, a, begin, KP);
+}
+
 int top_solve_capacity(size_t lds)
 {
     init_solve_lds();

@@ -58,3 +58,31 @@ def gather_records(local_records, n_problems, width, device=None):
             if not torch.isnan(row[0]):
                 out[int(row[0].item())] = row
     return out
+
+
+# ---- right-hand-side columns of ONE factorisation dealt to ranks ----
+def shard_columns(n_columns, world_size, rank):
+    """Round-robin: rank r solves columns r, r + world, r + 2 world, ..."""
+    return list(range(rank, n_columns, world_size))
+
+
+def gather_columns(local, n_columns, device=None):
+    """All-gather of the per-rank solution blocks.  `local`: (len(shard_columns(...)), length)
+    tensor, row q = this rank's q-th column.  Returns (n_columns, length), row j = column j, on
+    every rank.  One collective of n_columns*length/world doubles per rank -- the only exchange of
+    the batched-RHS mode (ring all-gather over xGMI: per-link bound, so it is issued once per
+    batch, not per column)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    length = local.shape[1]
+    if world == 1:
+        return local[:n_columns]
+    per = (n_columns + world - 1) // world
+    send = torch.zeros(per, length, dtype=local.dtype, device=local.device if device is None else device)
+    km = len(shard_columns(n_columns, world, rank))
+    send[:km] = local[:km]
+    out = torch.empty(world * per, length, dtype=local.dtype, device=send.device)
+    dist.all_gather_into_tensor(out, send)
+    # row r*per + q holds column q*world + r
+    out = out.view(world, per, length).transpose(0, 1).reshape(per * world, length)
+    return out[:n_columns]

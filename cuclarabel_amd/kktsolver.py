@@ -114,6 +114,31 @@ class HipKKTSolver:
                                                      C.c_void_p(d_lhsz) if d_lhsz else None),
                      "hipkkt_kkt_solve_dev")
 
+    def kktsolver_solve_multi(self, rhsx, rhsz, want_x=True, want_z=True):
+        """setrhs! + solve! for several right-hand sides against the current factorisation.
+        rhsx: (n, k), rhsz: (m, k).  Returns (is_success, lhsx (n, k) | None, lhsz (m, k) | None,
+        refinement rounds per column)."""
+        RX = np.asfortranarray(rhsx, dtype=np.float64)
+        RZ = np.asfortranarray(rhsz, dtype=np.float64)
+        if RX.ndim != 2 or RZ.ndim != 2 or RX.shape[0] != self.n or RZ.shape[0] != self.m or RX.shape[1] != RZ.shape[1]:
+            raise ValueError("rhsx must be (n, k) and rhsz (m, k)")
+        k = RX.shape[1]
+        LX = np.zeros((self.n, k), order="F") if want_x else None
+        LZ = np.zeros((self.m, k), order="F") if want_z else None
+        ir = np.zeros(max(k, 1), dtype=np.int64)
+        ok = check(_lib.lib().hipkkt_kkt_solve_multi(self._h, k, ptr(RX), ptr(RZ), ptr(LX), ptr(LZ), ptr(ir)),
+                   "hipkkt_kkt_solve_multi")
+        return ok, LX, LZ, ir[:k]
+
+    def kktsolver_solve_multi_dev(self, k, d_rx, d_rz, d_lhsx, d_lhsz):
+        """Device-pointer variant (column-major, contiguous).  Returns (is_success, rounds per column)."""
+        ir = np.zeros(max(k, 1), dtype=np.int64)
+        ok = check(_lib.lib().hipkkt_kkt_solve_multi_dev(self._h, k, C.c_void_p(d_rx), C.c_void_p(d_rz),
+                                                         C.c_void_p(d_lhsx) if d_lhsx else None,
+                                                         C.c_void_p(d_lhsz) if d_lhsz else None, ptr(ir)),
+                   "hipkkt_kkt_solve_multi_dev")
+        return ok, ir[:k]
+
     def kktsolver_update_P(self, P):
         Px = f64(P.data if sp.issparse(P) else P)
         if Px.size != self._nnzP:
@@ -243,6 +268,13 @@ class HipDirectLDLSolver:
         if x.dtype != np.float64 or x.size != self.N or b.size != self.N:
             raise ValueError("x, b must be float64 of length N")
         check(_lib.lib().hipkkt_ldl_solve(self._h, ptr(x), ptr(b)), "hipkkt_ldl_solve")
+
+    def solve_multi(self, K, X, B):
+        """solve! on the columns of B (N, k) into X (N, k), both Fortran-ordered float64."""
+        B = np.asfortranarray(B, dtype=np.float64)
+        if X.dtype != np.float64 or X.shape != B.shape or B.shape[0] != self.N or not X.flags.f_contiguous:
+            raise ValueError("X, B must be Fortran-ordered float64 (N, k)")
+        check(_lib.lib().hipkkt_ldl_solve_multi(self._h, B.shape[1], ptr(X), ptr(B)), "hipkkt_ldl_solve_multi")
 
     def linear_solver_info(self):
         info = _lib.Info()

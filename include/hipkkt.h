@@ -120,6 +120,13 @@ int hipkkt_ldl_refactor(hipkkt_ldl_t h);
 /* solve! (directldl_qdldl.jl:85-96): x = K^{-1} b, host vectors of length N, x != b allowed */
 int hipkkt_ldl_solve(hipkkt_ldl_t h, double *x, const double *b);
 int hipkkt_ldl_solve_dev(hipkkt_ldl_t h, double *d_x, const double *d_b);
+/* solve! for nrhs right-hand sides against the same factors (SURVEY.md 8b "batched", 8e(ii):
+ * the reference has no such call -- its solve! at directldl_qdldl.jl:85-96 takes one vector --
+ * a caller with several vectors loops over it).  X, B: N x nrhs column-major, host (ld = N) or
+ * device (ldx, ldb >= N); X may alias B.  Column j's result equals hipkkt_ldl_solve on column j. */
+int hipkkt_ldl_solve_multi(hipkkt_ldl_t h, int64_t nrhs, double *X, const double *B);
+int hipkkt_ldl_solve_multi_dev(hipkkt_ldl_t h, int64_t nrhs, double *d_X, int64_t ldx,
+                               const double *d_B, int64_t ldb);
 /* linear_solver_info (directldl_qdldl.jl:35-42) */
 int hipkkt_ldl_info(hipkkt_ldl_t h, hipkkt_info *info);
 int hipkkt_ldl_get_perm(hipkkt_ldl_t h, int64_t *perm /* N, 0-based */);
@@ -154,6 +161,17 @@ int hipkkt_kkt_setrhs(hipkkt_kkt_t h, const double *rhsx, const double *rhsz);
 int hipkkt_kkt_solve(hipkkt_kkt_t h, double *lhsx, double *lhsz);
 int hipkkt_kkt_setrhs_dev(hipkkt_kkt_t h, const double *d_rhsx, const double *d_rhsz);
 int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double *d_lhsx, double *d_lhsz);
+/* kktsolver_setrhs! + kktsolver_solve! for nrhs right-hand sides at once (SURVEY.md 8b
+ * "hipkkt_kkt_solve_multi"): rhsx n x nrhs, rhsz m x nrhs, column-major, contiguous; lhsx / lhsz
+ * likewise, either may be NULL.  Every column goes through the reference's refinement rule on its
+ * own (kktsolver_directldl.jl:389-449) and ends where its single solve would; ir_iterations
+ * (host, nrhs entries, may be NULL) receives the rounds each column took.  Returns 1 if any
+ * column's residual is not finite.  Does not disturb the right-hand side set by hipkkt_kkt_setrhs. */
+int hipkkt_kkt_solve_multi(hipkkt_kkt_t h, int64_t nrhs, const double *rhsx, const double *rhsz,
+                           double *lhsx, double *lhsz, int64_t *ir_iterations);
+int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double *d_rhsx,
+                               const double *d_rhsz, double *d_lhsx, double *d_lhsz,
+                               int64_t *ir_iterations);
 /* y = W'W x over all cones with the current scaling (mul_Hs!, coneops_compositecone.jl:138-150);
  * valid after hipkkt_kkt_update_from_sz*.  Host vectors of length m. */
 int hipkkt_kkt_mul_Hs(hipkkt_kkt_t h, double *y, const double *x);

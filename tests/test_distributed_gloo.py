@@ -72,3 +72,59 @@ def test_weighted_assignment_balances_and_is_a_partition():
     assert sorted(sum(parts, [])) == list(range(len(w)))
     loads = [sum(w[j] for j in p) for p in parts]
     assert max(loads) - min(loads) <= 2
+
+
+def _worker_columns(rank, world, port, n_columns, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuclarabel_amd import problems
+        from cuclarabel_amd.distributed import gather_columns, shard_columns
+        from tests.oracle_bindings import make_oracle
+        # ONE KKT system, replicated: every rank factorises it itself and solves its share of columns
+        pb = problems.config2(n=300)
+        o = make_oracle(pb)
+        assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+        rng = np.random.default_rng(77)
+        RX, RZ = rng.standard_normal((n_columns, pb.n)), rng.standard_normal((n_columns, pb.m))
+        mine = shard_columns(n_columns, world, rank)
+        local = torch.zeros(max(len(mine), 1), pb.n, dtype=torch.float64)
+        for qi, j in enumerate(mine):
+            o.kktsolver_setrhs(RX[j], RZ[j])
+            ok, x, _ = o.kktsolver_solve()
+            assert ok
+            local[qi] = torch.from_numpy(x)
+        full = gather_columns(local, n_columns)
+        q.put((rank, mine, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_rhs_column_sharding_and_solution_gather():
+    world, n_columns = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_columns, args=(r, world, port, n_columns, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    assert out[0][1] == [0, 2, 4] and out[1][1] == [1, 3]
+    np.testing.assert_array_equal(out[0][2], out[1][2])        # every rank holds every column, in order
+    # and they are the solutions a single process gets
+    from cuclarabel_amd import problems
+    from tests.oracle_bindings import make_oracle
+    pb = problems.config2(n=300)
+    o = make_oracle(pb)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    rng = np.random.default_rng(77)
+    RX, RZ = rng.standard_normal((n_columns, pb.n)), rng.standard_normal((n_columns, pb.m))
+    for j in range(n_columns):
+        o.kktsolver_setrhs(RX[j], RZ[j])
+        _, x, _ = o.kktsolver_solve()
+        np.testing.assert_array_equal(out[0][2][j], x)

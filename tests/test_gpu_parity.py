@@ -184,6 +184,16 @@ def test_numeric_failure_is_reported_not_raised():
     assert ks.kktsolver_update_from_sz(s, pb.z0) is False
 
 
+def test_psd_not_positive_definite_is_reported():
+    _, HipKKTSolver, _ = _hip()
+    pb = problems.config5(n=120, npsd=3, psd_dim=5, nsoc=1, soc_dim=8)
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    s = pb.s0.copy()
+    s[:15] = problems.mat_to_svec(np.diag([1.0, -1.0, 2.0, 1.0, 1.0]))      # first PSD block indefinite
+    assert ks.kktsolver_update_from_sz(s, pb.z0) is False                    # coneops_psdtrianglecone.jl:101-103
+
+
 def test_update_P_A_vs_fresh():
     _, HipKKTSolver, _ = _hip()
     pb = problems.config1(n=80, m=120, density=0.08)
@@ -220,3 +230,78 @@ def test_solve_with_lhs_nothing():
     x2, z2 = np.zeros(pb.n), np.zeros(pb.m)
     assert ks.kktsolver_solve(x2, z2)
     np.testing.assert_array_equal(z, z2)
+
+
+MULTI_CASES = [
+    ("cfg2_n2000", lambda: problems.config2(n=2000)),
+    ("cfg2_unstructured", lambda: problems.config_unstructured(n=800)),
+    ("mixed_with_psd", lambda: problems.small_mixed(seed=33)),
+    # fronts too tall for 8 columns of LDS per workgroup: exercises the narrower column blocks
+    ("unstructured_n3000", lambda: problems.config_unstructured(n=3000)),
+]
+
+
+@pytest.mark.parametrize("name,maker", MULTI_CASES, ids=[c[0] for c in MULTI_CASES])
+def test_solve_multi_matches_single_solves_and_oracle(name, maker):
+    """Boundary B, several right-hand sides per call: every column must end where its own
+    setrhs!/solve! pair ends (same refinement rule per column), and agree with the oracle."""
+    _, HipKKTSolver, _ = _hip()
+    pb = maker()
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    o = _oracle_for(pb, ks)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    rng = np.random.default_rng(11)
+    k = 7
+    RX, RZ = rng.standard_normal((pb.n, k)), rng.standard_normal((pb.m, k))
+    RX[:, 2] = 0.0; RZ[:, 2] = 0.0               # an all-zero column: solution 0, no refinement
+    RX[:, 5] *= 1e6; RZ[:, 5] *= 1e6             # a badly scaled one next to it
+    ok, LX, LZ, ir = ks.kktsolver_solve_multi(RX, RZ)
+    assert ok and LX.shape == (pb.n, k) and LZ.shape == (pb.m, k)
+    assert not LX[:, 2].any() and not LZ[:, 2].any() and ir[2] == 0
+    has_psd = any(isinstance(c, PSDTriangleConeT) for c in pb.cones)
+    for j in range(k):
+        ks.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        scale = max(np.abs(x).max(), np.abs(z).max(), 1e-300)
+        assert max(np.abs(LX[:, j] - x).max(), np.abs(LZ[:, j] - z).max()) / scale < 1e-12, j
+        assert abs(int(ir[j]) - ks.last_ir_iterations) <= 1, j     # different summation order: at most a borderline round
+        if j == 2:
+            continue
+        o.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        oko, xo, zo = o.kktsolver_solve()
+        assert oko
+        so = max(np.abs(xo).max(), np.abs(zo).max())
+        assert max(np.abs(LX[:, j] - xo).max(), np.abs(LZ[:, j] - zo).max()) / so < (1e-7 if has_psd else 1e-9), j
+    # lhs = nothing for one of the outputs, one column, and the empty call
+    ok, LX1, LZ1, ir1 = ks.kktsolver_solve_multi(RX[:, :1], RZ[:, :1], want_x=False)
+    assert ok and LX1 is None
+    assert np.abs(LZ1[:, 0] - LZ[:, 0]).max() / np.abs(LZ[:, 0]).max() < 1e-12
+    ok, _, _, ir0 = ks.kktsolver_solve_multi(np.zeros((pb.n, 0)), np.zeros((pb.m, 0)))
+    assert ok and ir0.size == 0
+
+
+def test_level_A_solve_multi_matches_column_solves():
+    _, _, HipDirectLDLSolver = _hip()
+    pb = problems.config2(n=1500)
+    from tests.oracle_bindings import make_oracle
+    o = make_oracle(pb)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    mp = o.maps()
+    Kv = o.K().copy()
+    Kv.data[mp["diag_full"]] += o.last_regularizer * o.dsigns()
+    ldl = HipDirectLDLSolver(Kv, o.dsigns())
+    assert ldl.refactor()
+    rng = np.random.default_rng(4)
+    B = np.asfortranarray(rng.standard_normal((ldl.N, 9)))
+    X = np.zeros_like(B, order="F")
+    ldl.solve_multi(None, X, B)
+    for j in range(B.shape[1]):
+        x = np.zeros(ldl.N)
+        ldl.solve(None, x, B[:, j].copy())
+        np.testing.assert_allclose(X[:, j], x, rtol=1e-12, atol=1e-13 * np.abs(x).max())
+    # against the un-permuted dense truth on a few columns
+    Kf = sp.csc_matrix(Kv) + sp.triu(sp.csc_matrix(Kv), 1).T
+    r = Kf @ X - B
+    assert np.abs(r).max() / np.abs(B).max() < 1e-6
