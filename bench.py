@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6       # MI355X_MICROARCH.md: dense FP64 matrix peak
 
 
 def algorithmic_bytes(info):
@@ -60,7 +61,7 @@ def cpu_baseline(pb, n_units):
     rhs = [(rng.standard_normal(pb.n), rng.standard_normal(pb.m)) for _ in range(3)]
     times = []
     ir = 0
-    for it in range(n_units + 1):
+    for it in range(n_units + 2):
         t0 = time.perf_counter()
         assert o.update_scaling(pb.s0, pb.z0)
         assert o.kktsolver_update()
@@ -70,10 +71,10 @@ def cpu_baseline(pb, n_units):
             assert ok
             ir += o.last_ir_iters
         times.append(time.perf_counter() - t0)
-    times = sorted(times[1:])
+    times = sorted(times[2:])
     med = times[len(times) // 2]
     return dict(value=1.0 / med, unit="KKT factorize+solve/s", cores=1, kind="port",
-                sample=f"{n_units} timed units (+1 warm-up) of the same workload, median; oracle/libkktoracle.so "
+                sample=f"{n_units} timed units (+2 warm-ups) of the same workload, median; oracle/libkktoracle.so "
                        f"(scalar up-looking LDL', AMD ordering, nnzL={o.nnzL}), host threads=1 of {os.cpu_count()}",
                 ms_per_unit=med * 1e3)
 
@@ -86,7 +87,7 @@ def main():
     ap.add_argument("--n", type=int, default=100_000, help="primal dimension of the SOCP (BASELINE: 100000)")
     ap.add_argument("--ordering", default="nd", choices=["nd", "amd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-units", type=int, default=4)
+    ap.add_argument("--cpu-units", type=int, default=10)
     args = ap.parse_args()
 
     import numpy as np
@@ -171,29 +172,41 @@ def main():
             gbs = byt / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             phases[name] = dict(total_ms=prof[ms_key], launches=prof[n_key], avg_ms=avg_ms,
                                 algorithmic_bytes=byt, achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
-        dominant = max(("factor", "trisolve"), key=lambda k: phases[k]["total_ms"])
-        d = phases[dominant]
         # flop-side view of the factorisation (dense Schur / panel work on v_mfma_f64_16x16x4_f64)
         phases["factor"]["flops"] = info["factor_flops"]
         phases["factor"]["achieved_TFLOPs"] = info["factor_flops"] / (phases["factor"]["avg_ms"] * 1e-3) / 1e12
-        phases["factor"]["frac_fp64_mfma_peak_78.6TF"] = phases["factor"]["achieved_TFLOPs"] / 78.6
-        # HBM traffic per launch of that phase from the committed PMC passes of this same command
+        phases["factor"]["frac_fp64_mfma_peak"] = phases["factor"]["achieved_TFLOPs"] / FP64_MFMA_PEAK_TF
+        # HBM traffic per launch of a phase from the committed PMC passes of this same command
         # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs: scripts/profile_bench.sh -> profiles/)
-        traffic, traffic_src = None, None
         import glob
         summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_summary.json")))
+        tsum, traffic_src = None, None
         if summaries and pb.n == 100_000:
             try:
-                ts = json.load(open(summaries[-1]))
-                key = "trisolve_hbm_MB_per_solve" if dominant == "trisolve" else "factor_hbm_MB_per_factorisation"
-                traffic = ts[key] * 1024.0 * 1024.0
+                tsum = json.load(open(summaries[-1]))
                 traffic_src = os.path.basename(summaries[-1])
             except Exception:
-                traffic = None
-        roofline = dict(kernel=dominant, bound="hbm", achieved=d["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=d["frac"], traffic=traffic, traffic_source=traffic_src,
-                        note="phase = all kernel launches of one %s; algorithmic bytes per SURVEY.md 8(d); "
-                             "traffic = FETCH_SIZE+WRITE_SIZE bytes per launch of the phase" % dominant)
+                tsum = None
+
+        def roofline_of(phase):
+            d = phases[phase]
+            traffic = None
+            if tsum is not None:
+                key = "trisolve_hbm_MB_per_solve" if phase == "trisolve" else "factor_hbm_MB_per_factorisation"
+                traffic = tsum[key] * 1024.0 * 1024.0
+            r = dict(kernel=phase, bound="hbm", achieved=d["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=d["frac"], traffic=traffic, traffic_source=traffic_src)
+            if phase == "factor" and d["frac_fp64_mfma_peak"] > d["frac"]:
+                # roofline.achieved(factor) = max(B_fact/t/8 TB/s, F_fact/t/78.6 TF)
+                r.update(bound="mfma", achieved=d["achieved_TFLOPs"], peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                         frac=d["frac_fp64_mfma_peak"])
+            r["note"] = ("phase = all kernel launches of one %s (a dependency chain over the elimination-tree levels, "
+                         "so latency- rather than roofline-bound); algorithmic bytes/flops per SURVEY.md 8(d); "
+                         "traffic = FETCH_SIZE+WRITE_SIZE bytes per launch of the phase" % phase)
+            return r
+
+        dominant = max(("factor", "trisolve"), key=lambda k: phases[k]["total_ms"])
+        roofline = roofline_of(dominant)
         out = {
             "metric": "KKT factorize+solve/sec (fp64) per IPM iter, 100k-var SOCP",
             "value": world * args.steps / elapsed,
@@ -212,6 +225,7 @@ def main():
                        "ir_rounds_per_step": prof["ir_iterations"] / max(args.steps, 1),
                        "setup_s": setup_s, "parallelism": "independent problems per GPU"},
             "roofline": roofline,
+            "roofline_trisolve": roofline_of("trisolve"),      # the north-star's named roofline target
             "phases": phases,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -70,6 +71,15 @@ struct Launch {
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
 
+// The persistent top-of-tree solve kernel needs all its workgroups resident.  Two such kernels running
+// at the same time on one device (two handles on different streams) could each hold part of the CUs while
+// waiting for workgroups that cannot be scheduled.  So per device only the handles that share ONE stream
+// (hence are serialised) may use it; a handle on another stream takes the launch-per-level path.
+// The kernel's bounded spins + abort word remain as the last line of defence (e.g. another process).
+struct TopOwner { hipStream_t stream = nullptr; int refs = 0; };
+static std::mutex g_top_mu;
+static std::map<int, TopOwner> g_top_owner;
+
 // ------------------------------------------------------------------------------------
 //  The numeric engine shared by both API levels
 // ------------------------------------------------------------------------------------
@@ -77,6 +87,7 @@ class LDLEngine {
 public:
     Symbolic S;
     hipStream_t stream = nullptr;
+    int device_id = 0;
     double dyn_eps, dyn_delta;
 
     LDLEngine(int N, const int64_t* colptr, const int64_t* rowval, int base, const std::vector<int>& dsigns,
@@ -123,12 +134,13 @@ public:
         HIP_CHECK(hipGraphLaunch(it->second, stream));
     }
 
-    // d_b, d_x in the caller's (original) ordering; may alias
-    void solve(const double* d_b, double* d_x)
+    // d_b, d_x in the caller's (original) ordering; may alias.  allow_top: the caller will synchronise and ask
+    // top_gave_up() afterwards (and repeat the solve if so); otherwise the launch-per-level path is used.
+    void solve(const double* d_b, double* d_x, bool allow_top = false)
     {
         static const bool no_graph = std::getenv("HIPKKT_GRAPH") == nullptr;
         if (no_graph || n_solve_calls++ == 0) {
-            enqueue_solve(d_b, d_x, stream);
+            enqueue_solve(d_b, d_x, stream, allow_top && claim_top());
             return;
         }
         auto key = std::make_pair((const void*)d_b, (const void*)d_x);
@@ -136,7 +148,7 @@ public:
         if (it == solve_graphs.end()) {
             ensure_capture_streams();
             HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-            enqueue_solve(d_b, d_x, cap_stream);
+            enqueue_solve(d_b, d_x, cap_stream, false);
             hipGraph_t g;
             HIP_CHECK(hipStreamEndCapture(cap_stream, &g));
             hipGraphExec_t ex;
@@ -185,6 +197,7 @@ public:
 
     ~LDLEngine()
     {
+        release_top();
         for (auto& kv : factor_graphs) (void)hipGraphExecDestroy(kv.second);
         for (auto& kv : solve_graphs) (void)hipGraphExecDestroy(kv.second);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
@@ -294,7 +307,7 @@ private:
         }
     }
 
-    void enqueue_solve(const double* d_b, double* d_x, hipStream_t st)
+    void enqueue_solve(const double* d_b, double* d_x, hipStream_t st, bool use_top)
     {
         SolveArgs a;
         a.T = tree();
@@ -308,7 +321,7 @@ private:
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         const size_t nl = launches.size();
-        const size_t ntl = no_top ? 0 : top_launches;            // the last ntl launches form the persistent top
+        const size_t ntl = (no_top || !use_top || top_disabled) ? 0 : top_launches;   // the last ntl launches form the persistent top
         for (size_t q = 0; q + ntl < nl; ++q) {
             const Launch& L = launches[q];
             launch_fwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, st);
@@ -324,17 +337,56 @@ private:
         HIP_CHECK(hipGetLastError());
     }
 
-    // synchronises; true if the persistent top kernel gave up on a flag (never expected)
-    bool top_aborted()
+    // ---- persistent-kernel bookkeeping
+    bool top_claimed = false, top_disabled = false;
+    hipStream_t claimed_stream = nullptr;
+
+    bool claim_top()
     {
-        if (!top_flags.p || top_launches == 0) return false;
+        if (top_disabled || top_launches == 0) return false;
+        if (top_claimed && claimed_stream == stream) return true;
+        release_top();
+        std::lock_guard<std::mutex> lk(g_top_mu);
+        TopOwner& o = g_top_owner[device_id];
+        if (o.refs == 0) o.stream = stream;
+        if (o.stream != stream) return false;
+        o.refs++;
+        top_claimed = true;
+        claimed_stream = stream;
+        return true;
+    }
+    void release_top()
+    {
+        if (!top_claimed) return;
+        std::lock_guard<std::mutex> lk(g_top_mu);
+        TopOwner& o = g_top_owner[device_id];
+        if (o.refs > 0 && o.stream == claimed_stream) o.refs--;
+        top_claimed = false;
+    }
+
+public:
+    // device word set by the persistent kernel when one of its bounded waits expired (nullptr: no such kernel)
+    const int* top_abort_word() const { return (top_flags.p && top_launches > 0) ? top_flags.p + 2 * top_count : nullptr; }
+    // The caller has synchronised and found the abort word set: clear it and never use the kernel again.
+    void top_gave_up()
+    {
+        top_disabled = true;
+        release_top();
+        HIP_CHECK(hipMemsetAsync(top_flags.p + 2 * top_count, 0, sizeof(int), stream));
+        std::fprintf(stderr, "[hipkkt] persistent top-of-tree kernel gave up waiting (GPU shared with another "
+                             "resident kernel?); falling back to one launch per level\n");
+    }
+    // synchronises; for callers without a read-back of their own
+    bool top_aborted_sync()
+    {
+        const int* w = top_abort_word();
+        if (!w) return false;
         int v = 0;
-        HIP_CHECK(hipMemcpyAsync(&v, top_flags.p + 2 * top_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(&v, w, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         return v != 0;
     }
 
-public:
     // synchronises: {#dynamic regularisations, non-finite flag}
     void read_flags(int out[2])
     {
@@ -953,6 +1005,7 @@ int hipkkt_ldl_create(hipkkt_ldl_t* out, int64_t N, const int64_t* colptr, const
         std::vector<int> ds((size_t)N);
         for (int64_t i = 0; i < N; ++i) ds[i] = dsigns[i] >= 0 ? 1 : -1;
         h->eng.reset(new LDLEngine((int)N, colptr, rowval, base, ds, h->st));
+        h->eng->device_id = h->device;
         h->eng->stream = h->stream;
         h->Kval.alloc((size_t)h->nnzK);
         HIP_CHECK(hipMemcpy(h->Kval.p, nzval, (size_t)h->nnzK * sizeof(double), hipMemcpyHostToDevice));
@@ -1040,7 +1093,11 @@ int hipkkt_ldl_solve(hipkkt_ldl_t h, double* x, const double* b)
         if (!h || !x || !b) throw ArgError("hipkkt_ldl_solve: bad argument");
         HIP_CHECK(hipSetDevice(h->device));
         HIP_CHECK(hipMemcpyAsync(h->b.p, b, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        h->eng->solve(h->b.p, h->x.p);
+        h->eng->solve(h->b.p, h->x.p, true);
+        if (h->eng->top_aborted_sync()) {                  // never expected; see TopOwner
+            h->eng->top_gave_up();
+            h->eng->solve(h->b.p, h->x.p, false);
+        }
         HIP_CHECK(hipMemcpyAsync(x, h->x.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return HIPKKT_OK;
@@ -1125,6 +1182,7 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
             st.user_perm = uperm.data();
         }
         h->eng.reset(new LDLEngine(K.N, K.colptr.data(), rv.data(), 0, K.dsigns, st));
+        h->eng->device_id = h->device;
         h->eng->stream = h->stream;
         h->st.user_perm = nullptr;
 
@@ -1391,25 +1449,28 @@ int hipkkt_kkt_setrhs(hipkkt_kkt_t h, const double* rx, const double* rz)
     });
 }
 
-// e = b - K xi, returns ||e||_inf via pinned read-back (slot 1), optionally ||b||_inf too (slot 2)
-static double kkt_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, double* normb)
+// e = b - K xi, returns ||e||_inf via pinned read-back (slot 1), optionally ||b||_inf too (slot 2);
+// slot 3 carries the persistent solve kernel's abort word along (*top_abort, nullable)
+static double kkt_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, double* normb, bool* top_abort)
 {
     SpmvDev A;
     A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.N = h->K.N; A.lanes_per_row = h->lanes_per_row;
     int pr = h->prof.begin(3, h->stream);
-    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + 1, h->stream);
+    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + 1, h->stream, 1, 0,
+                    h->eng->top_abort_word(), h->scal.p + 3);
     if (with_normb) launch_norm_inf(h->b.p, h->K.N, h->partial.p, h->scal.p + 2, h->stream);
     h->prof.end(pr, h->stream);
-    HIP_CHECK(hipMemcpyAsync(h->pin->h + 1, h->scal.p + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 1, h->scal.p + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (with_normb) *normb = h->pin->h[2];
+    if (top_abort) *top_abort = h->eng->top_abort_word() != nullptr && h->pin->h[3] != 0.0;
     return h->pin->h[1];
 }
 
-static void kkt_trisolve(hipkkt_kkt_t h, const double* rhs, double* out)
+static void kkt_trisolve(hipkkt_kkt_t h, const double* rhs, double* out, bool allow_top = true)
 {
     int ps = h->prof.begin(2, h->stream);
-    h->eng->solve(rhs, out);
+    h->eng->solve(rhs, out, allow_top);
     h->prof.end(ps, h->stream);
 }
 
@@ -1420,9 +1481,9 @@ static int kkt_solve_core(hipkkt_kkt_t h)
     const hipkkt_settings& st = h->st;
     double* x = h->cur_x;
     double* dx = h->cur_dx;
-    kkt_trisolve(h, h->b.p, x);
     h->last_ir = 0;
     if (!st.iterative_refinement_enable) {
+        kkt_trisolve(h, h->b.p, x, false);       // nothing reads the abort word back on this path
         int bad = 0;
         HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
         launch_check_finite(x, h->K.N, h->fail.p, h->stream);
@@ -1431,14 +1492,31 @@ static int kkt_solve_core(hipkkt_kkt_t h)
         return bad ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
     }
     double normb = 0.0;
-    double norme = kkt_refine_error(h, x, true, &normb);
+    bool gave_up = false;
+    kkt_trisolve(h, h->b.p, x);
+    double norme = kkt_refine_error(h, x, true, &normb, &gave_up);
+    if (gave_up) {                                               // never expected; see TopOwner
+        h->eng->top_gave_up();
+        kkt_trisolve(h, h->b.p, x);
+        norme = kkt_refine_error(h, x, true, &normb, nullptr);
+    }
     if (!std::isfinite(norme)) return HIPKKT_NUMERIC_FAILURE;
     for (int i = 0; i < st.iterative_refinement_max_iter; ++i) {
         if (norme <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb) break;
         const double lastnorme = norme;
-        kkt_trisolve(h, h->e.p, dx);                             // dx = K^{-1} e
-        launch_axpby_sum(dx, dx, x, h->K.N, h->stream);          // prospective solution x + dx
-        norme = kkt_refine_error(h, dx, false, nullptr);
+        // dx = K^{-1} e; prospective solution x + dx.  The residual overwrites e, so a repeat needs e back:
+        // only the (never expected) give-up path pays for the copy
+        kkt_trisolve(h, h->e.p, dx);
+        launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
+        norme = kkt_refine_error(h, dx, false, nullptr, &gave_up);
+        if (gave_up) {
+            // e was overwritten with the candidate's residual; rebuild e = b - K x and repeat the round
+            h->eng->top_gave_up();
+            (void)kkt_refine_error(h, x, false, nullptr, nullptr);
+            kkt_trisolve(h, h->e.p, dx);
+            launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
+            norme = kkt_refine_error(h, dx, false, nullptr, nullptr);
+        }
         h->last_ir++;
         h->prof.acc.ir_iterations++;
         if (!std::isfinite(norme)) return HIPKKT_NUMERIC_FAILURE;

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __res
     vmax = block_max_256(vmax, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = vmax;
 }
-__global__ void k_finish_norm(const double* __restrict__ partial, int nparts, double* __restrict__ out)
+__global__ void k_finish_norm(const double* __restrict__ partial, int nparts, double* __restrict__ out,
+                              const int* __restrict__ flag_in = nullptr, double* __restrict__ flag_out = nullptr)
 {
+    if (flag_out && blockIdx.x == 0 && threadIdx.x == 0) flag_out[0] = (flag_in && flag_in[0]) ? 1.0 : 0.0;
     __shared__ double sh[4];
     double v = 0.0;
     partial += blockIdx.x * nparts;
@@ -156,7 +158,8 @@ __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, do
     if (threadIdx.x == 0) out[0] = v;
 }
 void launch_residual(const SpmvDev& A, const double* K, const double* b, const double* x, double* e,
-                     double* partial, double* norm_out, hipStream_t st, int nrhs, int64_t ld)
+                     double* partial, double* norm_out, hipStream_t st, int nrhs, int64_t ld, const int* flag_in,
+                     double* flag_out)
 {
     int rows_per_block = 256 / A.lanes_per_row;
     int g = (A.N + rows_per_block - 1) / rows_per_block;
@@ -166,7 +169,7 @@ void launch_residual(const SpmvDev& A, const double* K, const double* b, const d
         hipLaunchKernelGGL(k_residual<8>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
     else
         hipLaunchKernelGGL(k_residual<64>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
-    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, norm_out);
+    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, norm_out, flag_in, flag_out);
 }
 __global__ void k_absmax(const double* __restrict__ v, int n, double* __restrict__ partial, int64_t ld)
 {
@@ -188,7 +191,7 @@ void launch_norm_inf(const double* v, int n, double* partial, double* out, hipSt
 {
     int g = grid_for(n, 256, kRedBlocks);
     hipLaunchKernelGGL(k_absmax, dim3(g, nrhs), dim3(256), 0, st, v, n, partial, ld);
-    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, out);
+    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, out, (const int*)nullptr, (double*)nullptr);
 }
 __global__ void k_sum2(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int64_t n)
 {

@@ -172,8 +172,11 @@ struct SpmvDev {
 // norm_out[j] = ||e_j||_inf (not finite if any entry is non-finite).  nrhs > 1: column j of b, x, e
 // at stride ld; `partial` then needs nrhs * kNormParts doubles
 constexpr int kNormParts = 2048;
+// flag_in/flag_out (nullable): *flag_out = (*flag_in != 0) as a double, so that a device status word rides along
+// with the norm read-back
 void launch_residual(const SpmvDev& A, const double* Kval, const double* b, const double* x, double* e,
-                     double* partial, double* norm_out, hipStream_t st, int nrhs = 1, int64_t ld = 0);
+                     double* partial, double* norm_out, hipStream_t st, int nrhs = 1, int64_t ld = 0,
+                     const int* flag_in = nullptr, double* flag_out = nullptr);
 void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st, int nrhs = 1,
                      int64_t ld = 0);
 void launch_axpby_sum(double* y, const double* a, const double* b, int64_t n, hipStream_t st);   // y = a + b

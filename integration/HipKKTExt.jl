@@ -198,6 +198,21 @@ function kktsolver_solve!(ks::HipKKTSolver{T}, lhsx::Union{Nothing,AbstractVecto
         (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), ks.handle, px, pz), "hipkkt_kkt_solve")
 end
 
+# Not part of the reference interface: nrhs right-hand sides against the current factorisation in one call
+# (columns of RHSX (n x k), RHSZ (m x k)); every column goes through the refinement rule of
+# kktsolver_directldl.jl:389-449 on its own.  Returns (is_success, refinement rounds per column).
+function kktsolver_solve_multi!(ks::HipKKTSolver{T}, RHSX::Matrix{T}, RHSZ::Matrix{T},
+                                LHSX::Union{Nothing,Matrix{T}}, LHSZ::Union{Nothing,Matrix{T}}) where {T}
+    k = size(RHSX, 2)
+    ir = zeros(Int64, max(k, 1))
+    px = LHSX === nothing ? Ptr{Cdouble}(C_NULL) : pointer(LHSX)
+    pz = LHSZ === nothing ? Ptr{Cdouble}(C_NULL) : pointer(LHSZ)
+    ok = GC.@preserve RHSX RHSZ LHSX LHSZ ir check(ccall((:hipkkt_kkt_solve_multi, libhipkkt), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int64}),
+        ks.handle, k, RHSX, RHSZ, px, pz, ir), "hipkkt_kkt_solve_multi")
+    return ok, ir[1:k]
+end
+
 kktsolver_update_P!(ks::HipKKTSolver{T}, P::SparseMatrixCSC{T}) where {T} =
     (GC.@preserve P check(ccall((:hipkkt_kkt_update_P, libhipkkt), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), ks.handle, P.nzval), "hipkkt_kkt_update_P"); nothing)
 kktsolver_update_A!(ks::HipKKTSolver{T}, A::SparseMatrixCSC{T}) where {T} =

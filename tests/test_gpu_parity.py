@@ -305,3 +305,41 @@ def test_level_A_solve_multi_matches_column_solves():
     Kf = sp.csc_matrix(Kv) + sp.triu(sp.csc_matrix(Kv), 1).T
     r = Kf @ X - B
     assert np.abs(r).max() / np.abs(B).max() < 1e-6
+
+
+def test_two_handles_on_their_own_streams_driven_concurrently():
+    """Several Solvers may coexist (threading): two handles, each on its own HIP stream and
+    host thread.  Only one of them may use the persistent top-of-tree kernel at a time; both must return
+    what a lone handle returns."""
+    import threading
+    _, HipKKTSolver, _ = _hip()
+    pbs = [problems.config2(n=4000, seed=77), problems.config2(n=4000, seed=78)]
+    rng = np.random.default_rng(9)
+    rhs = [(rng.standard_normal(pb.n), rng.standard_normal(pb.m)) for pb in pbs]
+
+    def run(ks, pb, r, reps, out):
+        for _ in range(reps):
+            assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+            ks.kktsolver_setrhs(*r)
+            x, z = np.zeros(pb.n), np.zeros(pb.m)
+            assert ks.kktsolver_solve(x, z)
+        out.append((x, z))
+
+    alone = []
+    for pb, r in zip(pbs, rhs):
+        ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+        out = []
+        run(ks, pb, r, 1, out)
+        alone.append(out[0])
+        del ks
+    sol = [HipKKTSolver(pb.P, pb.A, pb.cones) for pb in pbs]
+    outs = [[], []]
+    th = [threading.Thread(target=run, args=(sol[i], pbs[i], rhs[i], 6, outs[i])) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert len(outs[i]) == 1
+        for a, b in zip(outs[i][0], alone[i]):
+            assert np.abs(a - b).max() / np.abs(b).max() < 1e-12
