@@ -456,9 +456,13 @@ constexpr int LDA = TS + 16;    // k-rows 80 doubles apart: consecutive k land 3
 // D: col = lane&15, row = (lane>>4) + 4*reg.
 __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin)
 {
-    __shared__ double As[KC][LDA];        // As[k][r] = L21(r0 + r, k0 + k)
-    __shared__ double Bs[KC][LDA];        // Bs[k][c] = L21(q0 + c, k0 + k) * d_k
-    __shared__ double Ct[TS][TS + 1];     // the tile, [col][row]
+    // the operand chunks are dead once the product is done: the tile buffer shares their LDS (33 KB per
+    // workgroup instead of 53 KB -> one more workgroup per CU)
+    __shared__ __attribute__((aligned(16))) double smem_s[TS * (TS + 1)];
+    double (*As)[LDA] = reinterpret_cast<double (*)[LDA]>(smem_s);                 // As[k][r] = L21(r0 + r, k0 + k)
+    double (*Bs)[LDA] = reinterpret_cast<double (*)[LDA]>(smem_s + KC * LDA);      // Bs[k][c] = L21(q0 + c, k0 + k) * d_k
+    double (*Ct)[TS + 1] = reinterpret_cast<double (*)[TS + 1]>(smem_s);           // the tile, [col][row]
+    static_assert(2 * KC * LDA <= TS * (TS + 1), "operand chunks must fit under the tile buffer");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TreeDev& T = A.T;
@@ -483,6 +487,16 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     const int ml = lane & 15, mk = lane >> 4;
+    // the pass-through work list is static data: fetch this wave's range and its first eight descriptors now,
+    // so that after the product only the (rel, value) loads remain on the critical path
+    const int64_t* __restrict__ tc = T.tile_cut + 5 * (int64_t)(tile_begin + blockIdx.x);
+    const int64_t i0 = tc[wv], i1 = tc[wv + 1];
+    SubItem it[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        it[z] = T.sitems[max(min(i0 + z, i1 - 1), (int64_t)0)];
+        if (i0 + z >= i1) it[z].cnt = 0;
+    }
 
     for (int k0 = 0; k0 < nc; k0 += KC) {
         const int kw = min(KC, nc - k0);
@@ -493,7 +507,11 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 av[q] = (k < kw && rr + q < nr) ? F[(nc + r0 + rr + q) + (int64_t)(k0 + k) * f] : 0.0;
-                bv[q] = (k < kw && rr + q < nq) ? F[(nc + q0 + rr + q) + (int64_t)(k0 + k) * f] : 0.0;
+                bv[q] = (ti != tj && k < kw && rr + q < nq) ? F[(nc + q0 + rr + q) + (int64_t)(k0 + k) * f] : 0.0;
+            }
+            if (ti == tj) {                                  // diagonal tile: both strips are the same rows
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q] = av[q];
             }
             __syncthreads();           // previous chunk fully consumed
 #pragma unroll
@@ -519,6 +537,8 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
             }
         }
     }
+    __syncthreads();               // every wave is done reading the last operand chunk (Ct overlays it)
+    // quadrants that took no part hold zeros in acc: the whole tile buffer gets defined here
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -530,17 +550,16 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
     // children pass-through: this wave's slice of the tile's sub-items (whole columns, child order),
     // eight in flight: one round of descriptor loads, one round of (rel, value) loads, then LDS adds
     {
-        const int64_t* __restrict__ tc = T.tile_cut + 5 * (int64_t)(tile_begin + blockIdx.x);
-        const int64_t i0 = tc[wv], i1 = tc[wv + 1];
         const int rlo = nc + r0;
         for (int64_t ii = i0; ii < i1; ii += 8) {
-            SubItem it[8];
             double v[8];
             int tg[8];
+            if (ii > i0) {
 #pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                it[z] = T.sitems[min(ii + z, i1 - 1)];
-                if (ii + z >= i1) it[z].cnt = 0;
+                for (int z = 0; z < 8; ++z) {
+                    it[z] = T.sitems[min(ii + z, i1 - 1)];
+                    if (ii + z >= i1) it[z].cnt = 0;
+                }
             }
 #pragma unroll
             for (int z = 0; z < 8; ++z) {
