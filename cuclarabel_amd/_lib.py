@@ -90,6 +90,12 @@ SYMBOLS = {
     "hipkkt_kkt_solve_dev": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_solve_multi": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "hipkkt_kkt_solve_multi_dev": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "hipkkt_kkt_system_init": (C.c_int, [_P, _P, _P]),
+    "hipkkt_kkt_system_update": (C.c_int, [_P, _P, _P]),
+    "hipkkt_kkt_system_solve_constant_rhs": (C.c_int, [_P]),
+    "hipkkt_kkt_system_solve_initial_point": (C.c_int, [_P, _P, _P, _P]),
+    "hipkkt_kkt_system_solve": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
+                                          _P, _P, _P, C.c_double, C.c_double, C.c_int]),
     "hipkkt_kkt_mul_Hs": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_get_pattern": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_get_values": (C.c_int, [_P, _P]),

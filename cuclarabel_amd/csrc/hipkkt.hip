@@ -885,6 +885,11 @@ struct hipkkt_kkt_s {
     bool has_psd = false, psd_too_big = false, scaling_valid = false;
     double last_eps = 0;
     int64_t last_ir = 0;
+    // level C (DefaultKKTSystem on the device, kktsystem.jl:21-215)
+    DBuf<double> lam;                                        // scaled point, m
+    DBuf<double> sq, snegq, sb, sx1, sz1, sx2, sz2, sworkx, sworkz, sconic, spa, spb;
+    DBuf<double> sys_partial, sys_dots, sys_cached, sys_in, sys_out;
+    bool sys_ready = false;
     // solve_multi work space, N x mcap each (grown on demand)
     DBuf<double> mB, mX, mC, mE, mE2, mpartial, mnorms;
     DBuf<int> mmask;
@@ -906,6 +911,7 @@ struct hipkkt_kkt_s {
         ConeState S;
         S.w = w.p; S.eta = eta.p; S.u = soc_u.p; S.v = soc_v.p; S.eta2 = soc_eta2.p; S.Hs = Hs.p; S.fail = fail.p;
         S.psdA = psdA.p;
+        S.lam = lam.p;
         return S;
     }
 };
@@ -1285,7 +1291,7 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
             h->c_kind.upload(kind); h->c_off.upload(off); h->c_numel.upload(numel); h->c_boff.upload(boff);
             h->c_sidx.upload(sidx); h->c_soff.upload(soff); h->c_elem.upload(elem); h->c_soclist.upload(soclist);
             h->soc_of_entry.upload(soc_of);
-            h->w.alloc((size_t)K.m); h->eta.alloc(nc);
+            h->w.alloc((size_t)K.m); h->eta.alloc(nc); h->lam.alloc((size_t)K.m);
             h->soc_u.alloc((size_t)K.sparse_len); h->soc_v.alloc((size_t)K.sparse_len);
             h->soc_eta2.alloc((size_t)K.nsparse); h->Hs.alloc((size_t)K.nHs);
             h->fail.alloc(1);
@@ -1701,6 +1707,159 @@ int hipkkt_kkt_solve_multi(hipkkt_kkt_t h, int64_t nrhs, const double* rhsx, con
         if (rc != HIPKKT_OK) return rc;
         kkt_multi_unpack(h, (int)nrhs, lhsx, lhsz, hipMemcpyDeviceToHost);
         HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Level C: the reduced-system layer (DefaultKKTSystem, /root/reference/src/kktsystem.jl:21-215) with every
+//  vector resident in HBM -- right-hand-side construction and the recovery of (dtau, dx, dz, ds, dkappa)
+//  around the solves run on the device, so nothing but two scalars per solve crosses PCIe.
+// ------------------------------------------------------------------------------------------------
+static SpmvDev sys_spmv(hipkkt_kkt_t h)
+{
+    SpmvDev A;
+    A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.N = h->K.N; A.lanes_per_row = h->lanes_per_row;
+    return A;
+}
+
+int hipkkt_kkt_system_init(hipkkt_kkt_t h, const double* q, const double* b)
+{
+    return guarded([&]() {
+        if (!h || (h->K.n && !q) || (h->K.m && !b)) throw ArgError("hipkkt_kkt_system_init: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        const size_t n = (size_t)h->K.n, m = (size_t)h->K.m;
+        h->sq.alloc(n); h->snegq.alloc(n); h->sb.alloc(m);
+        h->sx1.alloc(n); h->sx2.alloc(n); h->sworkx.alloc(n); h->spa.alloc(n); h->spb.alloc(n);
+        h->sz1.alloc(m); h->sz2.alloc(m); h->sworkz.alloc(m); h->sconic.alloc(m);
+        h->sys_partial.alloc(8 * 64); h->sys_dots.alloc(8); h->sys_cached.alloc(4); h->sys_in.alloc(4); h->sys_out.alloc(4);
+        if (n) HIP_CHECK(hipMemcpyAsync(h->sq.p, q, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(h->sb.p, b, m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_neg_copy(h->snegq.p, h->sq.p, (int)n, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->sys_ready = true;
+        return HIPKKT_OK;
+    });
+}
+
+// setrhs! + solve! with device vectors; either output may be null
+static int sys_solve_into(hipkkt_kkt_t h, const double* rx, const double* rz, double* outx, double* outz)
+{
+    launch_pack_rhs(h->b.p, rx, rz, h->K.n, h->K.m, h->K.p, h->stream);
+    int rc = kkt_solve_core(h);
+    if (rc != HIPKKT_OK) return rc;
+    if (outx && h->K.n)
+        HIP_CHECK(hipMemcpyAsync(outx, h->cur_x, (size_t)h->K.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (outz && h->K.m)
+        HIP_CHECK(hipMemcpyAsync(outz, h->cur_x + h->K.n, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return HIPKKT_OK;
+}
+
+static int sys_constant_rhs(hipkkt_kkt_t h)
+{
+    // _kkt_solve_constant_rhs! (kktsystem.jl:80-92): (x2, z2) = K \ (-q, b)
+    int rc = sys_solve_into(h, h->snegq.p, h->sb.p, h->sx2.p, h->sz2.p);
+    if (rc != HIPKKT_OK) return rc;
+    // the x2-only terms of tau_den (kktsystem.jl:194-196) are the same for both solves of the iteration
+    launch_P_spmv(sys_spmv(h), h->Kval.p, h->sx2.p, h->spa.p, h->K.n, h->stream);
+    DotPairs P{};
+    P.npairs = 3;
+    P.a[0] = h->sq.p; P.b[0] = h->sx2.p; P.len[0] = h->K.n;
+    P.a[1] = h->sb.p; P.b[1] = h->sz2.p; P.len[1] = h->K.m;
+    P.a[2] = h->sx2.p; P.b[2] = h->spa.p; P.len[2] = h->K.n;
+    launch_dots(P, h->sys_partial.p, h->sys_cached.p, h->stream);
+    return HIPKKT_OK;
+}
+
+int hipkkt_kkt_system_solve_constant_rhs(hipkkt_kkt_t h)
+{
+    return guarded([&]() {
+        if (!h || !h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
+        HIP_CHECK(hipSetDevice(h->device));
+        return sys_constant_rhs(h);
+    });
+}
+
+int hipkkt_kkt_system_update(hipkkt_kkt_t h, const double* d_s, const double* d_z)
+{
+    // kkt_update! (kktsystem.jl:62-78)
+    int rc = hipkkt_kkt_update_from_sz_dev(h, d_s, d_z);
+    if (rc != HIPKKT_OK) return rc;
+    return hipkkt_kkt_system_solve_constant_rhs(h);
+}
+
+int hipkkt_kkt_system_solve_initial_point(hipkkt_kkt_t h, double* d_x, double* d_s, double* d_z)
+{
+    return guarded([&]() {
+        if (!h || !h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
+        if ((h->K.n && !d_x) || (h->K.m && (!d_s || !d_z))) throw ArgError("hipkkt_kkt_system_solve_initial_point: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        const int n = h->K.n, m = h->K.m;
+        int rc;
+        if (h->mapP.n == 0) {
+            // LP initialisation (kktsystem.jl:107-128): [0; b] -> (x, -s), then [-q; 0] -> z
+            if (n) HIP_CHECK(hipMemsetAsync(h->sworkx.p, 0, (size_t)n * sizeof(double), h->stream));
+            rc = sys_solve_into(h, h->sworkx.p, h->sb.p, d_x, h->sworkz.p);
+            if (rc != HIPKKT_OK) return rc;
+            launch_neg_copy(d_s, h->sworkz.p, m, h->stream);
+            if (m) HIP_CHECK(hipMemsetAsync(h->sworkz.p, 0, (size_t)m * sizeof(double), h->stream));
+            rc = sys_solve_into(h, h->snegq.p, h->sworkz.p, nullptr, d_z);
+            if (rc != HIPKKT_OK) return rc;
+        } else {
+            // QP initialisation (:129-137): [-q; b] -> (x, z), s = -z
+            rc = sys_solve_into(h, h->snegq.p, h->sb.p, d_x, d_z);
+            if (rc != HIPKKT_OK) return rc;
+            launch_neg_copy(d_s, d_z, m, h->stream);
+        }
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,
+                            const double* d_rhs_x, const double* d_rhs_s, const double* d_rhs_z, double rhs_tau,
+                            double rhs_kappa, const double* d_var_x, const double* d_var_s, const double* d_var_z,
+                            double var_tau, double var_kappa, int steptype)
+{
+    return guarded([&]() {
+        if (!h || !h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
+        const int n = h->K.n, m = h->K.m;
+        if ((n && (!d_lhs_x || !d_rhs_x || !d_var_x)) || (m && (!d_lhs_s || !d_lhs_z || !d_rhs_s || !d_rhs_z || !d_var_s || !d_var_z)) ||
+            !lhs_tau_kappa || (steptype != 0 && steptype != 1))
+            throw ArgError("hipkkt_kkt_system_solve: bad argument");
+        if (!h->scaling_valid) throw ArgError("hipkkt_kkt_system_solve: needs the cone scaling of hipkkt_kkt_system_update");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        // Delta_s constant term and the z part of the right-hand side (kktsystem.jl:150-166)
+        const bool affine = steptype == 0;
+        if (!launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, affine ? d_var_s : d_rhs_s,
+                               d_var_z, d_rhs_z, m, affine, st))
+            throw ArgError("hipkkt_kkt_system_solve: the combined step covers zero, nonnegative and second-order cones");
+        // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
+        int rc = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
+        if (rc != HIPKKT_OK) return rc;
+        // dtau (:176-199)
+        const double sc_in[4] = {rhs_tau, rhs_kappa, var_tau, var_kappa};
+        HIP_CHECK(hipMemcpyAsync(h->sys_in.p, sc_in, sizeof(sc_in), hipMemcpyHostToDevice, st));
+        launch_P_spmv(sys_spmv(h), h->Kval.p, h->sx1.p, h->spa.p, n, st);                          // P x1
+        launch_sys_axpby(h->sworkx.p, d_var_x, h->sys_in.p + 2, h->sx2.p, nullptr, -1.0, n, st);   // xi - x2
+        launch_P_spmv(sys_spmv(h), h->Kval.p, h->sworkx.p, h->spb.p, n, st);                       // P (xi - x2)
+        DotPairs P{};
+        P.npairs = 4;
+        P.a[0] = h->sq.p; P.b[0] = h->sx1.p; P.len[0] = n;
+        P.a[1] = h->sb.p; P.b[1] = h->sz1.p; P.len[1] = m;
+        P.a[2] = d_var_x; P.b[2] = h->spa.p; P.len[2] = n;
+        P.a[3] = h->sworkx.p; P.b[3] = h->spb.p; P.len[3] = n;
+        launch_dots(P, h->sys_partial.p, h->sys_dots.p, st);
+        launch_sys_scalars(h->sys_dots.p, h->sys_cached.p, h->sys_in.p, h->sys_out.p, st);
+        // (dx, dz) = (x1, z1) + dtau (x2, z2)                                 (:200-203)
+        launch_sys_axpby(d_lhs_x, h->sx1.p, nullptr, h->sx2.p, h->sys_out.p, 0.0, n, st);
+        launch_sys_axpby(d_lhs_z, h->sz1.p, nullptr, h->sz2.p, h->sys_out.p, 0.0, m, st);
+        // ds = -(Hs dz + const)                                               (:206-212)
+        launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st);
+        launch_neg_sum(d_lhs_s, d_lhs_s, h->sconic.p, m, st);
+        HIP_CHECK(hipMemcpyAsync(lhs_tau_kappa, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));            // also keeps sc_in alive for its copy
         return HIPKKT_OK;
     });
 }

@@ -262,10 +262,12 @@ __global__ void k_cone_elementwise(ConeDev C, ConeState S, const double* __restr
         const int kind = C.kind[c];
         if (kind == 0) {
             S.w[i] = 0.0;
+            if (S.lam) S.lam[i] = 0.0;
             S.Hs[C.boff[c] + (i - C.off[c])] = 0.0;
         } else if (kind == 1) {
             const double w = sqrt(s[i] / z[i]);
             S.w[i] = w;
+            if (S.lam) S.lam[i] = sqrt(s[i] * z[i]);
             S.Hs[C.boff[c] + (i - C.off[c])] = w * w;
         }
     }
@@ -320,6 +322,16 @@ __global__ __launch_bounds__(64) void k_cone_soc(ConeDev C, ConeState S, const d
     w1sqn = wave_sum(w1sqn);
     const double w0n = sqrt(1.0 + w1sqn);
     if (lane == 0) { w[0] = w0n; S.eta[c] = eta; }
+    if (S.lam) {
+        // scaling point lambda = W z = W^{-T} s (coneops_socone.jl:113-123)
+        double* lam = S.lam + off;
+        const double gamma = 0.5 * wscale;
+        const double a = (gamma + z0 / zscale) / sscale, b = (gamma + s0 / sscale) / zscale;
+        const double inv = 1.0 / (s0 / sscale + z0 / zscale + 2.0 * gamma);
+        const double sz = sqrt(sscale * zscale);
+        for (int i = 1 + lane; i < n; i += 64) lam[i] = (a * sc[i] + b * zc[i]) * inv * sz;
+        if (lane == 0) lam[0] = gamma * sz;
+    }
     __syncthreads();      // w[] written above is re-read below by other lanes of this wave
     const double eta2 = eta * eta;
     double* Hs = S.Hs + C.boff[c];
@@ -601,6 +613,197 @@ void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double
         const size_t lds = (size_t)3 * C.psd_kmax * C.psd_kmax * sizeof(double);
         hipLaunchKernelGGL(k_mul_Hs_psd, dim3(C.npsd), dim3(256), lds, st, C, S, y, x);
     }
+}
+
+}  // namespace hipkkt
+
+
+// =====================================================================================
+//  Reduced-system algebra of kkt_solve! on the device (kktsystem.jl:135-215)
+// =====================================================================================
+namespace hipkkt {
+
+__global__ void k_sys_offset_elementwise(ConeDev C, ConeState S, double* __restrict__ konst, double* __restrict__ workz,
+                                         const double* __restrict__ ds, const double* __restrict__ z,
+                                         const double* __restrict__ rhs_z, int m, int affine)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        double o;
+        if (affine) {
+            o = ds[i];                                  // Delta_s_const_term = variables.s (kktsystem.jl:157-158)
+        } else {
+            const int kind = C.kind[C.elem_cone[i]];
+            if (kind == 0) o = 0.0;                     // coneops_zerocone.jl:137-150
+            else if (kind == 1) o = ds[i] / z[i];       // coneops_nncone.jl:140-148
+            else continue;                              // second-order cones: k_sys_offset_soc
+        }
+        konst[i] = o;
+        workz[i] = o - rhs_z[i];
+    }
+}
+
+// out = W'(lambda \ ds) in the reference's more stable form (coneops_socone.jl:241-268); one wave per cone
+__global__ __launch_bounds__(64) void k_sys_offset_soc(ConeDev C, ConeState S, double* __restrict__ konst,
+                                                       double* __restrict__ workz, const double* __restrict__ ds,
+                                                       const double* __restrict__ z, const double* __restrict__ rhs_z)
+{
+    const int c = C.soc_list[blockIdx.x];
+    const int off = C.off[c], n = C.numel[c];
+    const int lane = threadIdx.x;
+    const double* dsc = ds + off;
+    const double* zc = z + off;
+    const double* w = S.w + off;
+    const double* lam = S.lam + off;
+    double zz = 0.0, l1d1 = 0.0, w1d1 = 0.0;
+    for (int i = 1 + lane; i < n; i += 64) {
+        zz += zc[i] * zc[i];
+        l1d1 += lam[i] * dsc[i];
+        w1d1 += w[i] * dsc[i];
+    }
+    zz = sqrt(wave_sum(zz));
+    l1d1 = wave_sum(l1d1);
+    w1d1 = wave_sum(w1d1);
+    const double z0 = zc[0];
+    const double resz = (z0 - zz) * (z0 + zz);
+    const double eta = S.eta[c];
+    const double cc = (lam[0] * dsc[0] - l1d1) / resz;
+    const double linv = 1.0 / lam[0];
+    const double wfac = w1d1 / (1.0 + w[0]);
+    for (int i = lane; i < n; i += 64) {
+        double o;
+        if (i == 0) o = z0 * cc + eta * w1d1;
+        else o = -zc[i] * cc + eta * (dsc[i] + wfac * w[i]);
+        o *= linv;
+        konst[off + i] = o;
+        workz[off + i] = o - rhs_z[off + i];
+    }
+}
+
+bool launch_sys_offset(const ConeDev& C, const ConeState& S, double* konst, double* workz, const double* ds,
+                       const double* z, const double* rhs_z, int m, bool affine, hipStream_t st)
+{
+    if (m <= 0) return true;
+    if (!affine && C.npsd > 0) return false;
+    hipLaunchKernelGGL(k_sys_offset_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, konst, workz, ds, z,
+                       rhs_z, m, affine ? 1 : 0);
+    if (!affine && C.nsoc > 0)
+        hipLaunchKernelGGL(k_sys_offset_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, konst, workz, ds, z, rhs_z);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_P_spmv(SpmvDev A, const double* __restrict__ K, const double* __restrict__ x,
+                                                double* __restrict__ y, int n)
+{
+    const int sub = threadIdx.x & 7;
+    for (int row = blockIdx.x * 32 + (threadIdx.x >> 3); row < n; row += gridDim.x * 32) {
+        double acc = 0.0;
+        for (int64_t q = A.ptr[row] + sub; q < A.ptr[row + 1]; q += 8) {
+            const int c = A.col[q];
+            if (c < n) acc = fma(K[A.vmap[q]], x[c], acc);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) acc += __shfl_down(acc, o, 8);
+        if (sub == 0) y[row] = acc;
+    }
+}
+void launch_P_spmv(const SpmvDev& A, const double* Kval, const double* x, double* y, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    int g = (n + 31) / 32;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_P_spmv, dim3(g), dim3(256), 0, st, A, Kval, x, y, n);
+}
+
+__global__ void k_sys_axpby(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ alpha,
+                            const double* __restrict__ b, const double* __restrict__ beta, double beta_host, int n)
+{
+    const double be = beta ? beta[0] : beta_host;
+    if (alpha) {
+        const double al = alpha[0];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+            out[i] = a[i] / al + be * b[i];
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+            out[i] = a[i] + be * b[i];
+    }
+}
+void launch_sys_axpby(double* out, const double* a, const double* alpha_div, const double* b, const double* beta,
+                      double beta_host, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_sys_axpby, dim3(grid_for(n, 256)), dim3(256), 0, st, out, a, alpha_div, b, beta, beta_host, n);
+}
+
+constexpr int kDotBlocks = 64;
+__global__ __launch_bounds__(256) void k_dots(DotPairs P, double* __restrict__ partial)
+{
+    __shared__ double sh[256];
+    const int p = blockIdx.y;
+    const double* __restrict__ a = P.a[p];
+    const double* __restrict__ b = P.b[p];
+    const int n = P.len[p];
+    double acc = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += kDotBlocks * 256) acc = fma(a[i], b[i], acc);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[p * kDotBlocks + blockIdx.x] = sh[0];
+}
+__global__ void k_dots_finish(const double* __restrict__ partial, double* __restrict__ out, int npairs)
+{
+    const int p = threadIdx.x;
+    if (p >= npairs) return;
+    double acc = 0.0;
+    for (int i = 0; i < kDotBlocks; ++i) acc += partial[p * kDotBlocks + i];
+    out[p] = acc;
+}
+void launch_dots(const DotPairs& P, double* partial, double* out, hipStream_t st)
+{
+    if (P.npairs <= 0) return;
+    hipLaunchKernelGGL(k_dots, dim3(kDotBlocks, P.npairs), dim3(256), 0, st, P, partial);
+    hipLaunchKernelGGL(k_dots_finish, dim3(1), dim3(64), 0, st, partial, out, P.npairs);
+}
+
+__global__ void k_sys_scalars(const double* __restrict__ dots, const double* __restrict__ cached,
+                              const double* __restrict__ in, double* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double rhs_tau = in[0], rhs_kappa = in[1], tau = in[2], kappa = in[3];
+    // kktsystem.jl:185-196; xi = x / tau, so xi.(P x1) = dots[2] / tau
+    const double tau_num = rhs_tau - rhs_kappa / tau + dots[0] + dots[1] + 2.0 * (dots[2] / tau);
+    double tau_den = kappa / tau - cached[0] - cached[1];
+    tau_den += dots[3] - cached[2];
+    const double dtau = tau_num / tau_den;
+    out[0] = dtau;
+    out[1] = -(rhs_kappa + kappa * dtau) / tau;          // :206
+    out[2] = tau_num;
+    out[3] = tau_den;
+}
+void launch_sys_scalars(const double* dots, const double* cached, const double* scal_in, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sys_scalars, dim3(1), dim3(64), 0, st, dots, cached, scal_in, out);
+}
+
+__global__ void k_neg_sum(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = -(a[i] + b[i]);
+}
+void launch_neg_sum(double* y, const double* a, const double* b, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_neg_sum, dim3(grid_for(n, 256)), dim3(256), 0, st, y, a, b, n);
+}
+__global__ void k_neg_copy(double* __restrict__ y, const double* __restrict__ a, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = -a[i];
+}
+void launch_neg_copy(double* y, const double* a, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_neg_copy, dim3(grid_for(n, 256)), dim3(256), 0, st, y, a, n);
 }
 
 }  // namespace hipkkt

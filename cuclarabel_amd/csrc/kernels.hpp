@@ -211,6 +211,7 @@ struct ConeDev {
 };
 struct ConeState {
     double* w;                   // m: NN: sqrt(s/z); SOC: normalised w
+    double* lam;                 // m: scaled point lambda = W z (NN: sqrt(s z); SOC: coneops_socone.jl:113-123); may be null
     double* eta;                 // per cone (SOC)
     double* u;                   // sparse_len
     double* v;                   // sparse_len
@@ -223,5 +224,26 @@ constexpr int kPsdMaxDim = 48;   // largest PSD side handled by the in-LDS scali
 void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, const double* z, int m,
                          hipStream_t st);
 void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st);
+
+// ---- the reduced-system algebra around the three solves of an IPM iteration (kktsystem.jl:135-215), device-resident
+// konst = Delta_s_from_Delta_z_offset!(cones, ds, z) (coneops_compositecone.jl:185-202; zero :137-150, nonnegative
+// coneops_nncone.jl:140-148, second-order coneops_socone.jl:241-268), or a copy of s for the affine step;
+// workz = konst - rhs_z.  Returns false if the cone list holds a cone kind this routine does not cover (PSD).
+bool launch_sys_offset(const ConeDev& C, const ConeState& S, double* konst, double* workz, const double* ds,
+                       const double* z, const double* rhs_z, int m, bool affine, hipStream_t st);
+// y = Symmetric(P) x for the leading n x n block of K (rows / columns < n of the full-CSR image)
+void launch_P_spmv(const SpmvDev& A, const double* Kval, const double* x, double* y, int n, hipStream_t st);
+// out = a / (*alpha_div) + beta * b  (alpha_div null: a as is; beta from the device scalar if given, else beta_host):
+// xi - x2 with xi = x / tau, and x1 + dtau x2
+void launch_sys_axpby(double* out, const double* a, const double* alpha_div, const double* b, const double* beta,
+                      double beta_host, int n, hipStream_t st);
+struct DotPairs { const double* a[8]; const double* b[8]; int len[8]; int npairs; };
+// out[p] = sum_i a_p[i] b_p[i], p < npairs (two-stage, fixed order); partial needs 8 * 64 doubles
+void launch_dots(const DotPairs& P, double* partial, double* out, hipStream_t st);
+// the scalars of kkt_solve! (kktsystem.jl:176-206): dots = {q.x1, b.z1, x.(P x1), xm.(P xm)}, cached = {q.x2, b.z2, x2.(P x2)}
+// scal_in = {rhs_tau, rhs_kappa, var_tau, var_kappa}; out = {dtau, dkappa, tau_num, tau_den}
+void launch_sys_scalars(const double* dots, const double* cached, const double* scal_in, double* out, hipStream_t st);
+void launch_neg_sum(double* y, const double* a, const double* b, int n, hipStream_t st);      // y = -(a + b)
+void launch_neg_copy(double* y, const double* a, int n, hipStream_t st);                    // y = -a
 
 }  // namespace hipkkt

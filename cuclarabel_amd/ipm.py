@@ -343,9 +343,20 @@ def solve(P, q, A, b, cone_specs, backend, settings=None):
 
     # ---- default start (symmetric cones): solver.jl:383-404
     x = np.zeros(n); s = np.zeros(m); z = np.zeros(m)
+    system = getattr(backend, "system", None)          # device-resident DefaultKKTSystem (level C), if the backend has one
+    if system is not None:
+        system.init(q, b)
     ok = backend.update_identity()
-    ok_c, x2, z2 = ksolve(-q, b)                       # kkt_update! also solves the constant RHS
-    if Pt.nnz == 0:                                    # kktsystem.jl:101-120 (LP initialisation)
+    if system is not None:
+        ok_c = system.solve_constant_rhs()
+        ok1, x, s, z = system.solve_initial_point()
+        ok2 = True
+        x2 = z2 = None
+    else:
+        ok_c, x2, z2 = ksolve(-q, b)                   # kkt_update! also solves the constant RHS
+    if system is not None:
+        pass
+    elif Pt.nnz == 0:                                  # kktsystem.jl:101-120 (LP initialisation)
         ok1, x, s = ksolve(np.zeros(n), b)
         s = -s
         ok2, _, z = ksolve(-q, np.zeros(m), want_x=False)
@@ -432,11 +443,19 @@ def solve(P, q, A, b, cone_specs, backend, settings=None):
             status = NUMERICAL_ERROR
             break
         it += 1
-        ok = backend.update(s, z)
-        if ok:
-            ok, x2, z2 = ksolve(-q, b)
+        if system is not None:
+            ok = system.update(s, z)                   # kkt_update!: scaling, refactor, constant-RHS solve
+        else:
+            ok = backend.update(s, z)
+            if ok:
+                ok, x2, z2 = ksolve(-q, b)
 
         def kkt_solve(rhs_x, rhs_z, rhs_s, rhs_tau, rhs_kappa, affine, lhs_z_work=None):   # kktsystem.jl:135-215
+            nonlocal ir_total
+            if system is not None:
+                okk, out = system.solve(rhs_x, rhs_s, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa, affine)
+                ir_total += backend.last_ir_iterations
+                return okk, out
             if affine:
                 const = s.copy()
             else:
@@ -547,3 +566,13 @@ class HipBackend:
     @property
     def last_ir_iterations(self):
         return self.ks.last_ir_iterations
+
+
+class HipSystemBackend(HipBackend):
+    """As HipBackend, but the reduced-system layer (kktsystem.jl) runs on the device too (level C of the
+    C ABI): the driver hands over iterates and right-hand sides and gets the step back."""
+
+    def __init__(self, P, A, cone_specs, settings=None):
+        super().__init__(P, A, cone_specs, settings=settings)
+        from .kktsolver import HipKKTSystem
+        self.system = HipKKTSystem(self.ks)

@@ -217,6 +217,85 @@ class HipKKTSolver:
         return p.as_dict()
 
 
+class HipKKTSystem:
+    """DefaultKKTSystem (`/root/reference/src/kktsystem.jl:21-215`) with its vectors in HBM (level C of
+    the C ABI): `kkt_update!`, `kkt_solve_initial_point!`, `kkt_solve!`.  The `*_dev` methods take raw
+    device pointers; the numpy-facing ones stage through torch tensors (plumbing for tests and the IPM
+    test driver)."""
+
+    def __init__(self, kktsolver):
+        self.ks = kktsolver
+        self._ready = False
+
+    def init(self, q, b):
+        q, b = f64(q), f64(b)
+        if q.size != self.ks.n or b.size != self.ks.m:
+            raise ValueError("q must have length n and b length m")
+        check(_lib.lib().hipkkt_kkt_system_init(self.ks._h, ptr(q), ptr(b)), "hipkkt_kkt_system_init")
+        self._ready = True
+
+    # ---- device-pointer interface
+    def update_dev(self, d_s, d_z):
+        return check(_lib.lib().hipkkt_kkt_system_update(self.ks._h, C.c_void_p(d_s), C.c_void_p(d_z)),
+                     "hipkkt_kkt_system_update")
+
+    def solve_constant_rhs(self):
+        return check(_lib.lib().hipkkt_kkt_system_solve_constant_rhs(self.ks._h), "hipkkt_kkt_system_solve_constant_rhs")
+
+    def solve_initial_point_dev(self, d_x, d_s, d_z):
+        return check(_lib.lib().hipkkt_kkt_system_solve_initial_point(self.ks._h, C.c_void_p(d_x), C.c_void_p(d_s),
+                                                                       C.c_void_p(d_z)),
+                     "hipkkt_kkt_system_solve_initial_point")
+
+    def solve_dev(self, d_lhs, d_rhs, rhs_tau, rhs_kappa, d_var, var_tau, var_kappa, affine):
+        """d_lhs, d_rhs, d_var: (x, s, z) triples of device pointers.  Returns (is_success, dtau, dkappa)."""
+        tk = np.zeros(2)
+        ok = check(_lib.lib().hipkkt_kkt_system_solve(
+            self.ks._h, C.c_void_p(d_lhs[0]), C.c_void_p(d_lhs[1]), C.c_void_p(d_lhs[2]), ptr(tk),
+            C.c_void_p(d_rhs[0]), C.c_void_p(d_rhs[1]), C.c_void_p(d_rhs[2]), float(rhs_tau), float(rhs_kappa),
+            C.c_void_p(d_var[0]), C.c_void_p(d_var[1]), C.c_void_p(d_var[2]), float(var_tau), float(var_kappa),
+            0 if affine else 1), "hipkkt_kkt_system_solve")
+        return ok, tk[0], tk[1]
+
+    # ---- numpy interface (stages through device tensors)
+    @property
+    def _devstr(self):
+        import torch
+        d = self.ks.settings.device
+        return f"cuda:{d if d >= 0 else torch.cuda.current_device()}"       # -1 = the current device
+
+    def _dev(self, a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._devstr)
+
+    def update(self, s, z):
+        ds, dz = self._dev(s), self._dev(z)
+        return self.update_dev(ds.data_ptr(), dz.data_ptr())
+
+    def solve_initial_point(self):
+        import torch
+        dev = self._devstr
+        x = torch.zeros(max(self.ks.n, 1), dtype=torch.float64, device=dev)
+        s = torch.zeros(max(self.ks.m, 1), dtype=torch.float64, device=dev)
+        z = torch.zeros(max(self.ks.m, 1), dtype=torch.float64, device=dev)
+        ok = self.solve_initial_point_dev(x.data_ptr(), s.data_ptr(), z.data_ptr())
+        return ok, x[:self.ks.n].cpu().numpy(), s[:self.ks.m].cpu().numpy(), z[:self.ks.m].cpu().numpy()
+
+    def solve(self, rhs_x, rhs_s, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa, affine):
+        import torch
+        dev = self._devstr
+        n, m = self.ks.n, self.ks.m
+        rhs = [self._dev(rhs_x), self._dev(rhs_s), self._dev(rhs_z)]
+        var = [self._dev(x), self._dev(s), self._dev(z)]
+        lhs = [torch.zeros(max(k, 1), dtype=torch.float64, device=dev) for k in (n, m, m)]
+        ok, dtau, dkappa = self.solve_dev([t.data_ptr() for t in lhs], [t.data_ptr() for t in rhs], rhs_tau, rhs_kappa,
+                                          [t.data_ptr() for t in var], tau, kappa, affine)
+        if not ok:
+            return False, None
+        dx, ds, dz = lhs[0][:n].cpu().numpy(), lhs[1][:m].cpu().numpy(), lhs[2][:m].cpu().numpy()
+        return True, (dx, dz, ds, float(dtau), float(dkappa))
+
+
 class HipDirectLDLSolver:
     """An AbstractDirectLDLSolver backend (`ldlsolver_constructor(::Val{:hipldl})`):
     constructor(KKT, Dsigns, settings), update_values!, scale_values!, refactor!, solve!."""

@@ -172,6 +172,31 @@ int hipkkt_kkt_solve_multi(hipkkt_kkt_t h, int64_t nrhs, const double *rhsx, con
 int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double *d_rhsx,
                                const double *d_rhsz, double *d_lhsx, double *d_lhsz,
                                int64_t *ir_iterations);
+/* ------------------------------------------- Level C: DefaultKKTSystem, device-resident
+ * The layer that calls the KKT solver three times per interior-point iteration
+ * (/root/reference/src/kktsystem.jl:21-215) with all its vectors in HBM: right-hand-side
+ * construction (Delta_s_from_Delta_z_offset!, coneops_compositecone.jl:185-202) and the recovery of
+ * (dtau, dx, dz, ds, dkappa) (dots, quad_form mathutils.jl:299-337, mul_Hs!) run on the device, so
+ * per solve only the scalars cross PCIe.  Vectors named d_* are
+ * device pointers: x-like length n, s/z-like length m.  Covers zero, nonnegative and second-order
+ * cones (the combined step of a PSD cone returns an argument error). */
+/* DefaultKKTSystem constructor (kktsystem.jl:21-52): q (n), b (m) host vectors, copied */
+int hipkkt_kkt_system_init(hipkkt_kkt_t h, const double *q, const double *b);
+/* kkt_update! (kktsystem.jl:62-78): cone scaling from (s, z), refactor, constant-RHS solve */
+int hipkkt_kkt_system_update(hipkkt_kkt_t h, const double *d_s, const double *d_z);
+/* _kkt_solve_constant_rhs! (kktsystem.jl:80-92) alone, after hipkkt_kkt_update_cones */
+int hipkkt_kkt_system_solve_constant_rhs(hipkkt_kkt_t h);
+/* kkt_solve_initial_point! (kktsystem.jl:95-143): LP / QP branch on nnz(P) */
+int hipkkt_kkt_system_solve_initial_point(hipkkt_kkt_t h, double *d_x, double *d_s, double *d_z);
+/* kkt_solve! (kktsystem.jl:145-215): lhs <- step for right-hand side rhs at the iterate
+ * `variables`; steptype 0 = :affine, 1 = :combined.  lhs_tau_kappa (host, 2) receives (dtau, dkappa). */
+int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double *d_lhs_x, double *d_lhs_s, double *d_lhs_z,
+                            double *lhs_tau_kappa,
+                            const double *d_rhs_x, const double *d_rhs_s, const double *d_rhs_z,
+                            double rhs_tau, double rhs_kappa,
+                            const double *d_var_x, const double *d_var_s, const double *d_var_z,
+                            double var_tau, double var_kappa, int steptype);
+
 /* y = W'W x over all cones with the current scaling (mul_Hs!, coneops_compositecone.jl:138-150);
  * valid after hipkkt_kkt_update_from_sz*.  Host vectors of length m. */
 int hipkkt_kkt_mul_Hs(hipkkt_kkt_t h, double *y, const double *x);

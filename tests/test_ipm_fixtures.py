@@ -83,3 +83,78 @@ def test_ipm_on_cfg2_small_hip_vs_oracle():
     for a, b in zip(res.history[:k], ref.history[:k]):        # first ten iterations walk together
         assert abs(a["pcost"] - b["pcost"]) < 1e-6 * max(1, abs(b["pcost"]))
         assert abs(a["mu"] - b["mu"]) < 1e-6 * max(1e-12, abs(b["mu"]))
+
+
+# ---- level C: the reduced-system layer (kktsystem.jl) on the device ----------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ALL))
+def test_reference_known_answers_with_device_resident_kkt_system(name):
+    """Same fixtures, but kkt_update! / kkt_solve_initial_point! / kkt_solve! run on the device
+    (hipkkt_kkt_system_*): the driver only sees iterates and steps."""
+    P, q, A, b, cones, exp = ALL[name]()
+    res = ipm.solve(P, q, A, b, cones, ipm.HipSystemBackend(P, A, cones))
+    _check(res, exp)
+    ref = ipm.solve(P, q, A, b, cones, OracleBackend(P, A, cones))
+    assert res.iterations == ref.iterations
+    np.testing.assert_allclose(res.x, ref.x, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("affine", [True, False])
+def test_device_kkt_solve_matches_host_algebra(affine):
+    """kkt_solve! (kktsystem.jl:145-215) on the device against the same formulas in numpy with host cone
+    operations and the oracle's K^{-1}: (dx, dz, ds, dtau, dkappa) to 1e-9."""
+    import scipy.sparse as sp
+    from cuclarabel_amd import problems
+    from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+    from tests.oracle_bindings import make_oracle
+    pb = problems.small_mixed(seed=41, psds=(), socs=(3, 4, 6, 15))      # zero + nonnegative + dense and sparse SOCs
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    system = HipKKTSystem(ks)
+    system.init(pb.q, pb.b)
+    rng = np.random.default_rng(17)
+    s, z = pb.s0, pb.z0
+    x = rng.standard_normal(pb.n)
+    tau, kappa = 1.3, 0.7
+    assert system.update(s, z)
+    rhs_x, rhs_z = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    rhs_s = s.copy() if affine else rng.standard_normal(pb.m)
+    rhs_tau, rhs_kappa = 0.4, -0.2
+    ok, (dx, dz, ds, dtau, dkappa) = system.solve(rhs_x, rhs_s, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa, affine)
+    assert ok
+    # ---- the same on the host
+    o = make_oracle(pb, perm=ks.perm())
+    assert o.update_scaling(s, z) and o.kktsolver_update()
+    cones = ipm._make_cones(pb.cones)
+    for c in cones:
+        assert c.update_scaling(s[c.rng].copy(), z[c.rng].copy())
+
+    def each(fn, *vecs):
+        out = np.empty(pb.m)
+        for c in cones:
+            out[c.rng] = fn(c, *[v[c.rng] for v in vecs])
+        return out
+
+    def ksolve(rx, rz):
+        o.kktsolver_setrhs(rx, rz)
+        ok_, xo, zo = o.kktsolver_solve()
+        assert ok_
+        return xo, zo
+
+    Pt = sp.triu(sp.csc_matrix(pb.P), format="csc")
+    Pfull = (Pt + sp.triu(Pt, 1).T).tocsr()
+    x2, z2 = ksolve(-pb.q, pb.b)
+    const = s.copy() if affine else each(lambda c, d, zz: c.ds_from_dz_offset(d, zz), rhs_s, z)
+    x1, z1 = ksolve(rhs_x, const - rhs_z)
+    xi = x / tau
+    tnum = rhs_tau - rhs_kappa / tau + pb.q @ x1 + pb.b @ z1 + 2 * (xi @ (Pfull @ x1))
+    xm = xi - x2
+    tden = kappa / tau - pb.q @ x2 - pb.b @ z2 + xm @ (Pfull @ xm) - x2 @ (Pfull @ x2)
+    dtau_h = tnum / tden
+    dx_h, dz_h = x1 + dtau_h * x2, z1 + dtau_h * z2
+    ds_h = -(each(lambda c, v: c.mul_Hs(v), dz_h) + const)
+    dkappa_h = -(rhs_kappa + kappa * dtau_h) / tau
+    assert abs(dtau - dtau_h) <= 1e-9 * max(1.0, abs(dtau_h))
+    assert abs(dkappa - dkappa_h) <= 1e-9 * max(1.0, abs(dkappa_h))
+    for a, bb in ((dx, dx_h), (dz, dz_h), (ds, ds_h)):
+        assert np.abs(a - bb).max() <= 1e-9 * max(1.0, np.abs(bb).max())
