@@ -96,6 +96,9 @@ SYMBOLS = {
     "hipkkt_kkt_system_solve_initial_point": (C.c_int, [_P, _P, _P, _P]),
     "hipkkt_kkt_system_solve": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                           _P, _P, _P, C.c_double, C.c_double, C.c_int]),
+    "hipkkt_equilibrate": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P,
+                                     C.c_int32, C.c_double, C.c_double, _P, _P, _P, C.c_int, C.c_int]),
+    "hipkkt_scale_matrix_values": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_int, C.c_int]),
     "hipkkt_kkt_mul_Hs": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_get_pattern": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_get_values": (C.c_int, [_P, _P]),

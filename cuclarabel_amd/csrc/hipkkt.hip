@@ -1864,6 +1864,124 @@ int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, do
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+//  Ruiz equilibration of the problem data (data_equilibrate!, problemdata.jl:133-221) -- SURVEY.md 8 f4.
+//  Stand-alone: runs before the KKT solver is built from the scaled (P, A).
+// ------------------------------------------------------------------------------------------------
+static void expand_csc(int64_t ncols, const int64_t* colptr, const int64_t* rowval, int base, std::vector<int>& row,
+                       std::vector<int>& col)
+{
+    const int64_t nnz = colptr[ncols] - base;
+    row.resize((size_t)nnz);
+    col.resize((size_t)nnz);
+    for (int64_t j = 0; j < ncols; ++j)
+        for (int64_t q = colptr[j] - base; q < colptr[j + 1] - base; ++q) {
+            row[(size_t)q] = (int)(rowval[q] - base);
+            col[(size_t)q] = (int)j;
+        }
+}
+
+int hipkkt_equilibrate(int64_t n, int64_t m, const int64_t* Pcolptr, const int64_t* Prowval, double* Pnzval,
+                       const int64_t* Acolptr, const int64_t* Arowval, double* Anzval, double* q, double* b,
+                       int64_t ncones, const int32_t* cone_kinds, const int64_t* cone_dims, int32_t max_iter,
+                       double min_scaling, double max_scaling, double* d, double* e, double* c, int index_base,
+                       int device)
+{
+    return guarded([&]() {
+        if (n < 0 || m < 0 || !Pcolptr || !Acolptr || (n && (!q || !d)) || (m && (!b || !e)) || !c || max_iter < 0 ||
+            ncones < 0 || (ncones && (!cone_kinds || !cone_dims)))
+            throw ArgError("hipkkt_equilibrate: bad argument");
+        hipkkt_settings st{};
+        st.device = device;
+        select_device(st);
+        hipStream_t stream;
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+        std::vector<int> prow, pcol, arow, acol;
+        expand_csc(n, Pcolptr, Prowval, index_base, prow, pcol);
+        expand_csc(n, Acolptr, Arowval, index_base, arow, acol);
+        for (size_t j = 0; j < prow.size(); ++j)
+            if (prow[j] < 0 || prow[j] >= n) throw ArgError("hipkkt_equilibrate: P row index out of range");
+        for (size_t j = 0; j < arow.size(); ++j)
+            if (arow[j] < 0 || arow[j] >= m) throw ArgError("hipkkt_equilibrate: A row index out of range");
+        // cone layout (numel per cone: k(k+1)/2 for a PSD cone of side k)
+        std::vector<int> ckind((size_t)ncones), coff((size_t)ncones), cnumel((size_t)ncones);
+        int64_t off = 0;
+        for (int64_t k = 0; k < ncones; ++k) {
+            const int64_t dim = cone_dims[k];
+            const int64_t ne = cone_kinds[k] == HIPKKT_CONE_PSD ? dim * (dim + 1) / 2 : dim;
+            ckind[(size_t)k] = cone_kinds[k];
+            coff[(size_t)k] = (int)off;
+            cnumel[(size_t)k] = (int)ne;
+            off += ne;
+        }
+        if (off != m) throw ArgError("hipkkt_equilibrate: cone dimensions do not add up to m");
+
+        DBuf<int> dprow, dpcol, darow, dacol, dkind, doff, dnumel;
+        dprow.upload(prow); dpcol.upload(pcol); darow.upload(arow); dacol.upload(acol);
+        dkind.upload(ckind); doff.upload(coff); dnumel.upload(cnumel);
+        DBuf<double> dP, dA, dq, db, dd, de, dw, ew, scal, partial;
+        const size_t nnzP = prow.size(), nnzA = arow.size();
+        dP.alloc(nnzP); dA.alloc(nnzA); dq.alloc((size_t)n); db.alloc((size_t)m);
+        dd.alloc((size_t)n); de.alloc((size_t)m); dw.alloc((size_t)n); ew.alloc((size_t)m);
+        scal.alloc(8); partial.alloc(512);
+        if (nnzP) HIP_CHECK(hipMemcpyAsync(dP.p, Pnzval, nnzP * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (nnzA) HIP_CHECK(hipMemcpyAsync(dA.p, Anzval, nnzA * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (n) HIP_CHECK(hipMemcpyAsync(dq.p, q, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(db.p, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream));
+        std::vector<double> ones((size_t)std::max<int64_t>(std::max(n, m), 8), 1.0);
+        if (n) HIP_CHECK(hipMemcpyAsync(dd.p, ones.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(de.p, ones.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(scal.p, ones.data(), 8 * sizeof(double), hipMemcpyHostToDevice, stream));
+        EquilDev E;
+        E.n = (int)n; E.m = (int)m; E.nnzP = (int64_t)nnzP; E.nnzA = (int64_t)nnzA;
+        E.Prow = dprow.p; E.Pcol = dpcol.p; E.Arow = darow.p; E.Acol = dacol.p;
+        E.Pval = dP.p; E.Aval = dA.p; E.q = dq.p; E.b = db.p; E.d = dd.p; E.e = de.p; E.dwork = dw.p; E.ework = ew.p;
+        E.scal = scal.p; E.partial = partial.p;
+        for (int it = 0; it < max_iter; ++it) launch_equil_round(E, min_scaling, max_scaling, stream);
+        if (max_iter > 0) launch_equil_rectify(E, dkind.p, doff.p, dnumel.p, nullptr, (int)ncones, stream);
+        HIP_CHECK(hipGetLastError());
+        if (nnzP) HIP_CHECK(hipMemcpyAsync(Pnzval, dP.p, nnzP * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (nnzA) HIP_CHECK(hipMemcpyAsync(Anzval, dA.p, nnzA * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (n) HIP_CHECK(hipMemcpyAsync(q, dq.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(b, db.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (n) HIP_CHECK(hipMemcpyAsync(d, dd.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(e, de.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(c, scal.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return HIPKKT_OK;
+    });
+}
+
+// _update_matrix (data_updating.jl:169-194): values <- cscale * L[row] * R[col] * values for a CSC matrix
+int hipkkt_scale_matrix_values(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowval, double* nzval,
+                               const double* lscale, const double* rscale, double cscale, int index_base, int device)
+{
+    return guarded([&]() {
+        if (nrows < 0 || ncols < 0 || !colptr || !lscale || !rscale) throw ArgError("hipkkt_scale_matrix_values: bad argument");
+        hipkkt_settings st{};
+        st.device = device;
+        select_device(st);
+        std::vector<int> row, col;
+        expand_csc(ncols, colptr, rowval, index_base, row, col);
+        if (row.empty()) return HIPKKT_OK;
+        if (!nzval) throw ArgError("hipkkt_scale_matrix_values: bad argument");
+        for (int r : row) if (r < 0 || r >= nrows) throw ArgError("hipkkt_scale_matrix_values: row index out of range");
+        DBuf<int> drow, dcol;
+        drow.upload(row); dcol.upload(col);
+        DBuf<double> v, L, R;
+        v.alloc(row.size()); L.alloc((size_t)nrows); R.alloc((size_t)ncols);
+        HIP_CHECK(hipMemcpy(v.p, nzval, row.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(L.p, lscale, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(R.p, rscale, (size_t)ncols * sizeof(double), hipMemcpyHostToDevice));
+        launch_lrscale(v.p, drow.p, dcol.p, (int64_t)row.size(), L.p, R.p, cscale, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(nzval, v.p, row.size() * sizeof(double), hipMemcpyDeviceToHost));
+        return HIPKKT_OK;
+    });
+}
+
 int hipkkt_kkt_mul_Hs(hipkkt_kkt_t h, double* y, const double* x)
 {
     return guarded([&]() {

@@ -1,5 +1,6 @@
 // See kernels.hpp.  Hand-written HIP for gfx950 (CDNA4, wave64).
 #include "kernels.hpp"
+#include <algorithm>
 
 #include <cmath>
 
@@ -804,6 +805,187 @@ void launch_neg_copy(double* y, const double* a, int n, hipStream_t st)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_neg_copy, dim3(grid_for(n, 256)), dim3(256), 0, st, y, a, n);
+}
+
+}  // namespace hipkkt
+
+
+// =====================================================================================
+//  Ruiz equilibration (problemdata.jl:133-221).  Infinity norms are order-independent, so the
+//  column / row maxima use atomicMax on the bit pattern of the non-negative doubles (exact and
+//  deterministic); the one sum (mean column norm of P) is reduced in a fixed two-stage order.
+// =====================================================================================
+namespace hipkkt {
+
+__device__ inline void atomic_max_nonneg(double* addr, double v)
+{
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ void k_equil_norms(EquilDev E)
+{
+    // kkt_col_norms! (mathutils.jl:129-141): dwork = column norms of [P A'] (P symmetric from its triangle),
+    // ework = row norms of A; both zeroed by the caller
+    const int64_t tot = E.nnzP + E.nnzA;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < tot; j += (int64_t)gridDim.x * blockDim.x) {
+        if (j < E.nnzP) {
+            const double v = fabs(E.Pval[j]);
+            atomic_max_nonneg(E.dwork + E.Pcol[j], v);
+            atomic_max_nonneg(E.dwork + E.Prow[j], v);
+        } else {
+            const int64_t k = j - E.nnzP;
+            const double v = fabs(E.Aval[k]);
+            atomic_max_nonneg(E.dwork + E.Acol[k], v);
+            atomic_max_nonneg(E.ework + E.Arow[k], v);
+        }
+    }
+}
+__global__ void k_equil_scalings(EquilDev E, double smin, double smax)
+{
+    // problemdata.jl:167-177
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E.n + E.m; i += gridDim.x * blockDim.x) {
+        double* w = i < E.n ? E.dwork + i : E.ework + (i - E.n);
+        double* cum = i < E.n ? E.d + i : E.e + (i - E.n);
+        double v = *w;
+        if (v == 0.0) v = 1.0;
+        v = 1.0 / sqrt(v);
+        const double lo = smin / *cum, hi = smax / *cum;
+        v = v < lo ? lo : (v > hi ? hi : v);
+        *w = v;
+        *cum *= v;                                  // :182-183
+    }
+}
+__global__ void k_equil_scale_data(EquilDev E, int with_d)
+{
+    // scale_data! (problemdata.jl:223-242)
+    const int64_t tot = (with_d ? E.nnzP : 0) + E.nnzA;
+    const int64_t pn = with_d ? E.nnzP : 0;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < tot; j += (int64_t)gridDim.x * blockDim.x) {
+        if (j < pn) {
+            E.Pval[j] *= E.dwork[E.Prow[j]] * E.dwork[E.Pcol[j]];
+        } else {
+            const int64_t k = j - pn;
+            if (with_d) E.Aval[k] *= E.ework[E.Arow[k]] * E.dwork[E.Acol[k]];
+            else E.Aval[k] *= E.ework[E.Arow[k]];
+        }
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E.n + E.m; i += gridDim.x * blockDim.x) {
+        if (i < E.n) { if (with_d) E.q[i] *= E.dwork[i]; }
+        else E.b[i - E.n] *= E.ework[i - E.n];
+    }
+}
+__global__ void k_equil_colnorm_P(EquilDev E)
+{
+    // col_norms!(dwork, P) on the stored triangle only (problemdata.jl:188; mathutils.jl:143-165); dwork zeroed
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < E.nnzP; j += (int64_t)gridDim.x * blockDim.x)
+        atomic_max_nonneg(E.dwork + E.Pcol[j], fabs(E.Pval[j]));
+}
+__global__ __launch_bounds__(256) void k_equil_cost_partials(EquilDev E)
+{
+    // partial[0..255] = block sums of dwork, partial[256..511] = block maxima of |q|
+    __shared__ double sh[256];
+    double acc = 0.0, mx = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < E.n; i += gridDim.x * 256) {
+        acc += E.dwork[i];
+        mx = fmax(mx, fabs(E.q[i]));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) E.partial[blockIdx.x] = sh[0];
+    __syncthreads();
+    sh[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) E.partial[256 + blockIdx.x] = sh[0];
+}
+__global__ void k_equil_cost_scalar(EquilDev E, int nblocks, double smin, double smax)
+{
+    // problemdata.jl:189-203: ctmp = clip(1 / max(||q||_inf, mean col norm of P), ...), 1 if either is zero
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sum = 0.0, mx = 0.0;
+    for (int i = 0; i < nblocks; ++i) { sum += E.partial[i]; mx = fmax(mx, E.partial[256 + i]); }
+    const double mean = E.n > 0 ? sum / (double)E.n : 0.0;
+    double ctmp = 1.0;
+    if (mean != 0.0 && mx != 0.0) {
+        const double c = E.scal[0];
+        ctmp = 1.0 / fmax(mx, mean);
+        const double lo = smin / c, hi = smax / c;
+        ctmp = ctmp < lo ? lo : (ctmp > hi ? hi : ctmp);
+        E.scal[0] = c * ctmp;
+    }
+    E.scal[1] = ctmp;
+}
+__global__ void k_equil_apply_cost(EquilDev E)
+{
+    const double ctmp = E.scal[1];
+    if (ctmp == 1.0) return;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < E.nnzP + E.n; j += (int64_t)gridDim.x * blockDim.x) {
+        if (j < E.nnzP) E.Pval[j] *= ctmp;
+        else E.q[j - E.nnzP] *= ctmp;
+    }
+}
+void launch_equil_round(const EquilDev& E, double smin, double smax, hipStream_t st)
+{
+    const int64_t tot = E.nnzP + E.nnzA;
+    (void)hipMemsetAsync(E.dwork, 0, (size_t)std::max(E.n, 1) * sizeof(double), st);
+    (void)hipMemsetAsync(E.ework, 0, (size_t)std::max(E.m, 1) * sizeof(double), st);
+    if (tot > 0) hipLaunchKernelGGL(k_equil_norms, dim3(grid_for(tot, 256)), dim3(256), 0, st, E);
+    if (E.n + E.m > 0) hipLaunchKernelGGL(k_equil_scalings, dim3(grid_for(E.n + E.m, 256)), dim3(256), 0, st, E, smin, smax);
+    hipLaunchKernelGGL(k_equil_scale_data, dim3(grid_for(std::max<int64_t>(tot, E.n + E.m), 256)), dim3(256), 0, st, E, 1);
+    (void)hipMemsetAsync(E.dwork, 0, (size_t)std::max(E.n, 1) * sizeof(double), st);
+    if (E.nnzP > 0) hipLaunchKernelGGL(k_equil_colnorm_P, dim3(grid_for(E.nnzP, 256)), dim3(256), 0, st, E);
+    const int nb = std::max(1, std::min(256, (E.n + 255) / 256));
+    hipLaunchKernelGGL(k_equil_cost_partials, dim3(nb), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_equil_cost_scalar, dim3(1), dim3(64), 0, st, E, nb, smin, smax);
+    hipLaunchKernelGGL(k_equil_apply_cost, dim3(grid_for(E.nnzP + E.n, 256)), dim3(256), 0, st, E);
+}
+
+// one wave per cone that needs a scalar scaling: delta = mean(e) / e over the cone
+__global__ __launch_bounds__(64) void k_equil_rectify(EquilDev E, const int* __restrict__ kind, const int* __restrict__ off,
+                                                      const int* __restrict__ numel, int ncones)
+{
+    const int c = blockIdx.x;
+    if (c >= ncones) return;
+    const int k = kind[c];
+    if (k == 0 || k == 1) return;                      // zero / nonnegative: elementwise scaling allowed, delta = 1
+    const int o = off[c], n = numel[c];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) acc += E.e[o + i];
+    acc = wave_sum(acc);
+    const double mean = acc / (double)n;
+    for (int i = threadIdx.x; i < n; i += 64) E.ework[o + i] = mean / E.e[o + i];
+}
+__global__ void k_equil_apply_e(EquilDev E)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E.m; i += gridDim.x * blockDim.x) E.e[i] *= E.ework[i];
+}
+__global__ void k_fill(double* __restrict__ p, double v, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_equil_rectify(const EquilDev& E, const int* cone_kind, const int* cone_off, const int* cone_numel,
+                          const int* elem_cone, int ncones, hipStream_t st)
+{
+    (void)elem_cone;
+    if (E.m <= 0 || ncones <= 0) return;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(E.m, 256)), dim3(256), 0, st, E.ework, 1.0, E.m);
+    hipLaunchKernelGGL(k_equil_rectify, dim3(ncones), dim3(64), 0, st, E, cone_kind, cone_off, cone_numel, ncones);
+    hipLaunchKernelGGL(k_equil_scale_data, dim3(grid_for(std::max<int64_t>(E.nnzA, E.n + E.m), 256)), dim3(256), 0, st, E, 0);
+    hipLaunchKernelGGL(k_equil_apply_e, dim3(grid_for(E.m, 256)), dim3(256), 0, st, E);
+}
+
+__global__ void k_lrscale(double* __restrict__ v, const int* __restrict__ row, const int* __restrict__ col, int64_t nnz,
+                          const double* __restrict__ L, const double* __restrict__ R, double cscale)
+{
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x)
+        v[j] = v[j] * (L[row[j]] * R[col[j]]) * cscale;
+}
+void launch_lrscale(double* values, const int* row, const int* col, int64_t nnz, const double* L, const double* R,
+                    double cscale, hipStream_t st)
+{
+    if (nnz <= 0) return;
+    hipLaunchKernelGGL(k_lrscale, dim3(grid_for(nnz, 256)), dim3(256), 0, st, values, row, col, nnz, L, R, cscale);
 }
 
 }  // namespace hipkkt

@@ -246,4 +246,27 @@ void launch_sys_scalars(const double* dots, const double* cached, const double* 
 void launch_neg_sum(double* y, const double* a, const double* b, int n, hipStream_t st);      // y = -(a + b)
 void launch_neg_copy(double* y, const double* a, int n, hipStream_t st);                    // y = -a
 
+
+// ---- Ruiz equilibration of (P, A, q, b) (problemdata.jl:133-221, mathutils.jl:129-269), all vectors on the device
+struct EquilDev {
+    int n, m;
+    int64_t nnzP, nnzA;
+    const int* Prow; const int* Pcol;   // per entry of triu(P)
+    const int* Arow; const int* Acol;   // per entry of A
+    double* Pval; double* Aval; double* q; double* b;
+    double* d; double* e;               // cumulative scalings
+    double* dwork; double* ework;       // this round's scalings
+    double* scal;                       // [0] c, [1] ctmp, [2..] scratch
+    double* partial;                    // 2 * 256 doubles
+};
+// one round of the loop at problemdata.jl:163-205
+void launch_equil_round(const EquilDev& E, double scale_min, double scale_max, hipStream_t st);
+// rectify_equilibration! (coneops_compositecone.jl:28-47; default coneops_defaults.jl:32-44, elementwise cones
+// coneops_nncone.jl:8-17 / coneops_zerocone.jl:16-25) followed by the row re-scaling at problemdata.jl:212-216
+void launch_equil_rectify(const EquilDev& E, const int* cone_kind, const int* cone_off, const int* cone_numel,
+                          const int* elem_cone, int ncones, hipStream_t st);
+// values[j] *= cscale * L[row[j]] * R[col[j]]   (lrscale!, mathutils.jl:231-244; data_updating.jl:181-194)
+void launch_lrscale(double* values, const int* row, const int* col, int64_t nnz, const double* L, const double* R,
+                    double cscale, hipStream_t st);
+
 }  // namespace hipkkt

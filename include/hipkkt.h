@@ -197,6 +197,28 @@ int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double *d_lhs_x, double *d_lhs_s, do
                             const double *d_var_x, const double *d_var_s, const double *d_var_z,
                             double var_tau, double var_kappa, int steptype);
 
+/* ------------------------------------------- problem-data scaling (before the KKT solver is built)
+ * data_equilibrate! (/root/reference/src/problemdata.jl:133-221): Ruiz equilibration of
+ * [P A'; A 0], q, b on the device.  P: n x n upper-triangular CSC,
+ * A: m x n CSC.  Pnzval, Anzval, q, b are overwritten with c D P D, E A D, c D q, E b; d (n),
+ * e (m) and c (1) receive the scalings (all ones / one when max_iter = 0).  Defaults of the
+ * reference: max_iter 10, min_scaling 1e-4, max_scaling 1e4 (settings.jl:98-101).  Cones that do
+ * not admit elementwise scaling (second-order, PSD) get one common factor per cone
+ * (rectify_equilibration!, coneops_defaults.jl:32-44). */
+int hipkkt_equilibrate(int64_t n, int64_t m,
+                       const int64_t *Pcolptr, const int64_t *Prowval, double *Pnzval,
+                       const int64_t *Acolptr, const int64_t *Arowval, double *Anzval,
+                       double *q, double *b,
+                       int64_t ncones, const int32_t *cone_kinds, const int64_t *cone_dims,
+                       int32_t max_iter, double min_scaling, double max_scaling,
+                       double *d, double *e, double *c, int index_base, int device);
+/* _update_matrix (data_updating.jl:169-194), the re-scaling update_P! / update_A! apply to new
+ * values before kktsolver_update_P!/A!: nzval <- cscale * lscale[row] * rscale[col] * nzval
+ * (P: lscale = rscale = d, cscale = c; A: lscale = e, rscale = d, cscale = 1). */
+int hipkkt_scale_matrix_values(int64_t nrows, int64_t ncols, const int64_t *colptr,
+                               const int64_t *rowval, double *nzval, const double *lscale,
+                               const double *rscale, double cscale, int index_base, int device);
+
 /* y = W'W x over all cones with the current scaling (mul_Hs!, coneops_compositecone.jl:138-150);
  * valid after hipkkt_kkt_update_from_sz*.  Host vectors of length m. */
 int hipkkt_kkt_mul_Hs(hipkkt_kkt_t h, double *y, const double *x);
