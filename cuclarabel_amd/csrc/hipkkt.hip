@@ -867,6 +867,14 @@ struct hipkkt_kkt_s {
     // residual SpMV
     DBuf<int64_t> fptr;
     DBuf<int> fcol, fmap;
+    DBuf<double> fval;               // K values in the CSR image's order, refreshed after every value change
+    bool fval_dirty = true;
+    // long rows of the image (kernels.hpp, SpmvDev)
+    DBuf<int> long_rows;
+    DBuf<int64_t> long_chunk_ptr, chunk_q;
+    DBuf<double> long_partial;
+    int nlong = 0, nchunks = 0;
+    size_t long_partial_cols = 0;
     int lanes_per_row = 8;
     // vectors
     DBuf<double> b, x, e, dx, rx, rz, sbuf, zbuf, ybuf;
@@ -1236,6 +1244,30 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
             h->fptr.upload(ptr);
             h->fcol.upload(col);
             h->fmap.upload(vmap);
+            h->fval.alloc(vmap.size());
+            {
+                std::vector<int> lrows;
+                std::vector<int64_t> lptr{0}, cq;
+                for (int i = 0; i < N; ++i) {
+                    const int64_t len = ptr[i + 1] - ptr[i];
+                    if (len <= kLongRow) continue;
+                    lrows.push_back(i);
+                    for (int64_t q = ptr[i]; q < ptr[i + 1]; q += kLongChunk) {
+                        cq.push_back(q);
+                        cq.push_back(std::min<int64_t>(q + kLongChunk, ptr[i + 1]));
+                    }
+                    lptr.push_back((int64_t)cq.size() / 2);
+                }
+                h->nlong = (int)lrows.size();
+                h->nchunks = (int)(cq.size() / 2);
+                if (h->nlong) {
+                    h->long_rows.upload(lrows);
+                    h->long_chunk_ptr.upload(lptr);
+                    h->chunk_q.upload(cq);
+                    h->long_partial.alloc((size_t)h->nchunks);
+                    h->long_partial_cols = 1;
+                }
+            }
             double avg = (double)ptr[N] / std::max(N, 1);
             h->lanes_per_row = avg > 24.0 ? 64 : 8;
         }
@@ -1327,6 +1359,7 @@ int hipkkt_kkt_info(hipkkt_kkt_t h, hipkkt_info* info)
 static int kkt_update_device(hipkkt_kkt_t h)
 {
     KKTAssembly& K = h->K;
+    h->fval_dirty = true;
     int pu = h->prof.begin(0, h->stream);
     launch_scatter(h->Kval.p, h->mapHs.p, h->Hs.p, K.nHs, -1.0, h->stream);       // :225-228
     launch_soc_columns(h->Kval.p, h->mapU.p, h->mapV.p, h->mapD.p, h->soc_u.p, h->soc_v.p, h->soc_eta2.p,
@@ -1413,6 +1446,7 @@ int hipkkt_kkt_update_P(hipkkt_kkt_t h, const double* Pnzval)
         if (!k) return HIPKKT_OK;
         HIP_CHECK(hipMemcpyAsync(h->Pval.p, Pnzval, k * sizeof(double), hipMemcpyHostToDevice, h->stream));
         launch_scatter(h->Kval.p, h->mapP.p, h->Pval.p, (int64_t)k, 1.0, h->stream);
+        h->fval_dirty = true;
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return HIPKKT_OK;
     });
@@ -1427,6 +1461,7 @@ int hipkkt_kkt_update_A(hipkkt_kkt_t h, const double* Anzval)
         if (!k) return HIPKKT_OK;
         HIP_CHECK(hipMemcpyAsync(h->Aval.p, Anzval, k * sizeof(double), hipMemcpyHostToDevice, h->stream));
         launch_scatter(h->Kval.p, h->mapA.p, h->Aval.p, (int64_t)k, 1.0, h->stream);
+        h->fval_dirty = true;
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return HIPKKT_OK;
     });
@@ -1455,12 +1490,26 @@ int hipkkt_kkt_setrhs(hipkkt_kkt_t h, const double* rx, const double* rz)
     });
 }
 
+// the full-symmetric CSR image of K with its values streamed in CSR order
+static SpmvDev kkt_spmv(hipkkt_kkt_t h)
+{
+    if (h->fval_dirty) {
+        launch_gather_values(h->fval.p, h->Kval.p, h->fmap.p, (int64_t)h->fmap.n, h->stream);
+        h->fval_dirty = false;
+    }
+    SpmvDev A;
+    A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.val = h->fval.p; A.N = h->K.N;
+    A.lanes_per_row = h->lanes_per_row;
+    A.nlong = h->nlong; A.nchunks = h->nchunks; A.long_rows = h->long_rows.p; A.long_chunk_ptr = h->long_chunk_ptr.p;
+    A.chunk_q = h->chunk_q.p; A.long_partial = h->long_partial.p;
+    return A;
+}
+
 // e = b - K xi, returns ||e||_inf via pinned read-back (slot 1), optionally ||b||_inf too (slot 2);
 // slot 3 carries the persistent solve kernel's abort word along (*top_abort, nullable)
 static double kkt_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, double* normb, bool* top_abort)
 {
-    SpmvDev A;
-    A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.N = h->K.N; A.lanes_per_row = h->lanes_per_row;
+    const SpmvDev A = kkt_spmv(h);
     int pr = h->prof.begin(3, h->stream);
     launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + 1, h->stream, 1, 0,
                     h->eng->top_abort_word(), h->scal.p + 3);
@@ -1578,7 +1627,8 @@ static void kkt_multi_reserve(hipkkt_kkt_t h, size_t k)
     if (k <= h->mcap) return;
     const size_t N = (size_t)h->K.N;
     h->mB.alloc(N * k); h->mX.alloc(N * k); h->mC.alloc(N * k); h->mE.alloc(N * k); h->mE2.alloc(N * k);
-    h->mpartial.alloc((size_t)kNormParts * k);
+    h->mpartial.alloc((size_t)(kNormParts + 1) * k);
+    if (h->nlong && k > h->long_partial_cols) { h->long_partial.alloc((size_t)h->nchunks * k); h->long_partial_cols = k; }
     h->mnorms.alloc(2 * k);
     h->mmask.alloc(k);
     h->mcap = k;
@@ -1605,8 +1655,7 @@ static int kkt_solve_multi_core(hipkkt_kkt_t h, int k, int64_t* ir_out)
         if (ir_out) std::copy(ir.begin(), ir.end(), ir_out);
         return bad ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
     }
-    SpmvDev A;
-    A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.N = N; A.lanes_per_row = h->lanes_per_row;
+    const SpmvDev A = kkt_spmv(h);
     std::vector<double> hn(2 * (size_t)k), norme((size_t)k), normb((size_t)k);
     std::vector<int> active((size_t)k, 1), mask((size_t)k, 0);
     {
@@ -1716,12 +1765,7 @@ int hipkkt_kkt_solve_multi(hipkkt_kkt_t h, int64_t nrhs, const double* rhsx, con
 //  vector resident in HBM -- right-hand-side construction and the recovery of (dtau, dx, dz, ds, dkappa)
 //  around the solves run on the device, so nothing but two scalars per solve crosses PCIe.
 // ------------------------------------------------------------------------------------------------
-static SpmvDev sys_spmv(hipkkt_kkt_t h)
-{
-    SpmvDev A;
-    A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.N = h->K.N; A.lanes_per_row = h->lanes_per_row;
-    return A;
-}
+static SpmvDev sys_spmv(hipkkt_kkt_t h) { return kkt_spmv(h); }
 
 int hipkkt_kkt_system_init(hipkkt_kkt_t h, const double* q, const double* b)
 {

@@ -123,14 +123,20 @@ __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __res
     b += blockIdx.y * ld;
     x += blockIdx.y * ld;
     e += blockIdx.y * ld;
-    partial += blockIdx.y * gridDim.x;
+    partial += blockIdx.y * (gridDim.x + 1);
     const int sub = threadIdx.x % G;
     const int rows_per_block = 256 / G;
     double vmax = 0.0;
     bool bad = false;
     for (int row = blockIdx.x * rows_per_block + threadIdx.x / G; row < A.N; row += gridDim.x * rows_per_block) {
+        const int64_t q0 = A.ptr[row], q1 = A.ptr[row + 1];
+        if (q1 - q0 > kLongRow) continue;               // handled by k_residual_long_*
         double acc = 0.0;
-        for (int64_t q = A.ptr[row] + sub; q < A.ptr[row + 1]; q += G) acc = fma(K[A.vmap[q]], x[A.col[q]], acc);
+        if (A.val) {
+            for (int64_t q = q0 + sub; q < q1; q += G) acc = fma(A.val[q], x[A.col[q]], acc);
+        } else {
+            for (int64_t q = q0 + sub; q < q1; q += G) acc = fma(K[A.vmap[q]], x[A.col[q]], acc);
+        }
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, G);
         if (sub == 0) {
@@ -142,7 +148,51 @@ __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __res
     }
     if (bad) vmax = INFINITY;        // marks non-finite; finished as NaN below
     vmax = block_max_256(vmax, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = vmax;
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = vmax;
+        if (blockIdx.x == 0 && A.nlong == 0) partial[gridDim.x] = 0.0;     // the long rows' slot
+    }
+}
+// one workgroup per chunk of a long row: fixed assignment of entries to threads, fixed reduction tree
+__global__ __launch_bounds__(256) void k_residual_long_chunks(SpmvDev A, const double* __restrict__ K,
+                                                              const double* __restrict__ x, int64_t ld)
+{
+    __shared__ double sh[256];
+    x += blockIdx.y * ld;
+    const int64_t q0 = A.chunk_q[2 * blockIdx.x], q1 = A.chunk_q[2 * blockIdx.x + 1];
+    double acc = 0.0;
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += 256)
+        acc = fma(A.val ? A.val[q] : K[A.vmap[q]], x[A.col[q]], acc);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.long_partial[(int64_t)blockIdx.y * A.nchunks + blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void k_residual_long_finish(SpmvDev A, const double* __restrict__ b,
+                                                              double* __restrict__ e, double* __restrict__ partial,
+                                                              int64_t ld, int gmain)
+{
+    __shared__ double sh[4];
+    b += blockIdx.y * ld;
+    e += blockIdx.y * ld;
+    const double* lp = A.long_partial + (int64_t)blockIdx.y * A.nchunks;
+    double vmax = 0.0;
+    bool bad = false;
+    for (int t = threadIdx.x; t < A.nlong; t += 256) {
+        const int row = A.long_rows[t];
+        double acc = 0.0;
+        for (int64_t c = A.long_chunk_ptr[t]; c < A.long_chunk_ptr[t + 1]; ++c) acc += lp[c];
+        const double r = b[row] - acc;
+        e[row] = r;
+        if (!isfinite(r)) bad = true;
+        vmax = fmax(vmax, fabs(r));
+    }
+    if (bad) vmax = INFINITY;
+    vmax = block_max_256(vmax, sh);
+    if (threadIdx.x == 0) partial[blockIdx.y * (gmain + 1) + gmain] = vmax;
 }
 __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, double* __restrict__ out,
                               const int* __restrict__ flag_in = nullptr, double* __restrict__ flag_out = nullptr)
@@ -170,7 +220,11 @@ void launch_residual(const SpmvDev& A, const double* K, const double* b, const d
         hipLaunchKernelGGL(k_residual<8>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
     else
         hipLaunchKernelGGL(k_residual<64>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
-    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, norm_out, flag_in, flag_out);
+    if (A.nlong > 0) {
+        hipLaunchKernelGGL(k_residual_long_chunks, dim3(A.nchunks, nrhs), dim3(256), 0, st, A, K, x, ld);
+        hipLaunchKernelGGL(k_residual_long_finish, dim3(1, nrhs), dim3(256), 0, st, A, b, e, partial, ld, g);
+    }
+    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g + 1, norm_out, flag_in, flag_out);
 }
 __global__ void k_absmax(const double* __restrict__ v, int n, double* __restrict__ partial, int64_t ld)
 {
@@ -193,6 +247,17 @@ void launch_norm_inf(const double* v, int n, double* partial, double* out, hipSt
     int g = grid_for(n, 256, kRedBlocks);
     hipLaunchKernelGGL(k_absmax, dim3(g, nrhs), dim3(256), 0, st, v, n, partial, ld);
     hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, out, (const int*)nullptr, (double*)nullptr);
+}
+__global__ void k_gather_values(double* __restrict__ val, const double* __restrict__ K, const int* __restrict__ vmap,
+                                int64_t nnz)
+{
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * blockDim.x)
+        val[q] = K[vmap[q]];
+}
+void launch_gather_values(double* val, const double* Kval, const int* vmap, int64_t nnz, hipStream_t st)
+{
+    if (nnz <= 0) return;
+    hipLaunchKernelGGL(k_gather_values, dim3(grid_for(nnz, 256, 8192)), dim3(256), 0, st, val, Kval, vmap, nnz);
 }
 __global__ void k_sum2(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int64_t n)
 {
@@ -700,7 +765,7 @@ __global__ __launch_bounds__(256) void k_P_spmv(SpmvDev A, const double* __restr
         double acc = 0.0;
         for (int64_t q = A.ptr[row] + sub; q < A.ptr[row + 1]; q += 8) {
             const int c = A.col[q];
-            if (c < n) acc = fma(K[A.vmap[q]], x[c], acc);
+            if (c < n) acc = fma(A.val ? A.val[q] : K[A.vmap[q]], x[c], acc);
         }
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) acc += __shfl_down(acc, o, 8);

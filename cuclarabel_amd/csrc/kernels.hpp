@@ -166,12 +166,22 @@ struct SpmvDev {
     const int64_t* ptr;          // N+1, full symmetric CSR
     const int* col;
     const int* vmap;             // entry -> index into Kval
+    const double* val;           // the values in CSR order (a refreshed copy of Kval[vmap[.]]), or null
     int N;
     int lanes_per_row;           // 8 or 64
+    // rows longer than kLongRow entries (a dense constraint row, say) are cut into chunks of kLongChunk entries,
+    // one workgroup each, and their partial sums combined in chunk order: no single wave walks 50 000 entries
+    int nlong, nchunks;
+    const int* long_rows;        // nlong
+    const int64_t* long_chunk_ptr;   // nlong + 1: chunk range of each long row
+    const int64_t* chunk_q;      // nchunks + 1 would not do (rows are not adjacent): 2 per chunk, [begin, end)
+    double* long_partial;        // nchunks per right-hand side
 };
+constexpr int kLongRow = 4096;
+constexpr int kLongChunk = 2048;
 // norm_out[j] = ||e_j||_inf (not finite if any entry is non-finite).  nrhs > 1: column j of b, x, e
-// at stride ld; `partial` then needs nrhs * kNormParts doubles
-constexpr int kNormParts = 2048;
+// at stride ld; `partial` then needs nrhs * (kNormParts + 1) doubles
+constexpr int kNormParts = 2048;   // partial needs nrhs * (kNormParts + 1) doubles
 // flag_in/flag_out (nullable): *flag_out = (*flag_in != 0) as a double, so that a device status word rides along
 // with the norm read-back
 void launch_residual(const SpmvDev& A, const double* Kval, const double* b, const double* x, double* e,
@@ -180,6 +190,9 @@ void launch_residual(const SpmvDev& A, const double* Kval, const double* b, cons
 void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st, int nrhs = 1,
                      int64_t ld = 0);
 void launch_axpby_sum(double* y, const double* a, const double* b, int64_t n, hipStream_t st);   // y = a + b
+// val[q] = Kval[vmap[q]]: the CSR-ordered copy the residual streams (one gather per value update instead of one
+// per residual)
+void launch_gather_values(double* val, const double* Kval, const int* vmap, int64_t nnz, hipStream_t st);
 // b_j = [rx_j; rz_j; 0]: rx is n x nrhs (ld n), rz is m x nrhs (ld m), b is N x nrhs (ld N)
 void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m, int p, hipStream_t st,
                      int nrhs = 1);

@@ -38,6 +38,8 @@ CASES = [
     ("cfg5_small", lambda: problems.config5(n=300, npsd=6, psd_dim=6, nsoc=4, soc_dim=12)),
     ("cfg5_psd20", lambda: problems.config5(n=500, npsd=8, psd_dim=20, nsoc=4, soc_dim=50)),
     ("cfg3_small", lambda: problems.config3(nblocks=4, blk=120)),
+    # the budget row 1'x = 1 has n = 4500 > 4096 entries: the residual's long-row path
+    ("cfg3_longrow", lambda: problems.config3(nblocks=10, blk=450)),
 ]
 
 
@@ -238,6 +240,7 @@ MULTI_CASES = [
     ("mixed_with_psd", lambda: problems.small_mixed(seed=33)),
     # fronts too tall for 8 columns of LDS per workgroup: exercises the narrower column blocks
     ("unstructured_n3000", lambda: problems.config_unstructured(n=3000)),
+    ("cfg3_longrow", lambda: problems.config3(nblocks=10, blk=450)),
 ]
 
 
