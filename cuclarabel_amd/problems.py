@@ -207,3 +207,15 @@ def small_mixed(seed=7, n=40, nn=30, socs=(3, 4, 5, 12), psds=(2, 3, 4), zero=3,
     P = (B.T @ B).tocsc()
     A = sp.random(m, n, density=density, random_state=rng, data_rvs=rng.standard_normal).tocsc()
     return _finish(f"mixed_n{n}", P, A, cones, rng, seed=seed)
+
+
+def block_diagonal(pbs, name=None):
+    """Stack independent problems into ONE block-diagonal problem (P = blkdiag(P_j), A = blkdiag(A_j),
+    cones concatenated): the "block-diagonal problem batch" of BASELINE.json's north_star / cfg4.  One
+    KKT handle then factorises and solves all of them in the same per-level launches."""
+    P = sp.block_diag([pb.P for pb in pbs], format="csc")
+    A = sp.block_diag([pb.A for pb in pbs], format="csc")
+    cat = lambda key: np.concatenate([getattr(pb, key) for pb in pbs])
+    return Problem(name or f"blockdiag_{len(pbs)}x_{pbs[0].name}", _triu_csc(P), cat("q"), _csc(A), cat("b"),
+                   [c for pb in pbs for c in pb.cones], cat("s0"), cat("z0"), cat("x0"),
+                   dict(blocks=[(pb.n, pb.m) for pb in pbs]))

@@ -8,7 +8,7 @@ on this box's host (1 thread, AMD ordering) on a bounded sample.  cfg4 is run as
 of the batch: 8 independent problems on one GPU, back to back on one stream (--concurrent: one HIP
 stream and host thread per problem; measured 284 vs 252 units/s).
 
-Usage: python scripts/bench_configs.py [--configs 1,2,3,4,5] [--steps 10] [--cpu-units 2]
+Usage: python scripts/bench_configs.py [--configs 1,2,3,4,4b,5] [--steps 10] [--cpu-units 2]
 """
 import argparse
 import json
@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="1,2,3,4,5")
+    ap.add_argument("--configs", default="1,2,3,4,4b,5")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu-units", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
@@ -36,10 +36,13 @@ def main():
     from tests.oracle_bindings import make_oracle
 
     dev = torch.device("cuda", 0)
-    makers = {1: lambda: [problems.config1()], 2: lambda: [problems.config2()], 3: lambda: [problems.config3()],
-              4: lambda: [problems.config4(j=j) for j in range(8)], 5: lambda: [problems.config5()]}
-    for c in [int(t) for t in args.configs.split(",")]:
+    makers = {"1": lambda: [problems.config1()], "2": lambda: [problems.config2()], "3": lambda: [problems.config3()],
+              "4": lambda: [problems.config4(j=j) for j in range(8)], "5": lambda: [problems.config5()],
+              # the per-GPU share of cfg4 as ONE block-diagonal problem: all 8 in the same per-level launches
+              "4b": lambda: [problems.block_diagonal([problems.config4(j=j) for j in range(8)])]}
+    for c in args.configs.split(","):
         pbs = makers[c]()
+        per_unit = 8 if c == "4b" else 1
         t0 = time.perf_counter()
         sol = [HipKKTSolver(pb.P, pb.A, pb.cones) for pb in pbs]
         setup_s = time.perf_counter() - t0
@@ -92,7 +95,7 @@ def main():
         row = dict(config=c, problems_on_gpu=len(sol), N=info["N"], nnzK=info["nnzK"], nnzL=info["nnzL"],
                    nnzL_stored=info["nnzL_stored"], levels=info["nlevels"], max_front=info["max_front"],
                    factor_gflop=info["factor_flops"] / 1e9, setup_s=setup_s / len(sol),
-                   gpu_ms_per_unit=dt * 1e3, gpu_units_per_s=1.0 / dt,
+                   gpu_ms_per_unit=dt * 1e3 / per_unit, gpu_units_per_s=per_unit / dt, problems_per_handle=per_unit,
                    factor_ms=prof["factor_ms"] / max(prof["n_factor"], 1),
                    trisolve_ms=prof["trisolve_ms"] / max(prof["n_trisolve"], 1),
                    update_ms=prof["update_ms"] / max(prof["n_update"], 1),
@@ -117,7 +120,7 @@ def main():
             x = st["lx"].cpu().numpy()
             z = st["lz"].cpu().numpy()
             scale = max(np.abs(xo).max(), np.abs(zo).max())
-            row.update(cpu_ms_per_unit=med * 1e3, cpu_units_per_s=1.0 / med, cpu_nnzL=int(o.nnzL), cpu_cores=1,
+            row.update(cpu_ms_per_unit=med * 1e3 / per_unit, cpu_units_per_s=per_unit / med, cpu_nnzL=int(o.nnzL), cpu_cores=1,
                        speedup=med / dt, rel_err_vs_oracle=float(max(np.abs(x - xo).max(), np.abs(z - zo).max()) / scale))
         print(json.dumps(row), flush=True)
         del sol, state

@@ -346,3 +346,31 @@ def test_two_handles_on_their_own_streams_driven_concurrently():
         assert len(outs[i]) == 1
         for a, b in zip(outs[i][0], alone[i]):
             assert np.abs(a - b).max() / np.abs(b).max() < 1e-12
+
+
+def test_block_diagonal_batch_equals_the_individual_problems():
+    """cfg4's batching: independent problems stacked block-diagonally share one handle (and every kernel
+    launch); each block of the solution must be that problem's own solution."""
+    _, HipKKTSolver, _ = _hip()
+    pbs = [problems.config4(j=j, n=600) for j in range(3)]
+    pbb = problems.block_diagonal(pbs)
+    ks = HipKKTSolver(pbb.P, pbb.A, pbb.cones)
+    assert ks.kktsolver_update_from_sz(pbb.s0, pbb.z0)
+    rng = np.random.default_rng(2)
+    rxs = [rng.standard_normal(pb.n) for pb in pbs]
+    rzs = [rng.standard_normal(pb.m) for pb in pbs]
+    ks.kktsolver_setrhs(np.concatenate(rxs), np.concatenate(rzs))
+    X, Z = np.zeros(pbb.n), np.zeros(pbb.m)
+    assert ks.kktsolver_solve(X, Z)
+    ox = oz = 0
+    for pb, rx, rz in zip(pbs, rxs, rzs):
+        k1 = HipKKTSolver(pb.P, pb.A, pb.cones)
+        assert k1.kktsolver_update_from_sz(pb.s0, pb.z0)
+        k1.kktsolver_setrhs(rx, rz)
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert k1.kktsolver_solve(x, z)
+        scale = max(np.abs(x).max(), np.abs(z).max())
+        assert np.abs(X[ox:ox + pb.n] - x).max() / scale < 1e-9
+        assert np.abs(Z[oz:oz + pb.m] - z).max() / scale < 1e-9
+        ox += pb.n
+        oz += pb.m
