@@ -70,6 +70,7 @@ struct Launch {
 };
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
+static int kSideWinvBlocks = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 192;
 
 // The persistent top-of-tree solve kernel needs all its workgroups resident.  Two such kernels running
 // at the same time on one device (two handles on different streams) could each hold part of the CUs while
@@ -258,7 +259,8 @@ private:
                 ensure_capture_streams();
                 HIP_CHECK(hipEventRecord(ev_fork, st));
                 HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
-                launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, launches[q].tinv_begin, tinv_ncmax, cap_side);
+                // a bounded grid: the top panels need whole CUs (their LDS), which a full-width launch would hold
+                launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, launches[q].tinv_begin, tinv_ncmax, cap_side, kSideWinvBlocks);
                 HIP_CHECK(hipEventRecord(ev_join, cap_side));
                 eager_fork = true;
             }

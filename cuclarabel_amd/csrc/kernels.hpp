@@ -128,8 +128,9 @@ size_t solve_lds_bytes(int fmax, int ncmax);
 constexpr int kTopMaxFronts = 480;
 int top_solve_capacity(size_t lds);   // resident workgroups the device guarantees for the persistent kernel
 void launch_top_solve(const SolveArgs& a, int begin, int count, size_t lds, int* flags, int epoch, hipStream_t st);
+// max_blocks > 0: at most that many workgroups (each walks several supernodes)
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
-                 hipStream_t st);
+                 hipStream_t st, int max_blocks = 0);
 
 // factorisation of one level: small fronts (one wave each), panels (one workgroup each), then the
 // update blocks tiled over many workgroups

@@ -477,12 +477,10 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int
 //      T21 = -T_B * (L21 * T_A), two small products whose entries are independent -- two barriers
 //      per doubling instead of two per row.
 // Then M = L21 * T, one thread per row, 8 columns at a time against T in LDS.
-__global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ wst,
-                                              const int* __restrict__ list)
+__device__ inline void winv_one(const TreeDev& T, const double* __restrict__ fronts, double* __restrict__ wst, int s,
+                                double* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
-    const int s = list[blockIdx.x];
     const int c0 = T.sn_start[s];
     const int nc = T.sn_start[s + 1] - c0;
     const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
@@ -613,6 +611,18 @@ __global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restric
         }
     }
 }
+
+// count supernodes, any grid: a small grid keeps this off most CUs when it runs beside the tree's critical path
+__global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ wst,
+                                              const int* __restrict__ list, int count)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    for (int it = blockIdx.x; it < count; it += gridDim.x) {
+        winv_one(T, fronts, wst, list[it], smem);
+        __syncthreads();               // LDS is reused by the next supernode
+    }
+}
+
 
 constexpr int kSolveBS = 512;
 
@@ -1076,12 +1086,13 @@ void launch_top_solve(const SolveArgs& a, int begin, int count, size_t lds, int*
     hipLaunchKernelGGL(k_top_solve<512>, dim3(count), dim3(512), lds, st, a, begin, flags, epoch, count);
 }
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
-                 hipStream_t st)
+                 hipStream_t st, int max_blocks)
 {
     if (count <= 0) return;
     init_solve_lds();
     const size_t lds = (size_t)ncmax * (ncmax | 1) * sizeof(double);
-    hipLaunchKernelGGL(k_winv, dim3(count), dim3(256), lds, st, T, fronts, tinv, list);
+    const int grid = (max_blocks > 0 && max_blocks < count) ? max_blocks : count;
+    hipLaunchKernelGGL(k_winv, dim3(grid), dim3(256), lds, st, T, fronts, tinv, list, count);
 }
 
 }  // namespace hipkkt
