@@ -225,7 +225,7 @@ private:
     // side != nullptr: put the T = L11^{-1} kernels on that stream, forked after each level's panels
     void enqueue_factor(const double* d_Kval, const double* d_eps, hipStream_t st, hipStream_t side, bool want_stamps)
     {
-        flags.zero(st);
+        launch_zero_ints(flags.p, 2, st);
         FactorArgs a;
         a.T = tree();
         a.Kval = d_Kval;
@@ -374,7 +374,7 @@ public:
     {
         top_disabled = true;
         release_top();
-        HIP_CHECK(hipMemsetAsync(top_flags.p + 2 * top_count, 0, sizeof(int), stream));
+        launch_zero_ints(top_flags.p + 2 * top_count, 1, stream);
         std::fprintf(stderr, "[hipkkt] persistent top-of-tree kernel gave up waiting (GPU shared with another "
                              "resident kernel?); falling back to one launch per level\n");
     }
@@ -1403,7 +1403,7 @@ int hipkkt_kkt_update_cones(hipkkt_kkt_t h, const double* Hs, const double* soc_
             HIP_CHECK(hipMemcpyAsync(h->soc_v.p, soc_v, (size_t)K.sparse_len * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIP_CHECK(hipMemcpyAsync(h->soc_eta2.p, soc_eta2, (size_t)K.nsparse * sizeof(double), hipMemcpyHostToDevice, h->stream));
         }
-        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        launch_zero_ints(h->fail.p, 1, h->stream);
         h->scaling_valid = false;
         return kkt_update_device(h);
     });
@@ -1416,7 +1416,7 @@ int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double* d_s, const doubl
         if (h->psd_too_big)
             throw ArgError("update_from_sz: PSD cones with side > 48 are scaled by the caller; use hipkkt_kkt_update_cones");
         HIP_CHECK(hipSetDevice(h->device));
-        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        launch_zero_ints(h->fail.p, 1, h->stream);
         int pu = h->prof.begin(0, h->stream);
         launch_cone_scaling(h->cone_dev(), h->cone_state(), d_s, d_z, h->K.m, h->stream);
         h->prof.end(pu, h->stream);
@@ -1542,7 +1542,7 @@ static int kkt_solve_core(hipkkt_kkt_t h)
     if (!st.iterative_refinement_enable) {
         kkt_trisolve(h, h->b.p, x, false);       // nothing reads the abort word back on this path
         int bad = 0;
-        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        launch_zero_ints(h->fail.p, 1, h->stream);
         launch_check_finite(x, h->K.N, h->fail.p, h->stream);
         HIP_CHECK(hipMemcpyAsync(&bad, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1650,7 +1650,7 @@ static int kkt_solve_multi_core(hipkkt_kkt_t h, int k, int64_t* ir_out)
     trisolve(h->mB.p, h->mX.p);
     if (!st.iterative_refinement_enable) {
         int bad = 0;
-        HIP_CHECK(hipMemsetAsync(h->fail.p, 0, sizeof(int), h->stream));
+        launch_zero_ints(h->fail.p, 1, h->stream);
         for (int j = 0; j < k; ++j) launch_check_finite(h->mX.p + (size_t)j * N, N, h->fail.p, h->stream);
         HIP_CHECK(hipMemcpyAsync(&bad, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));

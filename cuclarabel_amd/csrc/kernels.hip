@@ -299,6 +299,15 @@ void launch_accept_columns(double* x, const double* cand, double* e, const doubl
     if (N <= 0 || nrhs <= 0) return;
     hipLaunchKernelGGL(k_accept_columns, dim3(grid_for(N, 256, 1024), nrhs), dim3(256), 0, st, x, cand, e, e2, mask, N);
 }
+__global__ void k_zero_ints(int* __restrict__ p, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+void launch_zero_ints(int* p, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_zero_ints, dim3(grid_for(n, 64, 256)), dim3(64), 0, st, p, n);
+}
 __global__ void k_check_finite(const double* __restrict__ v, int n, int* __restrict__ flag)
 {
     bool bad = false;

@@ -201,6 +201,8 @@ void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m
 void launch_accept_columns(double* x, const double* cand, double* e, const double* e2, const int* mask, int N,
                            int nrhs, hipStream_t st);
 void launch_check_finite(const double* v, int n, int* flag, hipStream_t st);
+// p[0..n) = 0 with a kernel: a small hipMemsetAsync stalls the stream for ~40 us on this stack
+void launch_zero_ints(int* p, int n, hipStream_t st);
 
 // ---- cone scalings on the device (update_scaling! + get_Hs!, src/cones/coneops_*.jl)
 struct ConeDev {
