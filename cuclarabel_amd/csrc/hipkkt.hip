@@ -895,6 +895,7 @@ struct hipkkt_kkt_s {
     bool has_psd = false, psd_too_big = false, scaling_valid = false;
     double last_eps = 0;
     int64_t last_ir = 0;
+    bool spec_ir = false;            // the previous solve needed refinement: enqueue the first round ahead
     // level C (DefaultKKTSystem on the device, kktsystem.jl:21-215)
     DBuf<double> lam;                                        // scaled point, m
     DBuf<double> sq, snegq, sb, sx1, sz1, sx2, sz2, sworkx, sworkz, sconic, spa, spb;
@@ -1507,20 +1508,29 @@ static SpmvDev kkt_spmv(hipkkt_kkt_t h)
     return A;
 }
 
-// e = b - K xi, returns ||e||_inf via pinned read-back (slot 1), optionally ||b||_inf too (slot 2);
-// slot 3 carries the persistent solve kernel's abort word along (*top_abort, nullable)
-static double kkt_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, double* normb, bool* top_abort)
+// e = b - K xi; ||e||_inf -> scal[slot], optionally ||b||_inf -> scal[2]; scal[3] carries the persistent solve
+// kernel's abort word along.  Nothing is read back here.
+static void kkt_enqueue_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, int slot)
 {
     const SpmvDev A = kkt_spmv(h);
     int pr = h->prof.begin(3, h->stream);
-    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + 1, h->stream, 1, 0,
+    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + slot, h->stream, 1, 0,
                     h->eng->top_abort_word(), h->scal.p + 3);
     if (with_normb) launch_norm_inf(h->b.p, h->K.N, h->partial.p, h->scal.p + 2, h->stream);
     h->prof.end(pr, h->stream);
-    HIP_CHECK(hipMemcpyAsync(h->pin->h + 1, h->scal.p + 1, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+}
+// one read-back of scal[1..4] = {norme, normb, abort, speculative norme}; synchronises
+static void kkt_read_scalars(hipkkt_kkt_t h, bool* top_abort)
+{
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 1, h->scal.p + 1, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    if (with_normb) *normb = h->pin->h[2];
     if (top_abort) *top_abort = h->eng->top_abort_word() != nullptr && h->pin->h[3] != 0.0;
+}
+static double kkt_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, double* normb, bool* top_abort)
+{
+    kkt_enqueue_refine_error(h, xi, with_normb, 1);
+    kkt_read_scalars(h, top_abort);
+    if (with_normb) *normb = h->pin->h[2];
     return h->pin->h[1];
 }
 
@@ -1550,10 +1560,25 @@ static int kkt_solve_core(hipkkt_kkt_t h)
     }
     double normb = 0.0;
     bool gave_up = false;
+    // When the previous solve on this handle needed a refinement round (the rule, with the static regulariser
+    // on), the first round is enqueued before the first residual has been read back: one host round trip per
+    // solve instead of two.  If the first residual already met the tolerance the extra sweep is discarded
+    // (x is untouched by it) and the next solve does not speculate.
+    bool spec = h->spec_ir && st.iterative_refinement_max_iter >= 1;
     kkt_trisolve(h, h->b.p, x);
-    double norme = kkt_refine_error(h, x, true, &normb, &gave_up);
+    kkt_enqueue_refine_error(h, x, true, 1);
+    if (spec) {
+        kkt_trisolve(h, h->e.p, dx);
+        launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
+        kkt_enqueue_refine_error(h, dx, false, 4);
+    }
+    kkt_read_scalars(h, &gave_up);
+    double norme = h->pin->h[1];
+    normb = h->pin->h[2];
+    double spec_norme = h->pin->h[4];
     if (gave_up) {                                               // never expected; see TopOwner
         h->eng->top_gave_up();
+        spec = false;
         kkt_trisolve(h, h->b.p, x);
         norme = kkt_refine_error(h, x, true, &normb, nullptr);
     }
@@ -1561,18 +1586,21 @@ static int kkt_solve_core(hipkkt_kkt_t h)
     for (int i = 0; i < st.iterative_refinement_max_iter; ++i) {
         if (norme <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb) break;
         const double lastnorme = norme;
-        // dx = K^{-1} e; prospective solution x + dx.  The residual overwrites e, so a repeat needs e back:
-        // only the (never expected) give-up path pays for the copy
-        kkt_trisolve(h, h->e.p, dx);
-        launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
-        norme = kkt_refine_error(h, dx, false, nullptr, &gave_up);
-        if (gave_up) {
-            // e was overwritten with the candidate's residual; rebuild e = b - K x and repeat the round
-            h->eng->top_gave_up();
-            (void)kkt_refine_error(h, x, false, nullptr, nullptr);
+        if (i == 0 && spec) {
+            norme = spec_norme;                                  // this round is already on the device
+        } else {
+            // dx = K^{-1} e; prospective solution x + dx
             kkt_trisolve(h, h->e.p, dx);
             launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
-            norme = kkt_refine_error(h, dx, false, nullptr, nullptr);
+            norme = kkt_refine_error(h, dx, false, nullptr, &gave_up);
+            if (gave_up) {
+                // e was overwritten with the candidate's residual; rebuild e = b - K x and repeat the round
+                h->eng->top_gave_up();
+                (void)kkt_refine_error(h, x, false, nullptr, nullptr);
+                kkt_trisolve(h, h->e.p, dx);
+                launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
+                norme = kkt_refine_error(h, dx, false, nullptr, nullptr);
+            }
         }
         h->last_ir++;
         h->prof.acc.ir_iterations++;
@@ -1586,6 +1614,7 @@ static int kkt_solve_core(hipkkt_kkt_t h)
     }
     h->cur_x = x;
     h->cur_dx = dx;
+    h->spec_ir = h->last_ir >= 1;
     return HIPKKT_OK;
 }
 
