@@ -374,3 +374,133 @@ def test_block_diagonal_batch_equals_the_individual_problems():
         assert np.abs(Z[oz:oz + pb.m] - z).max() / scale < 1e-9
         ox += pb.n
         oz += pb.m
+
+
+# ---- settings that change the path's behaviour ---------------------------------------
+def test_dynamic_regularisation_count_and_values_match_oracle():
+    """P = 0 and no static regularisation: the x-block pivots are exactly 0, so the sign rule
+    D = +delta (directldl_qdldl.jl:18-25, settings.jl:123-124) must fire n times, as in the oracle."""
+    _lib, HipKKTSolver, _ = _hip()
+    from tests.oracle_bindings import OracleKKT, default_settings as orc_settings
+    n = m = 40
+    P = sp.csc_matrix((n, n))
+    A = sp.identity(m, format="csc")
+    cones = [NonnegativeConeT(m)]
+    # natural order eliminates the x block first (its pivots are the zeros); a fill-reducing order may reach
+    # them after their neighbours, so the count is compared with the oracle under the same permutation
+    for ordering, expect in ((_lib.ORDER_NATURAL, n), (_lib.ORDER_ND, None)):
+        kq = HipKKTSolver(P, A, cones, settings=_lib.default_settings(static_regularization_enable=0, ordering=ordering))
+        kq.profile_enable(True)
+        kq.profile_reset()
+        assert kq.kktsolver_update(np.ones(m))                  # identity scaling: Hs = 1
+        oq = OracleKKT(P, A, cones, perm=kq.perm(), settings=orc_settings(static_reg_enable=0))
+        oq.set_identity_scaling()
+        assert oq.kktsolver_update()
+        assert kq.profile()["dynamic_regularizations"] == oq.num_dyn_regularized
+        if expect is not None:
+            assert oq.num_dyn_regularized == expect
+    ks = HipKKTSolver(P, A, cones, settings=_lib.default_settings(static_regularization_enable=0, ordering=_lib.ORDER_NATURAL))
+    assert ks.kktsolver_update(np.ones(m))
+    o = OracleKKT(P, A, cones, perm=ks.perm(), settings=orc_settings(static_reg_enable=0))
+    o.set_identity_scaling()
+    assert o.kktsolver_update() and o.num_dyn_regularized == n
+    rng = np.random.default_rng(0)
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    ks.kktsolver_setrhs(rx, rz)
+    o.kktsolver_setrhs(rx, rz)
+    x, z = np.zeros(n), np.zeros(m)
+    ok = ks.kktsolver_solve(x, z)
+    oko, xo, zo = o.kktsolver_solve()
+    assert ok == oko
+    scale = max(np.abs(xo).max(), np.abs(zo).max())
+    assert max(np.abs(x - xo).max(), np.abs(z - zo).max()) / scale < 1e-9
+    assert ks.last_ir_iterations == o.last_ir_iters
+
+
+def test_iterative_refinement_disabled_returns_the_bare_ldl_solve():
+    """settings.iterative_refinement_enable = false (kktsolver_directldl.jl:366-369): the solution of the
+    regularised system, success = all finite."""
+    _lib, HipKKTSolver, _ = _hip()
+    from tests.oracle_bindings import default_settings as orc_settings
+    pb = problems.config2(n=1500)
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=_lib.default_settings(iterative_refinement_enable=0))
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    from tests.oracle_bindings import make_oracle
+    o = make_oracle(pb, perm=ks.perm(), settings=orc_settings(ir_enable=0))
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    rng = np.random.default_rng(1)
+    rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    ks.kktsolver_setrhs(rx, rz)
+    o.kktsolver_setrhs(rx, rz)
+    x, z = np.zeros(pb.n), np.zeros(pb.m)
+    assert ks.kktsolver_solve(x, z)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok and ks.last_ir_iterations == 0 and o.last_ir_iters == 0
+    scale = max(np.abs(xo).max(), np.abs(zo).max())
+    assert max(np.abs(x - xo).max(), np.abs(z - zo).max()) / scale < 1e-9
+    # and it is NOT the refined solution: the regularisation shows at the 1e-8 level
+    ks2 = HipKKTSolver(pb.P, pb.A, pb.cones)
+    assert ks2.kktsolver_update_from_sz(pb.s0, pb.z0)
+    ks2.kktsolver_setrhs(rx, rz)
+    x2, z2 = np.zeros(pb.n), np.zeros(pb.m)
+    assert ks2.kktsolver_solve(x2, z2) and ks2.last_ir_iterations >= 1
+
+
+@pytest.mark.parametrize("ordering", ["amd", "nd_small_leaves"])
+def test_other_orderings_give_the_same_solution(ordering):
+    """The reference's ordering (AMD, dense scale 1.5) and a nested dissection with tiny leaves: the solution
+    of K x = b does not depend on the elimination order beyond round-off."""
+    _lib, HipKKTSolver, _ = _hip()
+    pb = problems.config2(n=2500, long_range_frac=0.01)
+    st = _lib.default_settings(ordering=_lib.ORDER_AMD) if ordering == "amd" else _lib.default_settings(nd_leaf_size=40)
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
+    ref = HipKKTSolver(pb.P, pb.A, pb.cones)
+    assert not np.array_equal(ks.perm(), ref.perm())
+    rng = np.random.default_rng(8)
+    rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    sols = []
+    for k in (ks, ref):
+        assert k.kktsolver_update_from_sz(pb.s0, pb.z0)
+        k.kktsolver_setrhs(rx, rz)
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert k.kktsolver_solve(x, z)
+        sols.append(np.concatenate([x, z]))
+    assert np.abs(sols[0] - sols[1]).max() / np.abs(sols[1]).max() < 1e-9
+
+
+def test_level_A_one_based_indices_as_julia_passes_them():
+    """index_base = 1: colptr / rowval / update_values indices exactly as a Julia SparseMatrixCSC holds them
+    (integration/HipKKTExt.jl passes them through untouched)."""
+    import ctypes as C
+    _lib, _, HipDirectLDLSolver = _hip()
+    from cuclarabel_amd._lib import check, f64, i64, ptr
+    from tests.oracle_bindings import make_oracle
+    pb = problems.small_mixed(seed=12, psds=(), zero=0)    # (zero-cone rows have -1e-8 pivots: bare solves then agree to 1e-6 only)
+    o = make_oracle(pb)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    K = o.K().copy()
+    K.data[o.maps()["diag_full"]] += o.last_regularizer * o.dsigns()
+    L = _lib.lib()
+    h = C.c_void_p()
+    cp, ri, nz, ds = i64(K.indptr + 1), i64(K.indices + 1), f64(np.zeros_like(K.data)), i64(o.dsigns())
+    st = _lib.default_settings()
+    assert L.hipkkt_ldl_create(C.byref(h), K.shape[0], ptr(cp), ptr(ri), ptr(nz), ptr(ds), C.byref(st), 1) == 0
+    try:
+        idx = i64(np.arange(1, K.nnz + 1))                     # 1-based positions into K.nzval
+        vals = f64(K.data)
+        assert check(L.hipkkt_ldl_update_values(h, ptr(idx), ptr(vals), idx.size), "update_values")
+        half = i64(np.arange(1, K.nnz + 1)[: K.nnz // 2])
+        assert check(L.hipkkt_ldl_scale_values(h, ptr(half), 2.0, half.size), "scale_values")
+        assert check(L.hipkkt_ldl_scale_values(h, ptr(half), 0.5, half.size), "scale_values")
+        assert check(L.hipkkt_ldl_refactor(h), "refactor")
+        b = np.random.default_rng(3).standard_normal(K.shape[0])
+        x = np.zeros_like(b)
+        assert check(L.hipkkt_ldl_solve(h, ptr(x), ptr(b)), "solve")
+        perm = np.zeros(K.shape[0], dtype=np.int64)
+        assert check(L.hipkkt_ldl_get_perm(h, ptr(perm)), "get_perm")
+    finally:
+        L.hipkkt_ldl_destroy(h)
+    o2 = make_oracle(pb, perm=perm)
+    assert o2.update_scaling(pb.s0, pb.z0) and o2.kktsolver_update()
+    xo = o2.ldl_solve(b)
+    assert np.abs(x - xo).max() / np.abs(xo).max() < 1e-9
