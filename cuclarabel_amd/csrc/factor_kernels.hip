@@ -242,17 +242,9 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     }
     HIPKKT_STAMP(A, 3);
     long long t_i = 0, t_ii = 0, t_iii = 0, t0 = 0;
-    // ---- 4. blocked right-looking factorisation inside LDS
-    for (int kb = 0; kb < nc; kb += NB) {
-        const int w = min(NB, nc - kb);
-        __syncthreads();
-        if (A.stamps) t0 = wall_clock64();
-        // (i) diagonal 16 x 16 block by wave 0, wave-synchronous through LDS, in four micro-steps of four
-        //     pivots.  Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3).  Per micro-step every
-        //     lane redundantly factors the 4 x 4 diagonal micro-block in registers (no second broadcast),
-        //     solves its own row against it, and lanes right of it apply the rank-4 update: two LDS
-        //     round trips per four pivots instead of one per pivot.
-        if (wv == 0) {
+    // the 16 x 16 diagonal block kb (see (i) below) as a callable: with look-ahead it runs on wave 0 while the
+    // other waves finish the trailing update of the previous block
+    auto diag_block = [&](const int kb, const int w) {
             const int i = lane & 15, g = lane >> 4;
             const double my_sg = (lane < w) ? (double)T.psign[c0 + kb + lane] : 1.0;
             int nreg = 0;
@@ -361,7 +353,19 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 if (nreg) atomicAdd(&A.flags[0], nreg);
                 if (bad) A.flags[1] = 1;
             }
-        }
+            };
+    // ---- 4. blocked right-looking factorisation inside LDS
+    for (int kb = 0; kb < nc; kb += NB) {
+        const int w = min(NB, nc - kb);
+        __syncthreads();
+        if (A.stamps) t0 = wall_clock64();
+        const bool ahead_done = kb > 0;          // factored during the previous block's trailing update
+        // (i) diagonal 16 x 16 block by wave 0, wave-synchronous through LDS, in four micro-steps of four
+        //     pivots.  Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3).  Per micro-step every
+        //     lane redundantly factors the 4 x 4 diagonal micro-block in registers (no second broadcast),
+        //     solves its own row against it, and lanes right of it apply the rank-4 update: two LDS
+        //     round trips per four pivots instead of one per pivot.
+        if (wv == 0 && !ahead_done) diag_block(kb, w);
         __syncthreads();
         if (A.stamps) { long long t1 = wall_clock64(); t_i += t1 - t0; t0 = t1; }
         // (ii) rows below the block: L(i,j) = (A(i,j) - sum_{t<j} L(i,t) * [d_t L(j,t)]) / d_j, a thread per row.
@@ -387,6 +391,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         if (A.stamps) { long long t1 = wall_clock64(); t_ii += t1 - t0; t0 = t1; }
         // (iii) trailing update of the remaining panel columns on the matrix cores: 16 x 16 tiles,
         //       C(i,j) -= sum_k L(i,k) * Bd(k,j) with Bd(k,c) = d_k L(g0 + c, k) built once per block.
+        //       Look-ahead: the column tile that holds the NEXT diagonal block goes first (all waves); then
+        //       wave 0 factors that block while the other waves update the rest.
         const int g0 = kb + w;
         const int Tc = nc - g0, Tr = f - g0;
         if (Tc > 0) {
@@ -398,9 +404,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             __syncthreads();
             const int ml = lane & 15, mk = lane >> 4;
             const int ntr = (Tr + 15) >> 4, ntc = Tcp >> 4;
-            for (int t = wv; t < ntr * ntc; t += NW) {
-                const int tc = t / ntr, tr = t - tc * ntr;
-                if (tr < tc) continue;                           // wholly above the diagonal
+            auto tile = [&](const int tr, const int tc) {
                 const int i0 = g0 + 16 * tr, j0 = 16 * tc;
                 double av[4], bv[4];
 #pragma unroll
@@ -416,6 +420,17 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 for (int r = 0; r < 4; ++r) {
                     const int row = i0 + mk + 4 * r, col = g0 + j0 + ml;
                     if (row < f && col < nc && row >= col) P[row + col * f] -= acc[r];
+                }
+            };
+            for (int tr = wv; tr < ntr; tr += NW) tile(tr, 0);
+            __syncthreads();
+            if (wv == 0) {
+                diag_block(g0, min(NB, nc - g0));
+            } else {
+                for (int t = wv - 1; t < ntr * (ntc - 1); t += NW - 1) {
+                    const int tc = 1 + t / ntr, tr = t - (tc - 1) * ntr;
+                    if (tr < tc) continue;                       // wholly above the diagonal
+                    tile(tr, tc);
                 }
             }
         }
