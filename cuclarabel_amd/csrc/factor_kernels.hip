@@ -145,6 +145,19 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
 //               update by 4x4 register tiles whose rows are 64 apart (bank-conflict free).
 // =====================================================================================
 typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// 1/d from the hardware seed (v_rcp_f64) and two Newton steps: within an ulp of the quotient at a fraction of the
+// latency of the IEEE division sequence -- it sits on the serial pivot chain.  Zeros and infinities come out of
+// v_rcp_f64 as the division would give them, and a NaN stays a NaN.
+__device__ inline double fast_recip(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    if (isfinite(r) && r != 0.0) {
+        r = fma(fma(-d, r, 1.0), r, r);
+        r = fma(fma(-d, r, 1.0), r, r);
+    }
+    return r;
+}
 constexpr int NB = 16;
 constexpr int kBdCols = 128;       // trailing columns per block whose d*L copy is kept (nc - 16 <= 128 enforced by host)
 
@@ -197,11 +210,13 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     double* Lb = smem + 2 * NB;                   // NB x NB: Lb[j*NB + t] = d_t * L(j,t), t < j
     double* colb = smem + 2 * NB + NB * NB;       // 4*NB: micro-block broadcast buffer
     double* Bd = smem + 6 * NB + NB * NB;         // NB x kBdCols: d_k * L(j,k) for the trailing columns
-    double* P = Bd + NB * kBdCols;                // f x nc, ld f (+ 256 doubles of slack behind it)
+    double* sgn = Bd + NB * kBdCols;              // kBdCols + NB: expected pivot signs of this front's columns
+    double* P = sgn + kBdCols + NB;               // f x nc, ld f (+ 256 doubles of slack behind it)
 
     HIPKKT_STAMP(A, 0);
     const long long clk0 = A.stamps ? clock64() : 0;
-    // ---- 1. zero the panel
+    // ---- 1. zero the panel (and fetch the pivot signs: the serial diagonal step must not wait for global memory)
+    for (int k = tid; k < nc; k += BS) sgn[k] = (double)T.psign[c0 + k];
     for (int i = tid; i < f * nc; i += BS) P[i] = 0.0;
     __syncthreads();
     HIPKKT_STAMP(A, 1);
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     __syncthreads();
     if (A.eps) {
         const double eps = *A.eps;
-        for (int k = tid; k < nc; k += BS) P[k + k * f] += eps * (double)T.psign[c0 + k];
+        for (int k = tid; k < nc; k += BS) P[k + k * f] += eps * sgn[k];
     }
     __syncthreads();
     HIPKKT_STAMP(A, 2);
@@ -245,114 +260,66 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     // the 16 x 16 diagonal block kb (see (i) below) as a callable: with look-ahead it runs on wave 0 while the
     // other waves finish the trailing update of the previous block
     auto diag_block = [&](const int kb, const int w) {
-            const int i = lane & 15, g = lane >> 4;
-            const double my_sg = (lane < w) ? (double)T.psign[c0 + kb + lane] : 1.0;
-            int nreg = 0;
-            bool bad = false;
-            double a4[4];
+        // Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3).  Pivot by pivot, fully unrolled: the lanes
+        // owning column k put it into LDS, every lane reads back its row's entry, the entries of its own four
+        // columns' rows and the pivot (one LDS round trip per pivot, ~35 dependent instructions), while the
+        // reciprocal of the pivot is formed beside it.  Same operation order per entry as the scalar algorithm.
+        const int i = lane & 15, g = lane >> 4;
+        const double my_sg = (lane < w) ? sgn[kb + lane] : 1.0;      // lane k: expected sign of pivot k
+        int nreg = 0;
+        bool bad = false;
+        double a4[4], lout[4], vout[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = 4 * g + q;
-                a4[q] = (i < w && j <= i) ? P[(kb + i) + (kb + j) * f] : 0.0;
-            }
-            double* mbuf = colb;              // 64 doubles: row i's four values of the current micro column block
-            double* vbuf = Lb;                // 64 doubles: unscaled v(i,t) = l(i,t) d_t, reused before Lb is filled
+        for (int q = 0; q < 4; ++q) {
+            const int j = 4 * g + q;
+            a4[q] = (i < w && j <= i) ? P[(kb + i) + (kb + j) * f] : 0.0;
+            lout[q] = 0.0;
+            vout[q] = 0.0;
+        }
+        double dmine = 1.0, dimine = 1.0;                            // lane k keeps d_k and 1 / d_k
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (4 * m < w) {
-                    if (g == m) {
+        for (int k = 0; k < NB; ++k) {
+            if (k < w) {
+                const int gk = k >> 2, qk = k & 3;
+                double* cb = colb + (k & 1) * NB;                     // two buffers: no wait between pivots
+                if (g == gk) cb[i] = a4[qk];
+                WAVE_FENCE();
+                const double ci = cb[i];
+                double cj[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) mbuf[i * 4 + q] = a4[q];
-                    }
-                    WAVE_FENCE();
-                    double x[4][4];
+                for (int t = 0; t < 4; ++t) cj[t] = cb[4 * g + t];
+                double d = cb[k];
+                const double sg = rl_f64(my_sg, k);
+                const bool reg = (d * sg < A.dyn_eps);               // QDLDL's sign rule at pivot time
+                if (reg) d = sg * A.dyn_delta;
+                nreg += reg ? 1 : 0;
+                const double di = fast_recip(d);
+                bad = bad || !isfinite(di);
+                const double li = ci * di;
+                if (g == gk) {
+                    if (i > k) { lout[qk] = li; vout[qk] = ci; }
+                    else if (i == k) lout[qk] = d;
+                }
+                if (lane == k) { dmine = d; dimine = di; }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int c = 0; c <= r; ++c) x[r][c] = mbuf[(4 * m + r) * 4 + c];
-                    double d[4], di[4], v[4][4], l[4][4];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        // pivot p of the micro-block: v(r,p) = x(r,p) - sum_{t<p} l(r,t) v(p,t), r >= p
-#pragma unroll
-                        for (int r = p; r < 4; ++r) {
-                            double acc = x[r][p];
-#pragma unroll
-                            for (int t = 0; t < p; ++t) acc = fma(-l[r][t], v[p][t], acc);
-                            v[r][p] = acc;
-                        }
-                        double dd = v[p][p];
-                        const int k = 4 * m + p;
-                        if (k < w) {
-                            const double sg = rl_f64(my_sg, k);
-                            const bool reg = (dd * sg < A.dyn_eps);
-                            if (reg) dd = sg * A.dyn_delta;
-                            nreg += reg ? 1 : 0;
-                        } else {
-                            dd = 1.0;
-                        }
-                        d[p] = dd;
-                        di[p] = 1.0 / dd;
-                        bad = bad || !isfinite(di[p]);
-#pragma unroll
-                        for (int r = p + 1; r < 4; ++r) l[r][p] = v[r][p] * di[p];
-                    }
-                    // my own row against the micro-block: vr(t) = r_t - sum_{u<t} lr(u) v(t,u); lr(t) = vr(t)/d_t
-                    double rr[4], vr[4], lr[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) rr[t] = mbuf[i * 4 + t];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        double acc = rr[t];
-#pragma unroll
-                        for (int u = 0; u < t; ++u) acc = fma(-lr[u], v[t][u], acc);
-                        vr[t] = acc;
-                        lr[t] = acc * di[t];
-                    }
-                    if (g == m) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            vbuf[i * 4 + t] = vr[t];
-                            const int k = 4 * m + t;
-                            if (i > k) a4[t] = lr[t];          // scaled L(i,k)
-                            else if (i == k) a4[t] = d[t];
-                        }
-                    }
-                    if (lane == 0) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { sh_d[4 * m + t] = d[t]; sh_dinv[4 * m + t] = di[t]; }
-                    }
-                    WAVE_FENCE();
-                    // rank-4 update of the columns to the right: a(i,j) -= sum_t l(i,t) v(j,t), j = 4g+q > 4m+3
-                    if (g > m) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int j = 4 * g + q;
-                            double acc = a4[q];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) acc = fma(-lr[t], vbuf[j * 4 + t], acc);
-                            if (j <= i) a4[q] = acc;
-                        }
-                    }
-                    WAVE_FENCE();
+                for (int t = 0; t < 4; ++t) {
+                    const int j = 4 * g + t;
+                    if (j > k && j <= i) a4[t] = fma(-li, cj[t], a4[t]);
                 }
             }
+        }
+        if (lane < NB) { sh_d[lane] = dmine; sh_dinv[lane] = dimine; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = 4 * g + q;
-                if (i < w && j <= i) P[(kb + i) + (kb + j) * f] = a4[q];
-            }
-            WAVE_FENCE();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = 4 * g + q;
-                if (i < w && j < i) Lb[i * NB + j] = a4[q] * sh_d[j];
-            }
-            if (lane < w) A.Dinv[c0 + kb + lane] = sh_dinv[lane];
-            if (lane == 0) {
-                if (nreg) atomicAdd(&A.flags[0], nreg);
-                if (bad) A.flags[1] = 1;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int j = 4 * g + q;
+            if (i < w && j <= i) P[(kb + i) + (kb + j) * f] = lout[q];          // scaled L below, d on the diagonal
+            if (i < w && j < i) Lb[i * NB + j] = vout[q];                       // d_j L(i,j): what the rows below need
+        }
+        if (lane < w) A.Dinv[c0 + kb + lane] = dimine;
+        if (lane == 0) {
+            if (nreg) atomicAdd(&A.flags[0], nreg);
+            if (bad) A.flags[1] = 1;
+        }
             };
     // ---- 4. blocked right-looking factorisation inside LDS
     for (int kb = 0; kb < nc; kb += NB) {
@@ -360,11 +327,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         __syncthreads();
         if (A.stamps) t0 = wall_clock64();
         const bool ahead_done = kb > 0;          // factored during the previous block's trailing update
-        // (i) diagonal 16 x 16 block by wave 0, wave-synchronous through LDS, in four micro-steps of four
-        //     pivots.  Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3).  Per micro-step every
-        //     lane redundantly factors the 4 x 4 diagonal micro-block in registers (no second broadcast),
-        //     solves its own row against it, and lanes right of it apply the rank-4 update: two LDS
-        //     round trips per four pivots instead of one per pivot.
+        // (i) diagonal 16 x 16 block by wave 0, wave-synchronous through LDS (diag_block above)
         if (wv == 0 && !ahead_done) diag_block(kb, w);
         __syncthreads();
         if (A.stamps) { long long t1 = wall_clock64(); t_i += t1 - t0; t0 = t1; }
@@ -598,7 +561,7 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
 size_t panel_lds_bytes(int fmax, int panel_max)
 {
     (void)fmax;
-    return ((size_t)6 * NB + NB * NB + NB * kBdCols + (size_t)panel_max + 256) * sizeof(double);
+    return ((size_t)6 * NB + NB * NB + NB * kBdCols + (kBdCols + NB) + (size_t)panel_max + 256) * sizeof(double);
 }
 
 static void init_factor_lds()
