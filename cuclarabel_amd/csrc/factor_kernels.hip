@@ -147,16 +147,13 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // 1/d from the hardware seed (v_rcp_f64) and two Newton steps: within an ulp of the quotient at a fraction of the
-// latency of the IEEE division sequence -- it sits on the serial pivot chain.  Zeros and infinities come out of
-// v_rcp_f64 as the division would give them, and a NaN stays a NaN.
+// latency of the IEEE division sequence -- it sits on the serial pivot chain.
 __device__ inline double fast_recip(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
-    if (isfinite(r) && r != 0.0) {
-        r = fma(fma(-d, r, 1.0), r, r);
-        r = fma(fma(-d, r, 1.0), r, r);
-    }
-    return r;
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;          // d = 0 or not finite: NaN (the caller only asks whether the result is finite)
 }
 constexpr int NB = 16;
 constexpr int kBdCols = 128;       // trailing columns per block whose d*L copy is kept (nc - 16 <= 128 enforced by host)
@@ -277,6 +274,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             vout[q] = 0.0;
         }
         double dmine = 1.0, dimine = 1.0;                            // lane k keeps d_k and 1 / d_k
+        const double inv_delta = 1.0 / A.dyn_delta;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             if (k < w) {
@@ -288,12 +286,16 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 double cj[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) cj[t] = cb[4 * g + t];
-                double d = cb[k];
+                WAVE_FENCE();
+                // the pivot comes straight out of its owner's register (scalar broadcast), so its reciprocal is
+                // under way while the column is still on its way through LDS
+                double d = rl_f64(a4[qk], k + 16 * gk);
                 const double sg = rl_f64(my_sg, k);
                 const bool reg = (d * sg < A.dyn_eps);               // QDLDL's sign rule at pivot time
-                if (reg) d = sg * A.dyn_delta;
+                // the reciprocal starts from the raw pivot; the regularised case has a constant one
+                double di = fast_recip(d);
+                if (reg) { d = sg * A.dyn_delta; di = sg * inv_delta; }
                 nreg += reg ? 1 : 0;
-                const double di = fast_recip(d);
                 bad = bad || !isfinite(di);
                 const double li = ci * di;
                 if (g == gk) {
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int j = 4 * g + t;
-                    if (j > k && j <= i) a4[t] = fma(-li, cj[t], a4[t]);
+                    if (j > k) a4[t] = fma(-li, cj[t], a4[t]);      // (entries above the diagonal are never read)
                 }
             }
         }
