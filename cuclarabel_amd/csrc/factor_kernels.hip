@@ -161,9 +161,17 @@ constexpr int kBdCols = 128;       // trailing columns per block whose d*L copy 
 // apply the extend-add items [i0, i1) (whole columns, owned by this wave) into the LDS panel P (ld f):
 // eight items in flight -- one round of descriptor loads, one round of (rel, value) loads, then
 // the LDS adds in item order
-__device__ inline void apply_items_panel(const TreeDev& T, const double* __restrict__ upd, double* P, int f,
-                                         int64_t i0, int64_t i1, int lane)
+__device__ inline int64_t uniform_i64(int64_t v)
 {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffff));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+__device__ inline void apply_items_panel(const TreeDev& T, const double* __restrict__ upd, double* P, int f,
+                                         int64_t i0_, int64_t i1_, int lane)
+{
+    // the range is the same for every lane: say so, and the descriptors travel through the scalar cache
+    const int64_t i0 = uniform_i64(i0_), i1 = uniform_i64(i1_);
     for (int64_t ii = i0; ii < i1; ii += 8) {
         ExtItem it[8];
         double v[8];
@@ -181,10 +189,7 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (tg[q] >= 0) P[tg[q]] += v[q];
-            // long child columns: remaining 64-row blocks
-            for (int t = lane + 64; t < it[q].cnt; t += 64)
-                P[T.rel[it[q].relstart + t] + it[q].tcol * f] += upd[it[q].uoff + t];
+            if (tg[q] >= 0) P[tg[q]] += v[q];          // (a piece has at most 64 rows)
         }
     }
 }

@@ -637,39 +637,71 @@ private:
                 for (int64_t q = S.rowptr[c]; q < S.rowptr[c + 1]; ++q) ptr[lbase(p) + S.rel[q] + 1]++;
             }
             for (int64_t i = 0; i < nloc; ++i) ptr[i + 1] += ptr[i];
-            static_assert(sizeof(ExtItem) == 32, "ExtItem layout");
-            std::vector<ExtItem> items((size_t)ptr[nloc]);
+            // gather lists of the forward sweep: one entry per child row, keyed by the receiving local row
             std::vector<int> gsrc((size_t)ptr[nloc]);
-            std::vector<int64_t> nxt(ptr.begin(), ptr.end() - 1);
-            for (int p = 0; p < S.nsuper; ++p)
-                for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {     // children in fixed order
-                    int c = S.child_idx[e];
-                    int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
-                    for (int b = 0; b < nbc; ++b) {
-                        int64_t q = S.rowptr[c] + b;
-                        int64_t d = nxt[lbase(p) + S.rel[q]]++;
-                        ExtItem it;
-                        it.uoff = S.upd_off[c] + (int64_t)b * nbc + b;
-                        it.relstart = (int)q;
-                        it.cnt = nbc - b;
-                        it.child = c;
-                        it.b = b;
-                        it.tcol = S.rel[q];
-                        it.pad = 0;
-                        items[d] = it;
-                        gsrc[d] = (int)q;
+            {
+                std::vector<int64_t> nxt(ptr.begin(), ptr.end() - 1);
+                for (int p = 0; p < S.nsuper; ++p)
+                    for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {     // children in fixed order
+                        int c = S.child_idx[e];
+                        for (int64_t q = S.rowptr[c]; q < S.rowptr[c + 1]; ++q) gsrc[nxt[lbase(p) + S.rel[q]]++] = (int)q;
                     }
-                }
+            }
             if (S.rows.size() >= ((size_t)1 << 31)) throw std::runtime_error("row structure exceeds int32 indexing");
             d_item_ptr.upload(ptr);
-            std::vector<int64_t> raw(items.size() * 4);
+            // extend-add items of the PANEL columns (the update-block columns go through the Schur sub-items):
+            // one record per child update column and 64-row piece of it, grouped by the (global, permuted) panel
+            // column it lands in, children in fixed order -- a wave handles eight pieces at a time, all of them
+            // a single load round, however long the child's column is
+            static_assert(sizeof(ExtItem) == 32, "ExtItem layout");
+            std::vector<int64_t> pptr((size_t)S.N + 1, 0);
+            for (int c = 0; c < S.nsuper; ++c) {
+                int p = S.sn_parent[c];
+                if (p < 0) continue;
+                const int pnc = S.sn_start[p + 1] - S.sn_start[p];
+                const int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
+                for (int b = 0; b < nbc; ++b) {
+                    const int r = S.rel[S.rowptr[c] + b];
+                    if (r >= pnc) break;                                   // rel ascends: the rest lands in U
+                    pptr[(size_t)S.sn_start[p] + r + 1] += (nbc - b + 63) / 64;
+                }
+            }
+            for (int i = 0; i < S.N; ++i) pptr[i + 1] += pptr[i];
+            std::vector<ExtItem> items((size_t)pptr[S.N]);
+            {
+                std::vector<int64_t> nxt(pptr.begin(), pptr.end() - 1);
+                for (int p = 0; p < S.nsuper; ++p) {
+                    const int pnc = S.sn_start[p + 1] - S.sn_start[p];
+                    for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {
+                        int c = S.child_idx[e];
+                        int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
+                        for (int b = 0; b < nbc; ++b) {
+                            int64_t q = S.rowptr[c] + b;
+                            const int r = S.rel[q];
+                            if (r >= pnc) break;
+                            for (int a = b; a < nbc; a += 64) {
+                                ExtItem it;
+                                it.uoff = S.upd_off[c] + (int64_t)b * nbc + a;
+                                it.relstart = (int)(S.rowptr[c] + a);
+                                it.cnt = std::min(64, nbc - a);
+                                it.child = c;
+                                it.b = b;
+                                it.tcol = r;
+                                it.pad = 0;
+                                items[(size_t)nxt[(size_t)S.sn_start[p] + r]++] = it;
+                            }
+                        }
+                    }
+                }
+            }
+            std::vector<int64_t> raw(std::max<size_t>(items.size(), 1) * 4);
             std::memcpy(raw.data(), items.data(), items.size() * sizeof(ExtItem));
             d_items.upload(raw);
             // 16 slices of each supernode's panel items, cut on column boundaries
             std::vector<int64_t> wcut((size_t)S.nsuper * 17, 0);
             for (int s = 0; s < S.nsuper; ++s) {
                 const int nc = S.sn_start[s + 1] - S.sn_start[s];
-                const int64_t* cp = ptr.data() + lbase(s);      // nc + 1 column pointers
+                const int64_t* cp = pptr.data() + S.sn_start[s];      // nc + 1 column pointers
                 const int64_t I0 = cp[0], I1 = cp[nc];
                 int j = 0;
                 for (int w = 0; w < 16; ++w) {

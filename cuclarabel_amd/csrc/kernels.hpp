@@ -15,10 +15,10 @@
 
 namespace hipkkt {
 
-struct ExtItem {                 // one child update column (rows a >= b of child c); 32 bytes
-    int64_t uoff;                // offset in the update store of U_c(b, b)
-    int relstart;                // index into rel[] of the child's row b
-    int cnt;                     // rows a = b .. nbc-1
+struct ExtItem {                 // a piece (<= 64 rows) of one child update column that lands in a panel column; 32 bytes
+    int64_t uoff;                // offset in the update store of the piece's first entry U_c(a, b)
+    int relstart;                // index into rel[] of the child's row a
+    int cnt;                     // rows in the piece
     int child;
     int b;
     int tcol;                    // parent-local column this item lands in
@@ -67,11 +67,12 @@ struct TreeDev {                 // device copies of the symbolic structure
                                  // chain of dependent index loads at the head of every kernel)
     const signed char* psign;    // N: expected pivot sign, permuted order
     const int* perm;             // N: perm[new] = old
-    // Extend-add work lists.  Local column j of front s has index lc = sn_start[s] + rowptr[s] + j.
-    // items[item_ptr[lc] .. item_ptr[lc+1]) are the child update columns that land in that column,
-    // in child order: the owner of the column applies them one after the other (deterministic).
-    const int64_t* item_ptr;     // sum_s f_s + 1
-    const ExtItem* items;        // sum_s nb_s
+    // Extend-add work lists of the panel columns: the pieces of child update columns that land in a panel column,
+    // grouped by column, children in fixed order; a wave owns whole columns (wave_cut) and applies their pieces
+    // one after the other (deterministic).  Local row / column j of front s has index lc = sn_start[s] + rowptr[s] + j
+    // (used by the gather lists below).
+    const int64_t* item_ptr;     // = gl_ptr
+    const ExtItem* items;
     // forward-solve gather lists: local row r of front s (same indexing) receives
     // uvec[gl_src[q]] for q in gl_ptr[lc] .. gl_ptr[lc+1]
     const int64_t* gl_ptr;
