@@ -5,6 +5,7 @@ library has not been built in-tree (`python -c "import __graft_entry__ as g; g.b
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -128,6 +129,15 @@ def lib():
             raise HipKKTError(
                 f"{SO_PATH} is missing: the HIP extension is required (no CPU fallback). "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        # PyTorch-ROCm ships its own copy of the HIP runtime.  Whichever copy a process loads first serves both;
+        # torch fails to see the GPU ("No HIP GPUs are available") when the system copy got in first.  Callers
+        # that also use torch for device memory / streams / RCCL therefore need torch's copy loaded before
+        # ours: importing torch (not initialising it) is enough.  Without torch installed nothing happens.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)       # AttributeError if the ABI is incomplete

@@ -67,7 +67,23 @@ def eq_constrained(which):
     return P, c, sp.csc_matrix(A), b, cones, dict(status="SOLVED", x=x)
 
 
+def unconstrained(feasible=True):
+    # test/OptTests/basic_unconstrained.jl:14-29 (feasible: x = -c) and :31-45 (dual infeasible): no constraints
+    # at all -- A is 0 x 3, b and the cone list are empty
+    P = sp.identity(3, format="csc")
+    if feasible:
+        c = np.array([1.0, 2.0, -3.0])
+        exp = dict(status="SOLVED", x=-c)
+    else:
+        P = sp.csc_matrix(np.diag([0.0, 1.0, 1.0]))
+        c = np.array([1.0, 0.0, 0.0])
+        exp = dict(status="DUAL_INFEASIBLE")
+    return P, c, sp.csc_matrix((0, 3)), np.zeros(0), [], exp
+
+
 ALL = {
+    "unconstrained": lambda: unconstrained(True),
+    "unconstrained_dualinf": lambda: unconstrained(False),
     "basic_qp": basic_qp,
     "basic_qp_dualinf": basic_qp_dualinf,
     "basic_lp": basic_lp,
