@@ -504,3 +504,39 @@ def test_level_A_one_based_indices_as_julia_passes_them():
     assert o2.update_scaling(pb.s0, pb.z0) and o2.kktsolver_update()
     xo = o2.ldl_solve(b)
     assert np.abs(x - xo).max() / np.abs(xo).max() < 1e-9
+
+
+# ---- edge cases of the cone list (cone_types.jl constructors; cone_api.jl:96-153 collapses these before the KKT
+#      layer in the reference, but the boundary must survive them) -----------------------------------------------
+def test_empty_and_one_dimensional_cones():
+    _lib, HipKKTSolver, _ = _hip()
+    from tests.oracle_bindings import OracleKKT
+    P = sp.identity(3, format="csc")
+    A = sp.csc_matrix(np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [1.0, 1.0, 1.0]]))
+    rx, rz = np.ones(3), np.ones(4)
+    cases = [
+        # empty cones between real ones (dimension 0 is legal for zero / nonnegative / PSD cones: cone_types.jl:50,177)
+        ([NonnegativeConeT(0), NonnegativeConeT(2), ZeroConeT(0), ZeroConeT(2), PSDTriangleConeT(0)],
+         np.array([1.0, 2.0, 0.0, 0.0]), np.array([1.0, 1.0, 0.0, 0.0])),
+        # the smallest second-order cone (dense Hs form) between 1 x 1 PSD cones
+        ([PSDTriangleConeT(1), SecondOrderConeT(2), PSDTriangleConeT(1)],
+         np.array([1.0, 2.0, 0.5, 3.0]), np.array([2.0, 3.0, -1.0, 1.0])),
+    ]
+    for cones, s, z in cases:
+        ks = HipKKTSolver(P, A, cones)
+        assert ks.kktsolver_update_from_sz(s, z)
+        ks.kktsolver_setrhs(rx, rz)
+        x, zz = np.zeros(3), np.zeros(4)
+        assert ks.kktsolver_solve(x, zz)
+        o = OracleKKT(P, A, cones, perm=ks.perm())
+        assert o.update_scaling(s, z) and o.kktsolver_update()
+        o.kktsolver_setrhs(rx, rz)
+        ok, xo, zo = o.kktsolver_solve()
+        assert ok
+        np.testing.assert_allclose(np.concatenate([x, zz]), np.concatenate([xo, zo]), rtol=1e-9, atol=1e-12)
+    # a second-order cone needs dim >= 2 (cone_types.jl:103: DomainError): an argument error, not a crash
+    with pytest.raises(_lib.HipKKTError, match="second-order cone"):
+        HipKKTSolver(P, A, [SecondOrderConeT(1), NonnegativeConeT(3)])
+    # cone dimensions must add up to the number of rows of A
+    with pytest.raises(_lib.HipKKTError):
+        HipKKTSolver(P, A, [NonnegativeConeT(3)])
