@@ -540,3 +540,36 @@ def test_empty_and_one_dimensional_cones():
     # cone dimensions must add up to the number of rows of A
     with pytest.raises(_lib.HipKKTError):
         HipKKTSolver(P, A, [NonnegativeConeT(3)])
+
+
+def test_full_size_headline_workload_properties_and_oracle():
+    """BASELINE.json's configs[1] at full size (n = 100k, N = 302 000): size-independent properties of the
+    solve -- linearity in the right-hand side, bit-reproducibility across refactorisations -- and agreement
+    with the oracle on the same K, b."""
+    _, HipKKTSolver, _ = _hip()
+    pb = problems.config2()
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    assert ks.info["N"] == 302000 and ks.info["nlevels"] < 64
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    rng = np.random.default_rng(123)
+    b1 = (rng.standard_normal(pb.n), rng.standard_normal(pb.m))
+    b2 = (rng.standard_normal(pb.n), rng.standard_normal(pb.m))
+
+    def solve(rx, rz):
+        ks.kktsolver_setrhs(rx, rz)
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        return np.concatenate([x, z])
+
+    x1, x2 = solve(*b1), solve(*b2)
+    x12 = solve(2.0 * b1[0] - 3.0 * b2[0], 2.0 * b1[1] - 3.0 * b2[1])
+    assert np.abs(x12 - (2.0 * x1 - 3.0 * x2)).max() / np.abs(x12).max() < 1e-9            # linearity
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)                                         # same values again
+    np.testing.assert_array_equal(solve(*b1), x1)                                            # fixed summation order
+    o = _oracle_for(pb, ks)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    o.kktsolver_setrhs(*b1)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok
+    assert np.abs(x1 - np.concatenate([xo, zo])).max() / np.abs(x1).max() < 1e-9
+    assert ks.last_ir_iterations == o.last_ir_iters
