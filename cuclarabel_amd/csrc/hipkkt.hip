@@ -65,6 +65,7 @@ struct Launch {
     int bs_panel, nbk, slice;   // panel kernel block size / block-column width; small-front LDS slice
     size_t lds_panel, lds_solve;
     int fmax, ncmax;            // largest front / column count in the launch
+    int ntiny;                  // one-wave launches: the last ntiny fronts have f <= 8 (eight to a wave in the solves)
     int tile_begin, ntiles;     // Schur tiles of this launch's fronts
     int tinv_begin, tinv_count, tinv_ncmax;   // this launch's supernodes that need T = L11^{-1}
 };
@@ -326,7 +327,12 @@ private:
         const size_t ntl = (no_top || !use_top || top_disabled) ? 0 : top_launches;   // the last ntl launches form the persistent top
         for (size_t q = 0; q + ntl < nl; ++q) {
             const Launch& L = launches[q];
-            launch_fwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, st);
+            if (L.small) {
+                launch_fwd(a, L.begin, L.count - L.ntiny, 64, 0, st);
+                launch_fwd(a, L.begin + L.count - L.ntiny, L.ntiny, 8, 0, st);
+            } else {
+                launch_fwd(a, L.begin, L.count, 256, L.lds_solve, st);
+            }
         }
         if (ntl > 0) {
             const Launch& L0 = launches[nl - ntl];
@@ -334,7 +340,12 @@ private:
         }
         for (size_t q = nl - ntl; q-- > 0;) {
             const Launch& L = launches[q];
-            launch_bwd(a, L.begin, L.count, L.small ? 64 : 256, L.lds_solve, st);
+            if (L.small) {
+                launch_bwd(a, L.begin + L.count - L.ntiny, L.ntiny, 8, 0, st);
+                launch_bwd(a, L.begin, L.count - L.ntiny, 64, 0, st);
+            } else {
+                launch_bwd(a, L.begin, L.count, 256, L.lds_solve, st);
+            }
         }
         HIP_CHECK(hipGetLastError());
     }
@@ -471,6 +482,9 @@ private:
             auto by_work = [&](int a, int b) { double wa = work(a), wb = work(b); return wa != wb ? wa > wb : a < b; };
             std::sort(small.begin(), small.end(), by_work);
             std::sort(big.begin(), big.end(), by_work);
+            // the tiny fronts (f <= 8) go to the end of the one-wave launch: the solves give them their own kernel
+            std::stable_partition(small.begin(), small.end(), [&](int s) { return front_size(s) > 8; });
+            const int ntiny_level = (int)std::count_if(small.begin(), small.end(), [&](int s) { return front_size(s) <= 8; });
             for (int cls = 0; cls < 2; ++cls) {
                 const std::vector<int>& v = cls == 0 ? big : small;
                 if (v.empty()) continue;
@@ -478,6 +492,7 @@ private:
                 L.begin = (int)sched.size();
                 L.count = (int)v.size();
                 L.small = cls == 1;
+                L.ntiny = cls == 1 ? ntiny_level : 0;
                 int fmax = 0, slice = 0;
                 for (int s : v) {
                     int f = front_size(s), nc = ncols(s), nb = f - nc;

@@ -119,6 +119,72 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
     }
 }
 
+// ------------------------------------------------------------------ tiny fronts, eight to a wave
+// Most leaves of a KKT elimination tree are single columns with a handful of rows (cfg2: 82 000 of the
+// 92 000 one-wave fronts have f <= 8).  A whole wave for each wastes 7/8 of the machine's wave slots, and
+// these kernels are bound by how many waves are in flight: eight fronts share a wave, eight lanes each.
+constexpr int kTinyFront = 8;
+__global__ __launch_bounds__(256) void k_fwd_tiny(SolveArgs A, int begin, int count)
+{
+    const int sub = threadIdx.x & 7;                                 // row inside the front
+    const int item = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = item < count;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + fd.front_off;
+    double y = (sub < nc) ? A.b[T.perm[c0 + sub]] : 0.0;
+    if (sub < f) {
+        const int64_t lc = (int64_t)c0 + rp + sub;
+        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
+        for (int64_t g = g0; g < g1; ++g) y += A.uvec[T.gl_src[g]];
+    }
+    double lv[kTinyFront];
+#pragma unroll
+    for (int k = 0; k < kTinyFront; ++k) lv[k] = (k < nc && sub > k && sub < f) ? F[sub + k * f] : 0.0;
+#pragma unroll
+    for (int k = 0; k < kTinyFront; ++k) {
+        const double yk = __shfl(y, k, 8);                           // every lane takes part (no divergence here)
+        if (k < nc) y = fma(-lv[k], yk, y);
+    }
+    if (live) {
+        if (sub < nc) A.xp[c0 + sub] = y;
+        else if (sub < f) A.uvec[rp + sub - nc] = y;
+    }
+}
+__global__ __launch_bounds__(256) void k_bwd_tiny(SolveArgs A, int begin, int count)
+{
+    const int sub = threadIdx.x & 7;
+    const int item = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = item < count;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ F = A.fronts + fd.front_off;
+    double y = 0.0;
+    if (sub < nc) y = A.xp[c0 + sub] * A.Dinv[c0 + sub];
+    else if (sub < f) y = A.xp[T.rows[rp + sub - nc]];
+    double lv[kTinyFront];
+#pragma unroll
+    for (int j = 0; j < kTinyFront; ++j) lv[j] = (j < nc && sub > j && sub < f) ? F[sub + j * f] : 0.0;
+#pragma unroll
+    for (int j = kTinyFront - 1; j >= 0; --j) {
+        double sum = lv[j] * y;
+        sum += __shfl_xor(sum, 4, 8);
+        sum += __shfl_xor(sum, 2, 8);
+        sum += __shfl_xor(sum, 1, 8);
+        if (j < nc && sub == j) y -= sum;
+    }
+    if (live && sub < nc) {
+        A.xp[c0 + sub] = y;
+        A.out[T.perm[c0 + sub]] = y;
+    }
+}
+
 // ------------------------------------------------------------------ larger fronts, one block each
 // After the factorisation k_winv forms, per supernode, the "solve matrix"
 //        W = [ T ; M ],   T = L11^{-1} (unit lower, nc x nc),   M = L21 * T  (nb x nc),
@@ -654,7 +720,9 @@ size_t solve_lds_bytes(int fmax, int ncmax)
 void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
 {
     if (count <= 0 || nrhs <= 0) return;
-    if (bs == 64) {
+    if (bs == 8) {
+        hipLaunchKernelGGL(k_fwd_tiny, dim3((count + 31) / 32), dim3(256), 0, st, a, begin, count);
+    } else if (bs == 64) {
         hipLaunchKernelGGL(k_fwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
     } else {
         init_solve_lds();
@@ -664,7 +732,9 @@ void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
 void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
 {
     if (count <= 0 || nrhs <= 0) return;
-    if (bs == 64) {
+    if (bs == 8) {
+        hipLaunchKernelGGL(k_bwd_tiny, dim3((count + 31) / 32), dim3(256), 0, st, a, begin, count);
+    } else if (bs == 64) {
         hipLaunchKernelGGL(k_bwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
     } else {
         init_solve_lds();
