@@ -134,6 +134,94 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
 }
 
 // =====================================================================================
+//  tiny fronts (f <= 8): eight lanes per front, eight fronts per wave, 1 KB of LDS each.  Same steps and the
+//  same operation order as k_front_wave; these are most of a KKT tree's leaves, and a wave apiece leaves the
+//  machine short of wave slots (the kernel is bound by waves in flight, not by bytes).
+// =====================================================================================
+constexpr int kTinyF = 8;
+constexpr int kTinySlice = 128;        // doubles: f*nc + nb*nb <= 8*8 + 7*7
+__global__ __launch_bounds__(256) void k_front_tiny(FactorArgs A, int begin, int count)
+{
+    __shared__ __attribute__((aligned(16))) double smem_t[32 * kTinySlice];
+    const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const int item = blockIdx.x * 32 + grp;
+    if (item >= count) return;                    // (no wave-wide operation below: groups are independent)
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + item];
+    const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int f = nc + nb;
+    double* __restrict__ F = A.fronts + fd.front_off;
+    double* __restrict__ U = A.upd + fd.upd_off;
+    double* P = smem_t + grp * kTinySlice;        // f x nc, ld f
+    double* Us = P + f * nc;                      // nb x nb, ld nb
+
+    for (int i = sub; i < f * nc + nb * nb; i += 8) P[i] = 0.0;
+    WAVE_FENCE();
+    {
+        const int64_t e0 = fd.kptr;
+        const int ne = fd.nk;
+        for (int e = sub; e < ne; e += 8) P[T.kdst[e0 + e]] = A.Kval[T.ksrc[e0 + e]];
+    }
+    WAVE_FENCE();
+    if (A.eps) {
+        const double eps = *A.eps;
+        if (sub < nc) P[sub + sub * f] += eps * (double)T.psign[c0 + sub];
+    }
+    for (int ce = T.child_ptr[s]; ce < T.child_ptr[s + 1]; ++ce) {
+        const int c = T.child_idx[ce];
+        const int64_t crp = T.rowptr[c];
+        const int nbc = (int)(T.rowptr[c + 1] - crp);
+        const double* __restrict__ Uc = A.upd + T.upd_off[c];
+        const int* __restrict__ relc = T.rel + crp;
+        WAVE_FENCE();
+        for (int b = 0; b < nbc; ++b) {
+            const int rb = relc[b];
+            for (int a = b + sub; a < nbc; a += 8) {
+                const int ra = relc[a];
+                const double v = Uc[a + (int64_t)b * nbc];
+                if (rb < nc) P[ra + rb * f] += v;
+                else Us[(ra - nc) + (rb - nc) * nb] += v;
+            }
+        }
+    }
+    WAVE_FENCE();
+    for (int k = 0; k < nc; ++k) {
+        double d = P[k + k * f];
+        const double sg = (double)T.psign[c0 + k];
+        const bool reg = (d * sg < A.dyn_eps);
+        if (reg) d = sg * A.dyn_delta;
+        const double dinv = 1.0 / d;
+        if (sub == 0) {
+            if (reg) atomicAdd(&A.flags[0], 1);
+            if (!isfinite(dinv)) A.flags[1] = 1;
+            A.Dinv[c0 + k] = dinv;
+        }
+        if (sub > k && sub < f) {
+            const double vik = P[sub + k * f];
+            const double lik = vik * dinv;
+            const int jmax = min(sub, nc - 1);
+            for (int j = k + 1; j <= jmax; ++j) P[sub + j * f] -= lik * P[j + k * f];
+        }
+        WAVE_FENCE();
+        if (sub > k && sub < f) P[sub + k * f] *= dinv;
+        if (sub == k) P[k + k * f] = d;
+        WAVE_FENCE();
+    }
+    for (int i = sub; i < f * nc; i += 8) {
+        const int j = i / f, r = i - j * f;
+        if (r >= j) F[i] = P[i];
+    }
+    if (sub < nb) {
+        const int a = sub;
+        for (int b = 0; b <= a; ++b) {
+            double acc = 0.0;
+            for (int k = 0; k < nc; ++k) acc = fma(P[nc + a + k * f] * P[k + k * f], P[nc + b + k * f], acc);
+            U[a + (int64_t)b * nb] = Us[a + b * nb] - acc;
+        }
+    }
+}
+
+// =====================================================================================
 //  panel kernel: one workgroup per front, the whole f x nc panel resident in LDS
 //  (the symbolic phase splits wider supernodes so that f*nc fits: SymbolicOptions::panel_cap).
 //  Global traffic: K values and the children's update entries in (batched, independent loads),
@@ -582,6 +670,11 @@ static void init_factor_lds()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+void launch_front_tiny(const FactorArgs& a, int begin, int count, hipStream_t st)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_front_tiny, dim3((count + 31) / 32), dim3(256), 0, st, a, begin, count);
+}
 void launch_front_wave(const FactorArgs& a, int begin, int count, int slice_doubles, hipStream_t st)
 {
     if (count <= 0) return;

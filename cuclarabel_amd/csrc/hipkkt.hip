@@ -266,7 +266,8 @@ private:
                 eager_fork = true;
             }
             if (L.small) {
-                launch_front_wave(a, L.begin, L.count, L.slice, st);
+                launch_front_wave(a, L.begin, L.count - L.ntiny, L.slice, st);
+                launch_front_tiny(a, L.begin + L.count - L.ntiny, L.ntiny, st);
             } else {
                 a.nbk = L.nbk;
                 launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, st);
@@ -497,7 +498,7 @@ private:
                 for (int s : v) {
                     int f = front_size(s), nc = ncols(s), nb = f - nc;
                     fmax = std::max(fmax, f);
-                    slice = std::max(slice, f * nc + nb * nb);
+                    if (!(cls == 1 && f <= 8)) slice = std::max(slice, f * nc + nb * nb);     // (tiny fronts: own kernel)
                 }
                 L.slice = (slice + 1) & ~1;
                 int pmax = 0;

@@ -138,6 +138,7 @@ void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int
 constexpr int kSmallFrontMax = 64;         // f <= 64 ...
 constexpr int kSmallSliceMax = 1536;       // ... and f*nc + nb*nb <= this many doubles of LDS per wave
 void launch_front_wave(const FactorArgs& a, int begin, int count, int slice_doubles, hipStream_t st);
+void launch_front_tiny(const FactorArgs& a, int begin, int count, hipStream_t st);     // fronts with f <= 8, eight to a wave
 void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st);
 size_t panel_lds_bytes(int fmax, int panel_max);
