@@ -65,6 +65,7 @@ struct Launch {
     int bs_panel, nbk, slice;   // panel kernel block size / block-column width; small-front LDS slice
     size_t lds_panel, lds_solve;
     int fmax, ncmax;            // largest front / column count in the launch
+    int solve_bs;               // workgroup size of the block solve kernels for this launch (128 or 256 = the default 512-thread one)
     int ntiny;                  // one-wave launches: the last ntiny fronts have f <= 8 (eight to a wave in the solves)
     int tile_begin, ntiles;     // Schur tiles of this launch's fronts
     int tinv_begin, tinv_count, tinv_ncmax;   // this launch's supernodes that need T = L11^{-1}
@@ -332,7 +333,7 @@ private:
                 launch_fwd(a, L.begin, L.count - L.ntiny, 64, 0, st);
                 launch_fwd(a, L.begin + L.count - L.ntiny, L.ntiny, 8, 0, st);
             } else {
-                launch_fwd(a, L.begin, L.count, 256, L.lds_solve, st);
+                launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
             }
         }
         if (ntl > 0) {
@@ -345,7 +346,7 @@ private:
                 launch_bwd(a, L.begin + L.count - L.ntiny, L.ntiny, 8, 0, st);
                 launch_bwd(a, L.begin, L.count - L.ntiny, 64, 0, st);
             } else {
-                launch_bwd(a, L.begin, L.count, 256, L.lds_solve, st);
+                launch_bwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -513,6 +514,9 @@ private:
                 L.lds_solve = L.small ? 0 : solve_lds_bytes(fmax, ncmax);
                 L.fmax = fmax;
                 L.ncmax = ncmax;
+                static const int small_bs_count = std::getenv("HIPKKT_BS128_COUNT") ? std::atoi(std::getenv("HIPKKT_BS128_COUNT")) : 1024;
+                static const int small_bs_f = std::getenv("HIPKKT_BS128_F") ? std::atoi(std::getenv("HIPKKT_BS128_F")) : 128;
+                L.solve_bs = (L.count >= small_bs_count && fmax <= small_bs_f) ? 128 : 256;
                 L.tinv_begin = (int)tinv_list.size();
                 L.tinv_ncmax = 1;
                 if (!L.small) for (int s : v) {

@@ -697,6 +697,10 @@ static void init_solve_lds()
     static bool done = false;
     if (done) return;
     done = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_block<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_block<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_block<kSolveBS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_block<kSolveBS>),
@@ -726,7 +730,9 @@ void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
         hipLaunchKernelGGL(k_fwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
     } else {
         init_solve_lds();
-        hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
+        // bs = 128: a wide level of small fronts -- more fronts in flight per CU matter more than waves per front
+        if (bs == 128) hipLaunchKernelGGL(k_fwd_block<128>, dim3(count, nrhs), dim3(128), lds, st, a, begin);
+        else hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
     }
 }
 void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
@@ -738,7 +744,8 @@ void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
         hipLaunchKernelGGL(k_bwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
     } else {
         init_solve_lds();
-        hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
+        if (bs == 128) hipLaunchKernelGGL(k_bwd_block<128>, dim3(count, nrhs), dim3(128), lds, st, a, begin);
+        else hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
     }
 }
 // ------------------------------------------------------------------ several right-hand sides
