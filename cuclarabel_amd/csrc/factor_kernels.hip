@@ -295,13 +295,15 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     const int f = nc + nb;
     double* __restrict__ F = A.fronts + fd.front_off;
 
-    double* sh_d = smem;                          // NB
-    double* sh_dinv = smem + NB;                  // NB
-    double* Lb = smem + 2 * NB;                   // NB x NB: Lb[j*NB + t] = d_t * L(j,t), t < j
-    double* colb = smem + 2 * NB + NB * NB;       // 4*NB: micro-block broadcast buffer
-    double* Bd = smem + 6 * NB + NB * NB;         // NB x kBdCols: d_k * L(j,k) for the trailing columns
-    double* sgn = Bd + NB * kBdCols;              // kBdCols + NB: expected pivot signs of this front's columns
-    double* P = sgn + kBdCols + NB;               // f x nc, ld f (+ 256 doubles of slack behind it)
+    // block data is double-buffered by block parity: wave 0 factors diagonal block k+1 while the other waves
+    // still read block k's d, 1/d and d*L
+    double* sh_d_all = smem;                      // 2 x NB
+    double* sh_dinv_all = smem + 2 * NB;          // 2 x NB
+    double* Lb_all = smem + 4 * NB;               // 2 x NB x NB: Lb[j*NB + t] = d_t * L(j,t), t < j
+    double* colb = smem + 4 * NB + 2 * NB * NB;   // 4*NB: the diagonal step's broadcast buffer (wave 0 only)
+    double* sgn = colb + 4 * NB;                  // kBdCols + NB: expected pivot signs of this front's columns
+    int* lds_cnt = reinterpret_cast<int*>(sgn + kBdCols + NB);   // (2 doubles) arrival counter of the in-block barrier
+    double* P = sgn + kBdCols + NB + 2;           // f x nc, ld f (+ 256 doubles of slack behind it)
 
     HIPKKT_STAMP(A, 0);
     const long long clk0 = A.stamps ? clock64() : 0;
@@ -349,7 +351,10 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     long long t_i = 0, t_ii = 0, t_iii = 0, t0 = 0;
     // the 16 x 16 diagonal block kb (see (i) below) as a callable: with look-ahead it runs on wave 0 while the
     // other waves finish the trailing update of the previous block
-    auto diag_block = [&](const int kb, const int w) {
+    auto diag_block = [&](const int kb, const int w, const int par) {
+        double* sh_d = sh_d_all + par * NB;
+        double* sh_dinv = sh_dinv_all + par * NB;
+        double* Lb = Lb_all + par * NB * NB;
         // Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3).  Pivot by pivot, fully unrolled: the lanes
         // owning column k put it into LDS, every lane reads back its row's entry, the entries of its own four
         // columns' rows and the pivot (one LDS round trip per pivot, ~35 dependent instructions), while the
@@ -416,20 +421,29 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             if (bad) A.flags[1] = 1;
         }
             };
-    // ---- 4. blocked right-looking factorisation inside LDS
+    // ---- 4. blocked right-looking factorisation inside LDS, software-pipelined across the waves:
+    //   wave 0        rows of the NEXT diagonal block against block k (16 rows), the one 16 x 16 tile that updates
+    //                 that diagonal block, then its factorisation -- the serial chain of the panel, start to end;
+    //   waves 1..     the other rows against block k (thread per row), an LDS arrival counter as their barrier
+    //                 (wave 0 signals but does not wait), then the rest of the trailing update on the matrix cores.
+    //   One workgroup barrier per block.  The B operand of the trailing tiles is d_k L(j,k), scaled on the fly.
+    if (tid == 0) *lds_cnt = 0;
+    __syncthreads();                     // the panel is assembled (every wave has applied its children's columns)
+    if (wv == 0) diag_block(0, min(NB, nc), 0);
+    int epoch = 0;
     for (int kb = 0; kb < nc; kb += NB) {
         const int w = min(NB, nc - kb);
-        __syncthreads();
+        const int par = (kb / NB) & 1;
+        const double* sh_d = sh_d_all + par * NB;
+        const double* sh_dinv = sh_dinv_all + par * NB;
+        const double* Lb = Lb_all + par * NB * NB;
+        __syncthreads();                 // diagonal block kb is factored, trailing update kb - NB is complete
         if (A.stamps) t0 = wall_clock64();
-        const bool ahead_done = kb > 0;          // factored during the previous block's trailing update
-        // (i) diagonal 16 x 16 block by wave 0, wave-synchronous through LDS (diag_block above)
-        if (wv == 0 && !ahead_done) diag_block(kb, w);
-        __syncthreads();
-        if (A.stamps) { long long t1 = wall_clock64(); t_i += t1 - t0; t0 = t1; }
-        // (ii) rows below the block: L(i,j) = (A(i,j) - sum_{t<j} L(i,t) * [d_t L(j,t)]) / d_j, a thread per row.
-        //      (An MFMA form X = A * (L_bb^{-T} D^{-1}) was tried: the GEMM itself is 3x faster, but forming the
-        //      16 x 16 inverse in the serial diagonal step costs more than it saves.)
-        for (int i = kb + w + tid; i < f; i += BS) {
+        ++epoch;
+        const int g0 = kb + w;
+        const int Tc = nc - g0, Tr = f - g0;
+        // rows below the block: L(i,j) = (A(i,j) - sum_{t<j} L(i,t) * [d_t L(j,t)]) / d_j, a thread per row
+        auto trsm_row = [&](const int i) {
             double l[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) l[j] = (j < w) ? P[i + (kb + j) * f] : 0.0;
@@ -444,55 +458,55 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) if (j < w) P[i + (kb + j) * f] = l[j];
-        }
-        __syncthreads();
-        if (A.stamps) { long long t1 = wall_clock64(); t_ii += t1 - t0; t0 = t1; }
-        // (iii) trailing update of the remaining panel columns on the matrix cores: 16 x 16 tiles,
-        //       C(i,j) -= sum_k L(i,k) * Bd(k,j) with Bd(k,c) = d_k L(g0 + c, k) built once per block.
-        //       Look-ahead: the column tile that holds the NEXT diagonal block goes first (all waves); then
-        //       wave 0 factors that block while the other waves update the rest.
-        const int g0 = kb + w;
-        const int Tc = nc - g0, Tr = f - g0;
-        if (Tc > 0) {
-            const int Tcp = (Tc + 15) & ~15;
-            for (int idx = tid; idx < NB * Tcp; idx += BS) {
-                const int k = idx / Tcp, c = idx - k * Tcp;
-                Bd[k * kBdCols + c] = (k < w && c < Tc) ? P[(g0 + c) + (kb + k) * f] * sh_d[k] : 0.0;
+        };
+        const int ml = lane & 15, mk = lane >> 4;
+        // C(16 x 16 tile at rows g0 + 16 tr, columns g0 + 16 tc) -= L(rows, block) * (d L(cols, block))'
+        auto tile = [&](const int tr, const int tc) {
+            const int i0 = g0 + 16 * tr, j0 = g0 + 16 * tc;
+            double av[4], bv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * kk + mk;
+                av[kk] = (i0 + ml < f && k < w) ? P[(i0 + ml) + (kb + k) * f] : 0.0;
+                bv[kk] = (j0 + ml < nc && k < w) ? P[(j0 + ml) + (kb + k) * f] * sh_d[k] : 0.0;
             }
-            __syncthreads();
-            const int ml = lane & 15, mk = lane >> 4;
-            const int ntr = (Tr + 15) >> 4, ntc = Tcp >> 4;
-            auto tile = [&](const int tr, const int tc) {
-                const int i0 = g0 + 16 * tr, j0 = 16 * tc;
-                double av[4], bv[4];
+            d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 4 * kk + mk;
-                    av[kk] = (i0 + ml < f && k < w) ? P[(i0 + ml) + (kb + k) * f] : 0.0;
-                    bv[kk] = Bd[k * kBdCols + j0 + ml];
-                }
-                d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = i0 + mk + 4 * r, col = g0 + j0 + ml;
-                    if (row < f && col < nc && row >= col) P[row + col * f] -= acc[r];
-                }
-            };
-            for (int tr = wv; tr < ntr; tr += NW) tile(tr, 0);
-            __syncthreads();
-            if (wv == 0) {
-                diag_block(g0, min(NB, nc - g0));
-            } else {
-                for (int t = wv - 1; t < ntr * (ntc - 1); t += NW - 1) {
-                    const int tc = 1 + t / ntr, tr = t - (tc - 1) * ntr;
-                    if (tr < tc) continue;                       // wholly above the diagonal
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + mk + 4 * r, col = j0 + ml;
+                if (row < f && col < nc && row >= col) P[row + col * f] -= acc[r];
+            }
+        };
+        const int nfirst = min(NB, Tr);                       // rows of the next diagonal block (or the last rows)
+        if (wv == 0) {
+            if (lane < nfirst) trsm_row(g0 + lane);
+            WAVE_FENCE();
+            if (Tc > 0) {
+                tile(0, 0);
+                WAVE_FENCE();
+            }
+            if (lane == 0) __hip_atomic_fetch_add(lds_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (Tc > 0) diag_block(g0, min(NB, nc - g0), par ^ 1);
+        } else {
+            for (int i = g0 + nfirst + (tid - 64); i < f; i += BS - 64) trsm_row(i);
+            WAVE_FENCE();
+            if (lane == 0) __hip_atomic_fetch_add(lds_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (Tc > 0) {
+                // every wave's rows are in place once all NW arrivals of this block are counted
+                while (__hip_atomic_load(lds_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch)
+                    __builtin_amdgcn_s_sleep(1);
+                WAVE_FENCE();
+                const int ntr = (Tr + 15) >> 4, ntc = (Tc + 15) >> 4;
+                for (int t = wv - 1; t < ntr * ntc; t += NW - 1) {
+                    const int tc = t / ntr, tr = t - tc * ntr;
+                    if (tr < tc || (tr == 0 && tc == 0)) continue;      // above the diagonal / wave 0's tile
                     tile(tr, tc);
                 }
             }
         }
-        if (A.stamps) { __syncthreads(); long long t1 = wall_clock64(); t_iii += t1 - t0; }
+        if (A.stamps) { long long t1 = wall_clock64(); t_iii += t1 - t0; }
     }
     __syncthreads();
     HIPKKT_STAMP(A, 4);
@@ -656,7 +670,7 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
 size_t panel_lds_bytes(int fmax, int panel_max)
 {
     (void)fmax;
-    return ((size_t)6 * NB + NB * NB + NB * kBdCols + (kBdCols + NB) + (size_t)panel_max + 256) * sizeof(double);
+    return ((size_t)8 * NB + 2 * NB * NB + (kBdCols + NB) + 2 + (size_t)panel_max + 256) * sizeof(double);
 }
 
 static void init_factor_lds()
