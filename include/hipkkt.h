@@ -2,7 +2,8 @@
  * hipkkt.h -- C ABI of libhipkkt.so: an MI355X-native (HIP, gfx950) KKT linear-system solver
  * that drops in behind Clarabel.jl's KKT-solver interfaces.  fp64 throughout.
  *
- * Two boundaries are exported; citations are into /root/reference:
+ * Two boundaries are exported, plus the two layers either side of them
+ * (section 8f); citations are into /root/reference:
  *
  *   Level A  hipkkt_ldl_*   replaces an AbstractDirectLDLSolver backend
  *            contract  src/kktsolvers/direct-ldl/directldl_defaults.jl:1-72
@@ -10,6 +11,10 @@
  *   Level B  hipkkt_kkt_*   replaces the whole DirectLDLKKTSolver <: AbstractKKTSolver
  *            contract  src/kktsolvers/kktsolver_defaults.jl:2-48
  *            example   src/kktsolvers/kktsolver_directldl.jl:5-466
+ *   Level C  hipkkt_kkt_system_*   the caller of level B, DefaultKKTSystem, with its vectors in HBM
+ *            src/kktsystem.jl:21-215  (kkt_update!, kkt_solve_initial_point!, kkt_solve!)
+ *   Data     hipkkt_equilibrate / hipkkt_scale_matrix_values   Ruiz equilibration before level B is built
+ *            src/problemdata.jl:133-242, src/data_updating.jl:169-194
  *
  * Conventions
  *   - plain pointers and sizes only; the caller owns every array it passes and may free or
