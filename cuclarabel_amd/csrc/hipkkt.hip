@@ -1334,7 +1334,7 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
         h->cur_dx = h->dx.p;
         h->rx.alloc((size_t)K.n); h->rz.alloc((size_t)K.m);
         h->sbuf.alloc((size_t)K.m); h->zbuf.alloc((size_t)K.m); h->ybuf.alloc((size_t)K.m);
-        h->partial.alloc(4096);
+        h->partial.alloc(2 * (kNormParts + 1) + 8);
         h->scal.alloc(8);
         HIP_CHECK(hipMemset(h->scal.p, 0, 8 * sizeof(double)));
         h->pin.reset(new PinnedScalars);
@@ -1567,8 +1567,7 @@ static void kkt_enqueue_refine_error(hipkkt_kkt_t h, const double* xi, bool with
     const SpmvDev A = kkt_spmv(h);
     int pr = h->prof.begin(3, h->stream);
     launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + slot, h->stream, 1, 0,
-                    h->eng->top_abort_word(), h->scal.p + 3);
-    if (with_normb) launch_norm_inf(h->b.p, h->K.N, h->partial.p, h->scal.p + 2, h->stream);
+                    h->eng->top_abort_word(), h->scal.p + 3, with_normb ? h->scal.p + 2 : nullptr);
     h->prof.end(pr, h->stream);
 }
 // one read-back of scal[1..4] = {norme, normb, abort, speculative norme}; synchronises

@@ -117,7 +117,8 @@ void launch_regularizer(const double* K, const int* diag, int N, double c0, doub
 template <int G>
 __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __restrict__ K,
                                                   const double* __restrict__ b, const double* __restrict__ x,
-                                                  double* __restrict__ e, double* __restrict__ partial, int64_t ld)
+                                                  double* __restrict__ e, double* __restrict__ partial, int64_t ld,
+                                                  double* __restrict__ bpartial)
 {
     __shared__ double sh[4];
     b += blockIdx.y * ld;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __res
     partial += blockIdx.y * (gridDim.x + 1);
     const int sub = threadIdx.x % G;
     const int rows_per_block = 256 / G;
-    double vmax = 0.0;
+    double vmax = 0.0, bmax = 0.0;           // bmax: ||b||_inf rides along when bpartial is given (one column only)
     bool bad = false;
     for (int row = blockIdx.x * rows_per_block + threadIdx.x / G; row < A.N; row += gridDim.x * rows_per_block) {
         const int64_t q0 = A.ptr[row], q1 = A.ptr[row + 1];
@@ -140,10 +141,12 @@ __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __res
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, G);
         if (sub == 0) {
-            const double r = b[row] - acc;
+            const double bv = b[row];
+            const double r = bv - acc;
             e[row] = r;
             if (!isfinite(r)) bad = true;
             vmax = fmax(vmax, fabs(r));
+            bmax = isfinite(bv) ? fmax(bmax, fabs(bv)) : INFINITY;
         }
     }
     if (bad) vmax = INFINITY;        // marks non-finite; finished as NaN below
@@ -151,6 +154,11 @@ __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __res
     if (threadIdx.x == 0) {
         partial[blockIdx.x] = vmax;
         if (blockIdx.x == 0 && A.nlong == 0) partial[gridDim.x] = 0.0;     // the long rows' slot
+    }
+    if (bpartial) {
+        __syncthreads();
+        bmax = block_max_256(bmax, sh);
+        if (threadIdx.x == 0) bpartial[blockIdx.x] = bmax;
     }
 }
 // one workgroup per chunk of a long row: fixed assignment of entries to threads, fixed reduction tree
@@ -195,7 +203,9 @@ __global__ __launch_bounds__(256) void k_residual_long_finish(SpmvDev A, const d
     if (threadIdx.x == 0) partial[blockIdx.y * (gmain + 1) + gmain] = vmax;
 }
 __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, double* __restrict__ out,
-                              const int* __restrict__ flag_in = nullptr, double* __restrict__ flag_out = nullptr)
+                              const int* __restrict__ flag_in = nullptr, double* __restrict__ flag_out = nullptr,
+                              const double* __restrict__ bpartial = nullptr, int nbparts = 0,
+                              double* __restrict__ bout = nullptr)
 {
     if (flag_out && blockIdx.x == 0 && threadIdx.x == 0) flag_out[0] = (flag_in && flag_in[0]) ? 1.0 : 0.0;
     __shared__ double sh[4];
@@ -207,24 +217,35 @@ __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, do
     // norm(e, Inf) of a vector holding Inf or NaN is not finite either way; the caller only
     // tests isfinite() (kktsolver_directldl.jl:411,429)
     if (threadIdx.x == 0) out[0] = v;
+    if (bpartial && blockIdx.x == 0) {
+        __syncthreads();
+        double w = 0.0;
+        for (int i = threadIdx.x; i < nbparts; i += blockDim.x) w = fmax(w, bpartial[i]);
+        w = block_max_256(w, sh);
+        if (threadIdx.x == 0) bout[0] = w;
+    }
 }
 void launch_residual(const SpmvDev& A, const double* K, const double* b, const double* x, double* e,
                      double* partial, double* norm_out, hipStream_t st, int nrhs, int64_t ld, const int* flag_in,
-                     double* flag_out)
+                     double* flag_out, double* normb_out)
 {
     int rows_per_block = 256 / A.lanes_per_row;
     int g = (A.N + rows_per_block - 1) / rows_per_block;
     if (g > kNormParts) g = kNormParts;
     if (g < 1) g = 1;
+    // ||b||_inf in the same pass (one column, no long rows: every row's b is read here anyway)
+    double* bpartial = (normb_out && nrhs == 1 && A.nlong == 0) ? partial + (g + 1) : nullptr;
     if (A.lanes_per_row == 8)
-        hipLaunchKernelGGL(k_residual<8>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
+        hipLaunchKernelGGL(k_residual<8>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
     else
-        hipLaunchKernelGGL(k_residual<64>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld);
+        hipLaunchKernelGGL(k_residual<64>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
     if (A.nlong > 0) {
         hipLaunchKernelGGL(k_residual_long_chunks, dim3(A.nchunks, nrhs), dim3(256), 0, st, A, K, x, ld);
         hipLaunchKernelGGL(k_residual_long_finish, dim3(1, nrhs), dim3(256), 0, st, A, b, e, partial, ld, g);
     }
-    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g + 1, norm_out, flag_in, flag_out);
+    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g + 1, norm_out, flag_in, flag_out,
+                       (const double*)bpartial, g, normb_out);
+    if (normb_out && !bpartial) launch_norm_inf(b, A.N, partial, normb_out, st, nrhs, ld);
 }
 __global__ void k_absmax(const double* __restrict__ v, int n, double* __restrict__ partial, int64_t ld)
 {
@@ -246,7 +267,8 @@ void launch_norm_inf(const double* v, int n, double* partial, double* out, hipSt
 {
     int g = grid_for(n, 256, kRedBlocks);
     hipLaunchKernelGGL(k_absmax, dim3(g, nrhs), dim3(256), 0, st, v, n, partial, ld);
-    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, out, (const int*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g, out, (const int*)nullptr, (double*)nullptr,
+                       (const double*)nullptr, 0, (double*)nullptr);
 }
 __global__ void k_gather_values(double* __restrict__ val, const double* __restrict__ K, const int* __restrict__ vmap,
                                 int64_t nnz)

@@ -189,7 +189,9 @@ constexpr int kNormParts = 2048;   // partial needs nrhs * (kNormParts + 1) doub
 // with the norm read-back
 void launch_residual(const SpmvDev& A, const double* Kval, const double* b, const double* x, double* e,
                      double* partial, double* norm_out, hipStream_t st, int nrhs = 1, int64_t ld = 0,
-                     const int* flag_in = nullptr, double* flag_out = nullptr);
+                     const int* flag_in = nullptr, double* flag_out = nullptr, double* normb_out = nullptr);
+// normb_out (nullable): ||b_j||_inf as well -- in the same pass when there is one column and no long row
+// (partial then needs 2 * (kNormParts + 1) doubles), by a separate reduction otherwise
 void launch_norm_inf(const double* v, int n, double* partial, double* out, hipStream_t st, int nrhs = 1,
                      int64_t ld = 0);
 void launch_axpby_sum(double* y, const double* a, const double* b, int64_t n, hipStream_t st);   // y = a + b
