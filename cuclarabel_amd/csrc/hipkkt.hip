@@ -172,6 +172,7 @@ public:
         if (nrhs == 1) { solve(d_B, d_X); return; }
         const int KP = (nrhs + 15) & ~15;
         if (KP / 8 > 65535) throw ArgError("solve_multi: too many right-hand sides per call");
+        wait_w(stream);
         if ((size_t)KP > multi_cap) {
             xp_m.alloc((size_t)S.N * KP);
             uvec_m.alloc(std::max<size_t>(S.rows.size(), 1) * KP);
@@ -227,6 +228,7 @@ private:
     // side != nullptr: put the T = L11^{-1} kernels on that stream, forked after each level's panels
     void enqueue_factor(const double* d_Kval, const double* d_eps, hipStream_t st, hipStream_t side, bool want_stamps)
     {
+        wait_w(st);                  // (a refactorisation without a solve in between: the side stream still reads the fronts)
         launch_zero_ints(flags.p, 2, st);
         FactorArgs a;
         a.T = tree();
@@ -285,9 +287,15 @@ private:
             HIP_CHECK(hipEventRecord(ev_join, side));
             HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
         } else if (eager_fork) {
+            // the solve matrices of the top fronts are formed on the side stream as well, behind the tree: the next
+            // sweep only needs them when it reaches the top of the tree (enqueue_solve waits for ev_join there), so
+            // their formation hides behind the sweep's bottom levels instead of ending the factorisation
             const int done = launches[first_top].tinv_begin;
-            launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, st);
-            HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+            HIP_CHECK(hipEventRecord(ev_fork, st));
+            HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
+            launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, cap_side);
+            HIP_CHECK(hipEventRecord(ev_join, cap_side));
+            w_pending = true;
         } else {
             // one launch over every supernode, after the tree (all of them independent)
             launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st);
@@ -327,8 +335,10 @@ private:
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         const size_t nl = launches.size();
         const size_t ntl = (no_top || !use_top || top_disabled) ? 0 : top_launches;   // the last ntl launches form the persistent top
+        const size_t first_w = nl - std::min(nl, top_launches);     // fronts from here on get their W late (w_pending)
         for (size_t q = 0; q + ntl < nl; ++q) {
             const Launch& L = launches[q];
+            if (q == first_w) wait_w(st);
             if (L.small) {
                 launch_fwd(a, L.begin, L.count - L.ntiny, 64, 0, st);
                 launch_fwd(a, L.begin + L.count - L.ntiny, L.ntiny, 8, 0, st);
@@ -336,6 +346,7 @@ private:
                 launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
             }
         }
+        wait_w(st);
         if (ntl > 0) {
             const Launch& L0 = launches[nl - ntl];
             launch_top_solve(a, L0.begin, top_count, top_lds, top_flags.p, ++top_epoch, st);
@@ -350,6 +361,15 @@ private:
             }
         }
         HIP_CHECK(hipGetLastError());
+    }
+
+    // the side stream may still be forming the top fronts' solve matrices (enqueue_factor)
+    bool w_pending = false;
+    void wait_w(hipStream_t st)
+    {
+        if (!w_pending) return;
+        HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+        w_pending = false;
     }
 
     // ---- persistent-kernel bookkeeping
