@@ -1696,10 +1696,7 @@ int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double* d_lhsx, double* d_lhsz)
         HIP_CHECK(hipSetDevice(h->device));
         int rc = kkt_solve_core(h);
         if (rc != HIPKKT_OK) return rc;
-        if (d_lhsx && h->K.n)
-            HIP_CHECK(hipMemcpyAsync(d_lhsx, h->cur_x, (size_t)h->K.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        if (d_lhsz && h->K.m)
-            HIP_CHECK(hipMemcpyAsync(d_lhsz, h->cur_x + h->K.n, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        launch_unpack_lhs(d_lhsx, d_lhsz, h->cur_x, h->K.n, h->K.m, h->stream);
         return HIPKKT_OK;
     });
 }
@@ -1894,10 +1891,7 @@ static int sys_solve_into(hipkkt_kkt_t h, const double* rx, const double* rz, do
     launch_pack_rhs(h->b.p, rx, rz, h->K.n, h->K.m, h->K.p, h->stream);
     int rc = kkt_solve_core(h);
     if (rc != HIPKKT_OK) return rc;
-    if (outx && h->K.n)
-        HIP_CHECK(hipMemcpyAsync(outx, h->cur_x, (size_t)h->K.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (outz && h->K.m)
-        HIP_CHECK(hipMemcpyAsync(outz, h->cur_x + h->K.n, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    launch_unpack_lhs(outx, outz, h->cur_x, h->K.n, h->K.m, h->stream);
     return HIPKKT_OK;
 }
 

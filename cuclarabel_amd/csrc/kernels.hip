@@ -321,6 +321,18 @@ void launch_accept_columns(double* x, const double* cand, double* e, const doubl
     if (N <= 0 || nrhs <= 0) return;
     hipLaunchKernelGGL(k_accept_columns, dim3(grid_for(N, 256, 1024), nrhs), dim3(256), 0, st, x, cand, e, e2, mask, N);
 }
+__global__ void k_unpack_lhs(double* __restrict__ lhsx, double* __restrict__ lhsz, const double* __restrict__ x, int n, int m)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x) {
+        if (i < n) { if (lhsx) lhsx[i] = x[i]; }
+        else if (lhsz) lhsz[i - n] = x[i];
+    }
+}
+void launch_unpack_lhs(double* lhsx, double* lhsz, const double* x, int n, int m, hipStream_t st)
+{
+    if (n + m <= 0 || (!lhsx && !lhsz)) return;
+    hipLaunchKernelGGL(k_unpack_lhs, dim3(grid_for(n + m, 256)), dim3(256), 0, st, lhsx, lhsz, x, n, m);
+}
 __global__ void k_zero_ints(int* __restrict__ p, int n)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;

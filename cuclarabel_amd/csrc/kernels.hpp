@@ -205,6 +205,9 @@ void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m
 void launch_accept_columns(double* x, const double* cand, double* e, const double* e2, const int* mask, int N,
                            int nrhs, hipStream_t st);
 void launch_check_finite(const double* v, int n, int* flag, hipStream_t st);
+// kktsolver_getlhs! (kktsolver_directldl.jl:329-343) on the device: lhsx = x[0:n], lhsz = x[n:n+m]; either may be null.
+// One kernel instead of two device-to-device copies (the copy engine's latency is several kernel launches' worth).
+void launch_unpack_lhs(double* lhsx, double* lhsz, const double* x, int n, int m, hipStream_t st);
 // p[0..n) = 0 with a kernel: a small hipMemsetAsync stalls the stream for ~40 us on this stack
 void launch_zero_ints(int* p, int n, hipStream_t st);
 
