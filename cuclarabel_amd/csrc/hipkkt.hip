@@ -170,6 +170,26 @@ public:
     {
         if (nrhs <= 0) return;
         if (nrhs == 1) { solve(d_B, d_X); return; }
+        const int KP = multi_prepare(nrhs);
+        launch_permute_in(d_B, ldb, xp_m.p, KP, d_iperm.p, S.N, nrhs, stream);
+        multi_sweeps(KP);
+        launch_permute_out(d_X, ldx, xp_m.p, KP, d_iperm.p, S.N, nrhs, stream);
+        HIP_CHECK(hipGetLastError());
+    }
+    // the same with ROW-major vectors, N x KP (KP a multiple of 16, padding columns zero); d_X may alias d_B
+    void solve_multi_rm(const double* d_B, double* d_X, int KP)
+    {
+        if (KP <= 0 || (KP & 15)) throw ArgError("solve_multi_rm: KP must be a positive multiple of 16");
+        multi_prepare(KP);
+        launch_permute_rows(xp_m.p, d_B, KP, d_iperm.p, S.N, 0, stream);
+        multi_sweeps(KP);
+        launch_permute_rows(d_X, xp_m.p, KP, d_iperm.p, S.N, 1, stream);
+        HIP_CHECK(hipGetLastError());
+    }
+
+private:
+    int multi_prepare(int nrhs)
+    {
         const int KP = (nrhs + 15) & ~15;
         if (KP / 8 > 65535) throw ArgError("solve_multi: too many right-hand sides per call");
         wait_w(stream);
@@ -178,6 +198,11 @@ public:
             uvec_m.alloc(std::max<size_t>(S.rows.size(), 1) * KP);
             multi_cap = (size_t)KP;
         }
+        if (!d_iperm.p) d_iperm.upload(S.iperm);
+        return KP;
+    }
+    void multi_sweeps(int KP)
+    {
         SolveArgs a;
         a.T = tree();
         a.fronts = fronts.p;
@@ -188,17 +213,14 @@ public:
         a.xp = xp_m.p;
         a.uvec = uvec_m.p;
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
-        if (!d_iperm.p) d_iperm.upload(S.iperm);
-        launch_permute_in(d_B, ldb, xp_m.p, KP, d_iperm.p, S.N, nrhs, stream);
         for (const Launch& L : launches) launch_fwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
         for (size_t q = launches.size(); q-- > 0;) {
             const Launch& L = launches[q];
             launch_bwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
         }
-        launch_permute_out(d_X, ldx, xp_m.p, KP, d_iperm.p, S.N, nrhs, stream);
-        HIP_CHECK(hipGetLastError());
     }
 
+public:
     ~LDLEngine()
     {
         release_top();
@@ -1723,13 +1745,14 @@ int hipkkt_kkt_solve(hipkkt_kkt_t h, double* lhsx, double* lhsz)
 // not accepted any more), so every column ends where its own single solve would.
 static void kkt_multi_reserve(hipkkt_kkt_t h, size_t k)
 {
+    k = (k + 15) & ~(size_t)15;                      // the row-major path pads the columns to a multiple of 16
     if (k <= h->mcap) return;
     const size_t N = (size_t)h->K.N;
     h->mB.alloc(N * k); h->mX.alloc(N * k); h->mC.alloc(N * k); h->mE.alloc(N * k); h->mE2.alloc(N * k);
-    h->mpartial.alloc((size_t)(kNormParts + 1) * k);
+    h->mpartial.alloc(std::max((size_t)(kNormParts + 1) * k, (size_t)2 * 512 * k));
     if (h->nlong && k > h->long_partial_cols) { h->long_partial.alloc((size_t)h->nchunks * k); h->long_partial_cols = k; }
     h->mnorms.alloc(2 * k);
-    h->mmask.alloc(k);
+    h->mmask.alloc(k);                               // (k is padded: enough for the row-major path's KP entries)
     h->mcap = k;
 }
 
@@ -1809,6 +1832,82 @@ static int kkt_solve_multi_core(hipkkt_kkt_t h, int k, int64_t* ir_out)
     return HIPKKT_OK;
 }
 
+// The same on ROW-major work vectors (N x KP): used when the CSR image has no long rows.  A row of 16 columns is one
+// cache line, so the residual's gather of x, the permutations and the accept step all move whole lines.
+static int kkt_solve_multi_core_rm(hipkkt_kkt_t h, int k, int KP, int64_t* ir_out)
+{
+    const hipkkt_settings& st = h->st;
+    const int N = (int)h->K.N;
+    std::vector<int64_t> ir((size_t)k, 0);
+    auto trisolve = [&](const double* rhs, double* out) {
+        int ps = h->prof.begin(2, h->stream);
+        h->eng->solve_multi_rm(rhs, out, KP);
+        h->prof.end(ps, h->stream);
+    };
+    trisolve(h->mB.p, h->mX.p);
+    if (!st.iterative_refinement_enable) {
+        int bad = 0;
+        launch_zero_ints(h->fail.p, 1, h->stream);
+        launch_check_finite(h->mX.p, N * KP, h->fail.p, h->stream);
+        HIP_CHECK(hipMemcpyAsync(&bad, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (ir_out) std::copy(ir.begin(), ir.end(), ir_out);
+        return bad ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
+    }
+    const SpmvDev A = kkt_spmv(h);
+    std::vector<double> hn(2 * (size_t)KP), norme((size_t)k), normb((size_t)k);
+    std::vector<int> active((size_t)k, 1), mask((size_t)KP, 0);
+    {
+        int pr = h->prof.begin(3, h->stream);
+        launch_residual_rm(A, h->mB.p, h->mX.p, h->mE.p, h->mpartial.p, h->mnorms.p, h->mnorms.p + KP, KP, h->stream);
+        h->prof.end(pr, h->stream);
+        HIP_CHECK(hipMemcpyAsync(hn.data(), h->mnorms.p, 2 * (size_t)KP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    for (int j = 0; j < k; ++j) {
+        norme[j] = hn[j];
+        normb[j] = hn[KP + j];
+        if (!std::isfinite(norme[j])) return HIPKKT_NUMERIC_FAILURE;
+    }
+    for (int i = 0; i < st.iterative_refinement_max_iter; ++i) {
+        bool any = false;
+        for (int j = 0; j < k; ++j) {
+            if (active[j] && norme[j] <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb[j]) active[j] = 0;
+            any = any || active[j];
+        }
+        if (!any) break;
+        trisolve(h->mE.p, h->mC.p);                                               // dx_j = K^{-1} e_j
+        launch_axpby_sum(h->mC.p, h->mC.p, h->mX.p, (int64_t)N * KP, h->stream);  // prospective x_j + dx_j
+        int pr = h->prof.begin(3, h->stream);
+        launch_residual_rm(A, h->mB.p, h->mC.p, h->mE2.p, h->mpartial.p, h->mnorms.p, nullptr, KP, h->stream);
+        h->prof.end(pr, h->stream);
+        HIP_CHECK(hipMemcpyAsync(hn.data(), h->mnorms.p, (size_t)KP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        for (int j = 0; j < k; ++j) {
+            mask[j] = 0;
+            if (!active[j]) continue;
+            ir[j]++;
+            h->prof.acc.ir_iterations++;
+            if (!std::isfinite(hn[j])) return HIPKKT_NUMERIC_FAILURE;
+            const double ratio = norme[j] / hn[j];
+            if (ratio < st.iterative_refinement_stop_ratio) {
+                if (ratio > 1.0) mask[j] = 1;
+                active[j] = 0;
+            } else {
+                mask[j] = 1;
+            }
+            if (mask[j]) norme[j] = hn[j];
+        }
+        HIP_CHECK(hipMemcpyAsync(h->mmask.p, mask.data(), (size_t)KP * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        launch_accept_columns_rm(h->mX.p, h->mC.p, h->mE.p, h->mE2.p, h->mmask.p, N, KP, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));      // `mask` (pageable) must outlive the copy
+    }
+    h->last_ir = 0;
+    for (int j = 0; j < k; ++j) h->last_ir += ir[j];
+    if (ir_out) std::copy(ir.begin(), ir.end(), ir_out);
+    return HIPKKT_OK;
+}
+
 static void kkt_multi_unpack(hipkkt_kkt_t h, int k, double* lhsx, double* lhsz, hipMemcpyKind kind)
 {
     const size_t n = (size_t)h->K.n, m = (size_t)h->K.m, N = (size_t)h->K.N;
@@ -1826,7 +1925,29 @@ int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double* d_rhs
             throw ArgError("hipkkt_kkt_solve_multi_dev: bad argument");
         if (nrhs == 0) return HIPKKT_OK;
         HIP_CHECK(hipSetDevice(h->device));
+        if (nrhs == 1) {
+            // one column: the single-column path (persistent top kernel, no padding to 16 columns), on a borrowed
+            // right-hand-side buffer so that the one set by hipkkt_kkt_setrhs stays as it is
+            kkt_multi_reserve(h, 1);
+            std::swap(h->b.p, h->mB.p);
+            launch_pack_rhs(h->b.p, d_rhsx, d_rhsz, h->K.n, h->K.m, h->K.p, h->stream);
+            int rc;
+            try { rc = kkt_solve_core(h); } catch (...) { std::swap(h->b.p, h->mB.p); throw; }
+            std::swap(h->b.p, h->mB.p);
+            if (ir_iterations) ir_iterations[0] = h->last_ir;
+            if (rc != HIPKKT_OK) return rc;
+            launch_unpack_lhs(d_lhsx, d_lhsz, h->cur_x, h->K.n, h->K.m, h->stream);
+            return HIPKKT_OK;
+        }
         kkt_multi_reserve(h, (size_t)nrhs);
+        if (h->nlong == 0) {
+            const int KP = ((int)nrhs + 15) & ~15;
+            launch_pack_rhs_rm(h->mB.p, d_rhsx, d_rhsz, h->K.n, h->K.m, h->K.p, (int)nrhs, KP, h->stream);
+            int rc = kkt_solve_multi_core_rm(h, (int)nrhs, KP, ir_iterations);
+            if (rc != HIPKKT_OK) return rc;
+            launch_unpack_lhs_rm(d_lhsx, d_lhsz, h->mX.p, h->K.n, h->K.m, (int)nrhs, KP, h->stream);
+            return HIPKKT_OK;
+        }
         launch_pack_rhs(h->mB.p, d_rhsx, d_rhsz, h->K.n, h->K.m, h->K.p, h->stream, (int)nrhs);
         int rc = kkt_solve_multi_core(h, (int)nrhs, ir_iterations);
         if (rc != HIPKKT_OK) return rc;
@@ -1850,6 +1971,20 @@ int hipkkt_kkt_solve_multi(hipkkt_kkt_t h, int64_t nrhs, const double* rhsx, con
         double* sz = h->mC.p + n * k;
         if (n) HIP_CHECK(hipMemcpyAsync(sx, rhsx, n * k * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (m) HIP_CHECK(hipMemcpyAsync(sz, rhsz, m * k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (h->nlong == 0) {
+            const int KP = ((int)nrhs + 15) & ~15;
+            launch_pack_rhs_rm(h->mB.p, sx, sz, h->K.n, h->K.m, h->K.p, (int)nrhs, KP, h->stream);
+            int rc = kkt_solve_multi_core_rm(h, (int)nrhs, KP, ir_iterations);
+            if (rc != HIPKKT_OK) return rc;
+            // column-major staging in the candidate buffer again, then to the host
+            double* ox = h->mC.p;
+            double* oz = h->mC.p + n * k;
+            launch_unpack_lhs_rm(lhsx ? ox : nullptr, lhsz ? oz : nullptr, h->mX.p, h->K.n, h->K.m, (int)nrhs, KP, h->stream);
+            if (lhsx && n) HIP_CHECK(hipMemcpyAsync(lhsx, ox, n * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (lhsz && m) HIP_CHECK(hipMemcpyAsync(lhsz, oz, m * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            return HIPKKT_OK;
+        }
         launch_pack_rhs(h->mB.p, sx, sz, h->K.n, h->K.m, h->K.p, h->stream, (int)nrhs);
         int rc = kkt_solve_multi_core(h, (int)nrhs, ir_iterations);
         if (rc != HIPKKT_OK) return rc;

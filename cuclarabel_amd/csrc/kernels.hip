@@ -1097,3 +1097,133 @@ void launch_lrscale(double* values, const int* row, const int* col, int64_t nnz,
 }
 
 }  // namespace hipkkt
+
+
+// =====================================================================================
+//  Row-major multi-column helpers (N x KP): setrhs!/getlhs!, residual with norms, accept
+// =====================================================================================
+namespace hipkkt {
+
+__global__ void k_pack_rhs_rm(double* __restrict__ B, const double* __restrict__ rx, const double* __restrict__ rz, int n,
+                              int m, int p, int nrhs, int KP)
+{
+    // thread = (row i, group of 8 columns): column reads coalesced over i, one 64-byte write per thread
+    const int N = n + m + p, groups = KP >> 3;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)N * groups;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % N), g = (int)(idx / N);
+        double v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int col = 8 * g + c;
+            v[c] = (col < nrhs) ? (i < n ? rx[(int64_t)col * n + i] : (i < n + m ? rz[(int64_t)col * m + (i - n)] : 0.0)) : 0.0;
+        }
+        double2* dst = reinterpret_cast<double2*>(B + (int64_t)i * KP + 8 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[c] = make_double2(v[2 * c], v[2 * c + 1]);
+    }
+}
+void launch_pack_rhs_rm(double* B, const double* rx, const double* rz, int n, int m, int p, int nrhs, int KP, hipStream_t st)
+{
+    const int64_t work = (int64_t)(n + m + p) * (KP >> 3);
+    hipLaunchKernelGGL(k_pack_rhs_rm, dim3(grid_for(work, 256, 8192)), dim3(256), 0, st, B, rx, rz, n, m, p, nrhs, KP);
+}
+__global__ void k_unpack_lhs_rm(double* __restrict__ lhsx, double* __restrict__ lhsz, const double* __restrict__ X, int n,
+                                int m, int nrhs, int KP)
+{
+    const int rows = n + m, groups = KP >> 3;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)rows * groups;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % rows), g = (int)(idx / rows);
+        const double2* src = reinterpret_cast<const double2*>(X + (int64_t)i * KP + 8 * g);
+        double v[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const double2 t = src[c]; v[2 * c] = t.x; v[2 * c + 1] = t.y; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int col = 8 * g + c;
+            if (col >= nrhs) continue;
+            if (i < n) { if (lhsx) lhsx[(int64_t)col * n + i] = v[c]; }
+            else if (lhsz) lhsz[(int64_t)col * m + (i - n)] = v[c];
+        }
+    }
+}
+void launch_unpack_lhs_rm(double* lhsx, double* lhsz, const double* X, int n, int m, int nrhs, int KP, hipStream_t st)
+{
+    if (n + m <= 0 || (!lhsx && !lhsz)) return;
+    const int64_t work = (int64_t)(n + m) * (KP >> 3);
+    hipLaunchKernelGGL(k_unpack_lhs_rm, dim3(grid_for(work, 256, 8192)), dim3(256), 0, st, lhsx, lhsz, X, n, m, nrhs, KP);
+}
+
+// workgroup = 16 rows x 16 columns per step; the row's matrix entries are the same for its 16 lanes, the gathered
+// x rows are 128 contiguous bytes
+constexpr int kRmBlocks = 512;
+__global__ __launch_bounds__(256) void k_residual_rm(SpmvDev A, const double* __restrict__ B, const double* __restrict__ X,
+                                                     double* __restrict__ E, double* __restrict__ partial,
+                                                     double* __restrict__ bpartial, int KP)
+{
+    __shared__ double sh[2][16][17];
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int cb0 = blockIdx.y * 16;
+    double vmax = 0.0, bmax = 0.0;
+    for (int row = blockIdx.x * 16 + r; row < A.N; row += gridDim.x * 16) {
+        const int64_t q0 = A.ptr[row], q1 = A.ptr[row + 1];
+        double acc = 0.0;
+        for (int64_t q = q0; q < q1; ++q) acc = fma(A.val[q], X[(int64_t)A.col[q] * KP + cb0 + c], acc);
+        const double bv = B[(int64_t)row * KP + cb0 + c];
+        const double rr = bv - acc;
+        E[(int64_t)row * KP + cb0 + c] = rr;
+        vmax = isfinite(rr) ? fmax(vmax, fabs(rr)) : INFINITY;
+        bmax = isfinite(bv) ? fmax(bmax, fabs(bv)) : INFINITY;
+    }
+    sh[0][r][c] = vmax;
+    sh[1][r][c] = bmax;
+    __syncthreads();
+    if (r == 0) {
+        double v = 0.0, w = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v = fmax(v, sh[0][k][c]); w = fmax(w, sh[1][k][c]); }
+        partial[(int64_t)blockIdx.x * KP + cb0 + c] = v;
+        if (bpartial) bpartial[(int64_t)blockIdx.x * KP + cb0 + c] = w;
+    }
+}
+__global__ void k_finish_norm_rm(const double* __restrict__ partial, const double* __restrict__ bpartial, int nblocks, int KP,
+                                 double* __restrict__ out, double* __restrict__ bout)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= KP) return;
+    double v = 0.0, w = 0.0;
+    for (int i = 0; i < nblocks; ++i) {
+        v = fmax(v, partial[(int64_t)i * KP + c]);
+        if (bpartial) w = fmax(w, bpartial[(int64_t)i * KP + c]);
+    }
+    out[c] = v;
+    if (bpartial) bout[c] = w;
+}
+void launch_residual_rm(const SpmvDev& A, const double* B, const double* X, double* E, double* partial, double* norm_out,
+                        double* normb_out, int KP, hipStream_t st)
+{
+    int g = (A.N + 15) / 16;
+    if (g > kRmBlocks) g = kRmBlocks;
+    if (g < 1) g = 1;
+    double* bpartial = normb_out ? partial + (size_t)kRmBlocks * KP : nullptr;
+    hipLaunchKernelGGL(k_residual_rm, dim3(g, KP / 16), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
+    hipLaunchKernelGGL(k_finish_norm_rm, dim3((KP + 63) / 64), dim3(64), 0, st, (const double*)partial, (const double*)bpartial, g,
+                       KP, norm_out, normb_out);
+}
+__global__ void k_accept_columns_rm(double* __restrict__ X, const double* __restrict__ cand, double* __restrict__ E,
+                                    const double* __restrict__ E2, const int* __restrict__ mask, int64_t total, int KP)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mask[i % KP]) { X[i] = cand[i]; E[i] = E2[i]; }
+    }
+}
+void launch_accept_columns_rm(double* X, const double* cand, double* E, const double* E2, const int* mask, int N, int KP,
+                              hipStream_t st)
+{
+    const int64_t total = (int64_t)N * KP;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_accept_columns_rm, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, X, cand, E, E2, mask, total, KP);
+}
+
+}  // namespace hipkkt

@@ -149,6 +149,8 @@ void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
 // several right-hand sides: work vectors row-major N x KP / sum(nb) x KP (KP = columns rounded up to 16)
 // iperm[caller's index] = permuted index
 void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
+// row-major source / destination (N x KP): rows move, columns stay; dir 0: Xp[iperm[o]] = B[o], 1: X[o] = Xp[iperm[o]]
+void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st);
 void launch_permute_out(double* X, int64_t ldx, const double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
 void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
@@ -201,6 +203,15 @@ void launch_gather_values(double* val, const double* Kval, const int* vmap, int6
 // b_j = [rx_j; rz_j; 0]: rx is n x nrhs (ld n), rz is m x nrhs (ld m), b is N x nrhs (ld N)
 void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m, int p, hipStream_t st,
                      int nrhs = 1);
+// ---- row-major (N x KP, KP = columns rounded up to 16, padding columns zero) variants for the multi-column path:
+// a row of 16 columns is one 128-byte line, so the SpMV's gather of x moves whole lines
+void launch_pack_rhs_rm(double* B, const double* rx, const double* rz, int n, int m, int p, int nrhs, int KP, hipStream_t st);
+void launch_unpack_lhs_rm(double* lhsx, double* lhsz, const double* X, int n, int m, int nrhs, int KP, hipStream_t st);
+// norm_out[c] = ||e_c||_inf, normb_out[c] = ||b_c||_inf (nullable); partial: 2 * 512 * KP doubles; no long rows (A.nlong == 0)
+void launch_residual_rm(const SpmvDev& A, const double* B, const double* X, double* E, double* partial, double* norm_out,
+                        double* normb_out, int KP, hipStream_t st);
+void launch_accept_columns_rm(double* X, const double* cand, double* E, const double* E2, const int* mask, int N, int KP,
+                              hipStream_t st);
 // columns j with mask[j] != 0: x_j = cand_j, e_j = e2_j  (N x nrhs, ld N)
 void launch_accept_columns(double* x, const double* cand, double* e, const double* e2, const int* mask, int N,
                            int nrhs, hipStream_t st);

@@ -1113,6 +1113,29 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
     }
 }
 
+__global__ __launch_bounds__(256) void k_permute_rows(double* __restrict__ dst, const double* __restrict__ src, int KP,
+                                                      const int* __restrict__ iperm, int N, int dir)
+{
+    const int groups = KP >> 3;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)N * groups;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups), o = (int)(idx / groups);          // a row's groups are adjacent threads
+        const int i = iperm[o];
+        const double2* s2 = reinterpret_cast<const double2*>(src + (int64_t)(dir ? i : o) * KP + 8 * g);
+        double2* d2 = reinterpret_cast<double2*>(dst + (int64_t)(dir ? o : i) * KP + 8 * g);
+        double2 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = s2[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d2[c] = v[c];
+    }
+}
+void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st)
+{
+    const int64_t work = (int64_t)N * (KP >> 3);
+    int g = (int)std::min<int64_t>((work + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_permute_rows, dim3(g < 1 ? 1 : g), dim3(256), 0, st, dst, src, KP, iperm, N, dir);
+}
 void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st)
 {
     const int64_t work = (int64_t)N * (KP >> 3);
