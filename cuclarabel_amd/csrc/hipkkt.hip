@@ -275,8 +275,8 @@ private:
         // W = [T; M] of everything below are formed on a side stream meanwhile (HIPKKT_NO_OVERLAP=1 disables)
         static const bool no_overlap = std::getenv("HIPKKT_NO_OVERLAP") != nullptr;
         const size_t nl = launches.size();
-        const size_t first_top = (!side && !no_overlap && !want_stamps && top_launches > 0 && top_launches < nl)
-                                     ? nl - top_launches : nl;
+        const size_t first_top = (!side && !no_overlap && !want_stamps && late_launches > 0 && late_launches < nl)
+                                     ? nl - late_launches : nl;
         bool eager_fork = false;
         for (size_t q = 0; q < nl; ++q) {
             const Launch& L = launches[q];
@@ -356,8 +356,13 @@ private:
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         const size_t nl = launches.size();
-        const size_t ntl = (no_top || !use_top || top_disabled) ? 0 : top_launches;   // the last ntl launches form the persistent top
-        const size_t first_w = nl - std::min(nl, top_launches);     // fronts from here on get their W late (w_pending)
+        // the persistent kernel covers the last ntl launches.  Right after a factorisation the W of the narrow top is
+        // still being formed on the side stream: that sweep keeps the per-level launches for the levels below the
+        // narrow top, so that the formation hides behind them
+        size_t ntl = (no_top || !use_top || top_disabled) ? 0 : top_launches;
+        int ncount = top_count;
+        if (ntl > 0 && w_pending && late_launches > 0 && late_launches < ntl) { ntl = late_launches; ncount = late_count; }
+        const size_t first_w = nl - std::min(nl, late_launches);    // fronts from here on get their W late (w_pending)
         for (size_t q = 0; q + ntl < nl; ++q) {
             const Launch& L = launches[q];
             if (q == first_w) wait_w(st);
@@ -371,7 +376,7 @@ private:
         wait_w(st);
         if (ntl > 0) {
             const Launch& L0 = launches[nl - ntl];
-            launch_top_solve(a, L0.begin, top_count, top_lds, top_flags.p, ++top_epoch, st);
+            launch_top_solve(a, L0.begin, ncount, std::min(top_grid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st);
         }
         for (size_t q = nl - ntl; q-- > 0;) {
             const Launch& L = launches[q];
@@ -477,8 +482,8 @@ private:
     DBuf<int64_t> d_tile_cut;
     DBuf<int64_t> d_desc;        // FrontDesc = 8 x int64
     DBuf<int> d_spos, d_sn_parent, top_flags;
-    size_t top_launches = 0, top_lds = 0;
-    int top_count = 0, top_epoch = 0;
+    size_t top_launches = 0, late_launches = 0, top_lds = 0;
+    int top_count = 0, late_count = 0, top_grid = 0, top_epoch = 0;
     std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
     DBuf<int> d_gl_src, d_udst;
     std::vector<Launch> launches;
@@ -640,29 +645,40 @@ private:
             for (size_t q = 0; q < sched.size(); ++q) spos[sched[q]] = (int)q;
             d_spos.upload(spos);
             d_sn_parent.upload(S.sn_parent);
-            // persistent top: the longest suffix of block-class launches with <= kTopMaxFronts fronts
-            top_launches = 0; top_count = 0; top_lds = 0;
-            for (size_t q = launches.size(); q-- > 0;) {
-                const Launch& L = launches[q];
-                if (L.small || top_count + L.count > kTopMaxFronts) break;
-                top_count += L.count;
-                top_lds = std::max(top_lds, L.lds_solve);
-                ++top_launches;
-            }
+            // late_launches: the longest suffix of block-class launches with <= kTopMaxFronts fronts in total -- the
+            // narrow top of the tree, whose W is formed behind the factorisation (enqueue_factor / wait_w)
+            late_launches = 0;
             {
-                // every workgroup of the persistent kernel must be resident: shrink the set to what the
-                // device admits for this LDS size (dropping whole levels from the bottom of the set)
-                int cap = std::min(kTopMaxFronts, top_solve_capacity(top_lds));
-                size_t first = launches.size() - top_launches;
-                while (top_launches > 0 && top_count > cap) {
-                    top_count -= launches[first].count;
-                    ++first;
-                    --top_launches;
+                int cnt = 0;
+                for (size_t q = launches.size(); q-- > 0;) {
+                    const Launch& L = launches[q];
+                    if (L.small || cnt + L.count > kTopMaxFronts) break;
+                    cnt += L.count;
+                    ++late_launches;
                 }
-                top_lds = 0;
-                for (size_t q = first; q < launches.size(); ++q) top_lds = std::max(top_lds, launches[q].lds_solve);
+                late_count = cnt;
+                if (late_launches < 3) { late_launches = 0; late_count = 0; }
             }
-            if (top_launches < 3) { top_launches = 0; top_count = 0; }     // not worth a special kernel
+            // persistent top: the longest suffix of block-class launches none of which holds more fronts than the
+            // device keeps resident workgroups of the persistent kernel (a workgroup then has at most one front per
+            // level; k_top_solve walks its fronts in level order)
+            top_launches = 0; top_count = 0; top_lds = 0; top_grid = 0;
+            {
+                size_t lds = 0;
+                for (size_t q = launches.size(); q-- > 0 && !launches[q].small;) lds = std::max(lds, launches[q].lds_solve);
+                static const int cap_env = std::getenv("HIPKKT_TOP_CAP") ? std::atoi(std::getenv("HIPKKT_TOP_CAP")) : 1 << 30;
+                const int cap = std::min(std::min(kTopMaxFronts, cap_env), top_solve_capacity(lds));
+                for (size_t q = launches.size(); q-- > 0;) {
+                    const Launch& L = launches[q];
+                    static const double mult = std::getenv("HIPKKT_TOP_MULT") ? std::atof(std::getenv("HIPKKT_TOP_MULT")) : 1.0;
+                    if (L.small || L.count > mult * cap) break;
+                    top_count += L.count;
+                    top_lds = std::max(top_lds, L.lds_solve);
+                    ++top_launches;
+                }
+                top_grid = std::min(cap, top_count);
+            }
+            if (top_launches < 3) { top_launches = 0; top_count = 0; top_grid = 0; }     // not worth a special kernel
             top_flags.alloc((size_t)2 * std::max(top_count, 1) + 4);
             HIP_CHECK(hipMemset(top_flags.p, 0, top_flags.n * sizeof(int)));
             tinv.alloc((size_t)toff[S.nsuper]);

@@ -128,7 +128,8 @@ size_t solve_lds_bytes(int fmax, int ncmax);
 // persistent kernel over the top `count` fronts (schedule positions begin ..): forward then backward sweep
 constexpr int kTopMaxFronts = 480;
 int top_solve_capacity(size_t lds);   // resident workgroups the device guarantees for the persistent kernel
-void launch_top_solve(const SolveArgs& a, int begin, int count, size_t lds, int* flags, int epoch, hipStream_t st);
+void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
+                      hipStream_t st);
 // max_blocks > 0: at most that many workgroups (each walks several supernodes)
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks = 0);

@@ -364,7 +364,7 @@ constexpr int kTopPF = 4;        // forward items per wave kept in registers (8 
 constexpr int kTopPB = 5;        // backward items per wave
 
 template <int BS>
-__global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop)
+__global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop, int nflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int sh_ok;
@@ -372,168 +372,188 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const int me = blockIdx.x;
-    const FrontDesc fd = T.desc[begin + me];
-    const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
-    const int f = nc + nb;
-    const double* __restrict__ W = A.tinv + fd.w_off;
-    const double* __restrict__ Wt = W + (int64_t)f * nc;
-    const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
-    double* y = smem;
-    double* part = smem + fpad;
+    // Workgroup `me` owns the fronts at positions me, me + G, me + 2G, ... of the set (positions are in level order,
+    // leaves first): forward in ascending, then backward in descending order.  Every task depends only on tasks that
+    // come earlier in that global order and every workgroup is resident, so the earliest unfinished task can always
+    // run -- no deadlock whatever the number of fronts.  A level of the set never holds more fronts than G (host), so
+    // a workgroup has at most one front per level.
+    const int me = blockIdx.x, G = gridDim.x;
     int* flag_f = flags;                 // forward done
-    int* flag_b = flags + ntop;          // backward done
-    int* abort_word = flags + 2 * ntop;
+    int* flag_b = flags + nflag;         // backward done (nflag >= ntop: the layout does not move with the set's size)
+    int* abort_word = flags + 2 * nflag;
     const long long t0 = wall_clock64();
     const long long limit = 5000000;     // 50 ms at 100 MHz: far beyond any real sweep
 
-    // ================= forward: preload =================
-    const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6, nitF = nrb * nks;
-    ItemRegs rf[kTopPF];
+    // ================= forward =================
+    int pos = me;
+    for (; pos < ntop; pos += G) {
+        const FrontDesc fd = T.desc[begin + pos];
+        const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+        const int64_t rp = fd.rp;
+        const int f = nc + nb;
+        const double* __restrict__ W = A.tinv + fd.w_off;
+        const int fpad = (f + 3) & ~3;
+        double* y = smem;
+        double* part = smem + fpad;
+        // ---- preload
+        const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6, nitF = nrb * nks;
+        ItemRegs rf[kTopPF];
 #pragma unroll
-    for (int p = 0; p < kTopPF; ++p) {
-        const int it = wv + p * NW;
-        const int ks = it / nrb, rb = it - ks * nrb;
-        const int r = rb * 64 + lane, k0 = 8 * ks;
-        const bool live = it < nitF && !(rb * 64 + 63 < k0);
+        for (int p = 0; p < kTopPF; ++p) {
+            const int it = wv + p * NW;
+            const int ks = it / nrb, rb = it - ks * nrb;
+            const int r = rb * 64 + lane, k0 = 8 * ks;
+            const bool live = it < nitF && !(rb * 64 + 63 < k0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
-    }
-    int gsrc[4] = {-1, -1, -1, -1};
-    int64_t g0 = 0, g1 = 0;
-    double bmine = 0.0;
-    if (tid < f) {
-        const int64_t lc = (int64_t)c0 + rp + tid;
-        g0 = T.gl_ptr[lc];
-        g1 = T.gl_ptr[lc + 1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
-        if (tid < nc) bmine = A.b[T.perm[c0 + tid]];
-    }
-    if (tid == 0) sh_ok = 1;
-    __syncthreads();
-    if (wv == 0) {
-        // children inside the persistent set: poll their forward flags, lanes over children
-        bool ok = true;
-        for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
-            const int pos = T.spos[T.child_idx[e]] - begin;
-            if (pos >= 0) ok = wait_flag(flag_f + pos, epoch, abort_word, t0, limit) && ok;
+            for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
         }
-        if (!ok) sh_ok = 0;
-    }
-    __syncthreads();
-    if (!sh_ok) return;
-    // ---- gather (only the handed-over values are loaded now)
-    if (tid < f) {
-        double u[4];
+        int gsrc[4] = {-1, -1, -1, -1};
+        int64_t g0 = 0, g1 = 0;
+        double bmine = 0.0;
+        if (tid < f) {
+            const int64_t lc = (int64_t)c0 + rp + tid;
+            g0 = T.gl_ptr[lc];
+            g1 = T.gl_ptr[lc + 1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
-        double v = bmine;
+            for (int q = 0; q < 4; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
+            if (tid < nc) bmine = A.b[T.perm[c0 + tid]];
+        }
+        if (tid == 0) sh_ok = 1;
+        __syncthreads();
+        if (wv == 0) {
+            // children inside the persistent set: poll their forward flags, lanes over children
+            bool ok = true;
+            for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
+                const int cp = T.spos[T.child_idx[e]] - begin;
+                if (cp >= 0) ok = wait_flag(flag_f + cp, epoch, abort_word, t0, limit) && ok;
+            }
+            if (!ok) sh_ok = 0;
+        }
+        __syncthreads();
+        if (!sh_ok) return;
+        // ---- gather (only the handed-over values are loaded now)
+        if (tid < f) {
+            double u[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v += u[q];
-        for (int64_t g = g0 + 4; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
-        y[tid] = v;
-    }
-    for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
-        double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
-        const int64_t lc = (int64_t)c0 + rp + i;
-        for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
-        y[i] = v;
-    }
-    __syncthreads();
+            for (int q = 0; q < 4; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
+            double v = bmine;
 #pragma unroll
-    for (int p = 0; p < kTopPF; ++p) {
-        const int it = wv + p * NW;
-        if (it < nitF) item_apply(rf[p], y, f, nc, part, fpad, it, nrb, lane);
-    }
-    for (int it = wv + kTopPF * NW; it < nitF; it += NW) {
-        const int ks = it / nrb, rb = it - ks * nrb;
-        const int r = rb * 64 + lane, k0 = 8 * ks;
-        ItemRegs rr;
-        const bool live = !(rb * 64 + 63 < k0);
+            for (int q = 0; q < 4; ++q) v += u[q];
+            for (int64_t g = g0 + 4; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+            y[tid] = v;
+        }
+        for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
+            double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
+            const int64_t lc = (int64_t)c0 + rp + i;
+            for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+            y[i] = v;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) rr.m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
-        item_apply(rr, y, f, nc, part, fpad, it, nrb, lane);
+        for (int p = 0; p < kTopPF; ++p) {
+            const int it = wv + p * NW;
+            if (it < nitF) item_apply(rf[p], y, f, nc, part, fpad, it, nrb, lane);
+        }
+        for (int it = wv + kTopPF * NW; it < nitF; it += NW) {
+            const int ks = it / nrb, rb = it - ks * nrb;
+            const int r = rb * 64 + lane, k0 = 8 * ks;
+            ItemRegs rr;
+            const bool live = !(rb * 64 + 63 < k0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rr.m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+            item_apply(rr, y, f, nc, part, fpad, it, nrb, lane);
+        }
+        __syncthreads();
+        for (int i = tid; i < f; i += BS) {
+            double v = 0.0;
+            for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
+            if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
+            else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag_f + pos, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    for (int i = tid; i < f; i += BS) {
-        double v = 0.0;
-        for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
-        if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
-        else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag_f + me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // ================= backward: preload =================
-    const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3, nitB = ncb * nrs;
-    ItemRegs rbk[kTopPB];
+    // ================= backward =================
+    for (pos -= G; pos >= 0; pos -= G) {
+        const FrontDesc fd = T.desc[begin + pos];
+        const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+        const int64_t rp = fd.rp;
+        const int f = nc + nb;
+        const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;
+        const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
+        double* z = smem;
+        double* part = smem + fpad;
+        // ---- preload
+        const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3, nitB = ncb * nrs;
+        ItemRegs rbk[kTopPB];
 #pragma unroll
-    for (int p = 0; p < kTopPB; ++p) {
-        const int it = wv + p * NW;
-        const int rs = it / ncb, cb = it - rs * ncb;
-        const int j = cb * 64 + lane, r0 = 8 * rs;
-        const bool live = it < nitB && !(r0 + 7 < cb * 64);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rbk[p].m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
-    }
-    int ridx = -1;
-    double dinv = 0.0;
-    if (tid < nc) dinv = A.Dinv[c0 + tid];
-    else if (tid < f) ridx = T.rows[rp + tid - nc];
-    if (wv == 0) {
-        bool ok = true;
-        const int par = T.sn_parent[s];
-        if (lane == 0 && par >= 0) {
-            const int pos = T.spos[par] - begin;       // the parent of a top front is a top front
-            ok = wait_flag(flag_b + pos, epoch, abort_word, t0, limit);
-        }
-        if (!ok) sh_ok = 0;
-    }
-    __syncthreads();
-    if (!sh_ok) return;
-    double* z = smem;
-    if (tid < nc) z[tid] = LD_AGENT_F64(A.xp + c0 + tid) * dinv;
-    else if (tid < f) z[tid] = -LD_AGENT_F64(A.xp + ridx);
-    for (int i = tid + BS; i < f; i += BS)
-        z[i] = (i < nc) ? LD_AGENT_F64(A.xp + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < kTopPB; ++p) {
-        const int it = wv + p * NW;
-        if (it < nitB) {
+        for (int p = 0; p < kTopPB; ++p) {
+            const int it = wv + p * NW;
             const int rs = it / ncb, cb = it - rs * ncb;
             const int j = cb * 64 + lane, r0 = 8 * rs;
-            double acc = 0.0;
+            const bool live = it < nitB && !(r0 + 7 < cb * 64);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+            for (int q = 0; q < 8; ++q) rbk[p].m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+        }
+        int ridx = -1;
+        double dinv = 0.0;
+        if (tid < nc) dinv = A.Dinv[c0 + tid];
+        else if (tid < f) ridx = T.rows[rp + tid - nc];
+        if (tid == 0) sh_ok = 1;
+        __syncthreads();
+        if (wv == 0) {
+            bool ok = true;
+            const int par = T.sn_parent[s];
+            if (lane == 0 && par >= 0) {
+                const int pp = T.spos[par] - begin;        // the parent of a front of the set is in the set
+                ok = wait_flag(flag_b + pp, epoch, abort_word, t0, limit);
+            }
+            if (!ok) sh_ok = 0;
+        }
+        __syncthreads();
+        if (!sh_ok) return;
+        if (tid < nc) z[tid] = LD_AGENT_F64(A.xp + c0 + tid) * dinv;
+        else if (tid < f) z[tid] = -LD_AGENT_F64(A.xp + ridx);
+        for (int i = tid + BS; i < f; i += BS)
+            z[i] = (i < nc) ? LD_AGENT_F64(A.xp + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < kTopPB; ++p) {
+            const int it = wv + p * NW;
+            if (it < nitB) {
+                const int rs = it / ncb, cb = it - rs * ncb;
+                const int j = cb * 64 + lane, r0 = 8 * rs;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+                if (j < nc) part[rs * ncpad + j] = acc;
+            }
+        }
+        for (int it = wv + kTopPB * NW; it < nitB; it += NW) {
+            const int rs = it / ncb, cb = it - rs * ncb;
+            const int j = cb * 64 + lane, r0 = 8 * rs;
+            const bool live = !(r0 + 7 < cb * 64);
+            double acc = 0.0;
+            double m[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fma(m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
             if (j < nc) part[rs * ncpad + j] = acc;
         }
+        __syncthreads();
+        for (int j = tid; j < nc; j += BS) {
+            double v = 0.0;
+            for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
+            ST_AGENT_F64(A.xp + c0 + j, v);
+            A.out[T.perm[c0 + j]] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag_b + pos, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (int it = wv + kTopPB * NW; it < nitB; it += NW) {
-        const int rs = it / ncb, cb = it - rs * ncb;
-        const int j = cb * 64 + lane, r0 = 8 * rs;
-        const bool live = !(r0 + 7 < cb * 64);
-        double acc = 0.0;
-        double m[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = fma(m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-        if (j < nc) part[rs * ncpad + j] = acc;
-    }
-    __syncthreads();
-    for (int j = tid; j < nc; j += BS) {
-        double v = 0.0;
-        for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
-        ST_AGENT_F64(A.xp + c0 + j, v);
-        A.out[T.perm[c0 + j]] = v;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag_b + me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ W = [L11^{-1} ; L21 L11^{-1}]
@@ -1187,11 +1207,12 @@ int top_solve_capacity(size_t lds)
     per_cu = per_cu > 3 ? 3 : per_cu;
     return (int)(per_cu * prop.multiProcessorCount * 0.94);
 }
-void launch_top_solve(const SolveArgs& a, int begin, int count, size_t lds, int* flags, int epoch, hipStream_t st)
+void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
+                      hipStream_t st)
 {
-    if (count <= 0) return;
+    if (count <= 0 || grid <= 0 || nflag < count) return;
     init_solve_lds();
-    hipLaunchKernelGGL(k_top_solve<512>, dim3(count), dim3(512), lds, st, a, begin, flags, epoch, count);
+    hipLaunchKernelGGL(k_top_solve<512>, dim3(std::min(grid, count)), dim3(512), lds, st, a, begin, flags, epoch, count, nflag);
 }
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks)

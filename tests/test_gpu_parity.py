@@ -573,3 +573,47 @@ def test_full_size_headline_workload_properties_and_oracle():
     assert ok
     assert np.abs(x1 - np.concatenate([xo, zo])).max() / np.abs(x1).max() < 1e-9
     assert ks.last_ir_iterations == o.last_ir_iters
+
+
+_SMALL_GRID_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver
+from tests.oracle_bindings import make_oracle
+pb = problems.config2(n=6000)
+ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+o = make_oracle(pb, perm=ks.perm())
+assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+rng = np.random.default_rng(11)
+worst = 0.0
+for _ in range(4):
+    rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    ks.kktsolver_setrhs(rx, rz); o.kktsolver_setrhs(rx, rz)
+    x, z = np.zeros(pb.n), np.zeros(pb.m)
+    assert ks.kktsolver_solve(x, z)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok
+    worst = max(worst, max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()))
+print("levels", ks.info["nlevels"], "worst", worst)
+assert worst < 1e-9
+print("SMALL GRID OK")
+"""
+
+
+@pytest.mark.parametrize("cap,mult", [(3, 1.0), (5, 64.0)])
+def test_persistent_top_with_fewer_workgroups_than_fronts(cap, mult):
+    """The persistent kernel over the top of the tree walks several fronts per workgroup (k_top_solve: positions me,
+    me + G, ...).  HIPKKT_TOP_CAP / HIPKKT_TOP_MULT (read once per process) force a tiny grid and several fronts per
+    workgroup and level; results must still match the oracle and the grid must drain."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPKKT_TOP_CAP=str(cap), HIPKKT_TOP_MULT=str(mult))
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root)], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SMALL GRID OK" in r.stdout
