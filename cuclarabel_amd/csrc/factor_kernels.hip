@@ -258,26 +258,33 @@ __device__ inline int64_t uniform_i64(int64_t v)
 __device__ inline void apply_items_panel(const TreeDev& T, const double* __restrict__ upd, double* P, int f,
                                          int64_t i0_, int64_t i1_, int lane)
 {
-    // the range is the same for every lane: say so, and the descriptors travel through the scalar cache
+    // the range is the same for every lane
     const int64_t i0 = uniform_i64(i0_), i1 = uniform_i64(i1_);
-    for (int64_t ii = i0; ii < i1; ii += 8) {
-        ExtItem it[8];
-        double v[8];
-        int tg[8];
+    constexpr int IF = 16;        // pieces in flight
+    for (int64_t ii = i0; ii < i1; ii += 64) {
+        // the next 64 descriptors in ONE vector load round (lane l fetches item ii + l); their fields are handed out
+        // with v_readlane as the pieces are issued -- no scalar-load latency per batch
+        const ExtItem mine = T.items[min(ii + lane, i1 - 1)];
+        const int lo = (int)(mine.uoff & 0xffffffff), hi = (int)(mine.uoff >> 32);
+        const int nhere = (int)min((int64_t)64, i1 - ii);
+        for (int q0 = 0; q0 < nhere; q0 += IF) {
+            double v[IF];
+            int tg[IF];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            it[q] = T.items[min(ii + q, i1 - 1)];
-            if (ii + q >= i1) it[q].cnt = 0;
-        }
+            for (int q = 0; q < IF; ++q) {
+                const int j = min(q0 + q, 63);
+                const int64_t uoff = ((int64_t)__builtin_amdgcn_readlane(hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, j);
+                const int relstart = __builtin_amdgcn_readlane(mine.relstart, j);
+                const int cnt = (q0 + q < nhere) ? __builtin_amdgcn_readlane(mine.cnt, j) : 0;
+                const int tcol = __builtin_amdgcn_readlane(mine.tcol, j);
+                const bool ok = lane < cnt;
+                v[q] = ok ? upd[uoff + lane] : 0.0;
+                tg[q] = ok ? T.rel[relstart + lane] + tcol * f : -1;
+            }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool ok = lane < it[q].cnt;
-            v[q] = ok ? upd[it[q].uoff + lane] : 0.0;
-            tg[q] = ok ? T.rel[it[q].relstart + lane] + it[q].tcol * f : -1;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (tg[q] >= 0) P[tg[q]] += v[q];          // (a piece has at most 64 rows)
+            for (int q = 0; q < IF; ++q) {
+                if (tg[q] >= 0) P[tg[q]] += v[q];          // (a piece has at most 64 rows; pieces in item order)
+            }
         }
     }
 }
