@@ -527,6 +527,13 @@ private:
                 int s = S.level_sn[t];
                 (is_small(s) ? small : big).push_back(s);
             }
+            // a handful of one-wave fronts beside a block-class launch is not worth launches of its own (one in the
+            // factorisation, two per solve, each ~5-45 us of pure latency): they ride with the block-class fronts
+            static const int merge_small = std::getenv("HIPKKT_MERGE_SMALL") ? std::atoi(std::getenv("HIPKKT_MERGE_SMALL")) : 128;
+            if (!big.empty() && (int)small.size() <= merge_small) {
+                big.insert(big.end(), small.begin(), small.end());
+                small.clear();
+            }
             auto work = [&](int s) { return (double)front_size(s) * front_size(s) * ncols(s); };
             auto by_work = [&](int a, int b) { double wa = work(a), wb = work(b); return wa != wb ? wa > wb : a < b; };
             std::sort(small.begin(), small.end(), by_work);
