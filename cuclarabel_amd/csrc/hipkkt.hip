@@ -367,8 +367,7 @@ private:
             const Launch& L = launches[q];
             if (q == first_w) wait_w(st);
             if (L.small) {
-                launch_fwd(a, L.begin, L.count - L.ntiny, 64, 0, st);
-                launch_fwd(a, L.begin + L.count - L.ntiny, L.ntiny, 8, 0, st);
+                launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st);
             } else {
                 launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
             }
@@ -381,8 +380,7 @@ private:
         for (size_t q = nl - ntl; q-- > 0;) {
             const Launch& L = launches[q];
             if (L.small) {
-                launch_bwd(a, L.begin + L.count - L.ntiny, L.ntiny, 8, 0, st);
-                launch_bwd(a, L.begin, L.count - L.ntiny, 64, 0, st);
+                launch_bwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st);
             } else {
                 launch_bwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
             }

@@ -146,6 +146,9 @@ size_t panel_lds_bytes(int fmax, int panel_max);
 // nrhs > 1: grid.y = right-hand side column, strides in SolveArgs::ld_*
 void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
 void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
+// one launch for a level's one-wave fronts [begin, begin + nwave) and the tiny fronts behind them (single right-hand side)
+void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st);
+void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st);
 
 // several right-hand sides: work vectors row-major N x KP / sum(nb) x KP (KP = columns rounded up to 16)
 // iperm[caller's index] = permuted index

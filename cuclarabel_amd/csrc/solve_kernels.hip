@@ -35,10 +35,10 @@ __device__ inline double wave_reduce_sum(double v)
 }
 
 // ------------------------------------------------------------------ small fronts, one wave each
-__global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int count)
+__device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wv;
+    const int item = bx * 4 + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + item];
@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int co
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    const double* __restrict__ bcol = A.b + blockIdx.y * A.ld_b;          // right-hand side column blockIdx.y
-    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
-    double* __restrict__ uvec = A.uvec + blockIdx.y * A.ld_uvec;
+    const double* __restrict__ bcol = A.b + by * A.ld_b;          // right-hand side column by
+    double* __restrict__ xp = A.xp + by * A.ld_xp;
+    double* __restrict__ uvec = A.uvec + by * A.ld_uvec;
 
     // gather: right-hand side entry plus the children's contributions to this row, in child order
     double y = (lane < nc) ? bcol[T.perm[c0 + lane]] : 0.0;
@@ -77,11 +77,15 @@ __global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int co
     if (lane < nc) xp[c0 + lane] = y;
     else if (lane < f) uvec[rp + lane - nc] = y;
 }
+__global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int count)
+{
+    fwd_wave_body(A, begin, count, blockIdx.x, blockIdx.y);
+}
 
-__global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int count)
+__device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wv;
+    const int item = bx * 4 + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + item];
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
-    double* __restrict__ out = A.out + blockIdx.y * A.ld_out;
+    double* __restrict__ xp = A.xp + by * A.ld_xp;
+    double* __restrict__ out = A.out + by * A.ld_out;
 
     // lane = row: y_r = D^{-1} x_r for the front's own columns, the ancestors' solution below
     double y = 0.0;
@@ -119,16 +123,20 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
         out[T.perm[c0 + lane]] = y;
     }
 }
+__global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int count)
+{
+    bwd_wave_body(A, begin, count, blockIdx.x, blockIdx.y);
+}
 
 // ------------------------------------------------------------------ tiny fronts, eight to a wave
 // Most leaves of a KKT elimination tree are single columns with a handful of rows (cfg2: 82 000 of the
 // 92 000 one-wave fronts have f <= 8).  A whole wave for each wastes 7/8 of the machine's wave slots, and
 // these kernels are bound by how many waves are in flight: eight fronts share a wave, eight lanes each.
 constexpr int kTinyFront = 8;
-__global__ __launch_bounds__(256) void k_fwd_tiny(SolveArgs A, int begin, int count)
+__device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int count, int bx)
 {
     const int sub = threadIdx.x & 7;                                 // row inside the front
-    const int item = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int item = bx * 32 + (threadIdx.x >> 3);
     const bool live = item < count;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
@@ -155,10 +163,14 @@ __global__ __launch_bounds__(256) void k_fwd_tiny(SolveArgs A, int begin, int co
         else if (sub < f) A.uvec[rp + sub - nc] = y;
     }
 }
-__global__ __launch_bounds__(256) void k_bwd_tiny(SolveArgs A, int begin, int count)
+__global__ __launch_bounds__(256) void k_fwd_tiny(SolveArgs A, int begin, int count)
+{
+    fwd_tiny_body(A, begin, count, blockIdx.x);
+}
+__device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int count, int bx)
 {
     const int sub = threadIdx.x & 7;
-    const int item = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int item = bx * 32 + (threadIdx.x >> 3);
     const bool live = item < count;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
@@ -184,6 +196,24 @@ __global__ __launch_bounds__(256) void k_bwd_tiny(SolveArgs A, int begin, int co
         A.xp[c0 + sub] = y;
         A.out[T.perm[c0 + sub]] = y;
     }
+}
+__global__ __launch_bounds__(256) void k_bwd_tiny(SolveArgs A, int begin, int count)
+{
+    bwd_tiny_body(A, begin, count, blockIdx.x);
+}
+// A level's one-wave and tiny fronts are independent of each other: one launch for both (the first nwb workgroups
+// take the one-wave fronts [begin, begin + nwave), the others the tiny fronts behind them) saves a launch per sweep
+__global__ __launch_bounds__(256) void k_fwd_small(SolveArgs A, int begin, int nwave, int ntiny)
+{
+    const int nwb = (nwave + 3) >> 2;
+    if ((int)blockIdx.x < nwb) fwd_wave_body(A, begin, nwave, blockIdx.x, 0);
+    else fwd_tiny_body(A, begin + nwave, ntiny, blockIdx.x - nwb);
+}
+__global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int nwave, int ntiny)
+{
+    const int nwb = (nwave + 3) >> 2;
+    if ((int)blockIdx.x < nwb) bwd_wave_body(A, begin, nwave, blockIdx.x, 0);
+    else bwd_tiny_body(A, begin + nwave, ntiny, blockIdx.x - nwb);
 }
 
 // ------------------------------------------------------------------ larger fronts, one block each
@@ -755,6 +785,24 @@ void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
         if (bs == 128) hipLaunchKernelGGL(k_fwd_block<128>, dim3(count, nrhs), dim3(128), lds, st, a, begin);
         else hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
     }
+}
+void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st)
+{
+    if (nwave <= 0 || ntiny <= 0) {
+        launch_fwd(a, begin, nwave, 64, 0, st, 1);
+        launch_fwd(a, begin + nwave, ntiny, 8, 0, st, 1);
+        return;
+    }
+    hipLaunchKernelGGL(k_fwd_small, dim3((nwave + 3) / 4 + (ntiny + 31) / 32), dim3(256), 0, st, a, begin, nwave, ntiny);
+}
+void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st)
+{
+    if (nwave <= 0 || ntiny <= 0) {
+        launch_bwd(a, begin + nwave, ntiny, 8, 0, st, 1);
+        launch_bwd(a, begin, nwave, 64, 0, st, 1);
+        return;
+    }
+    hipLaunchKernelGGL(k_bwd_small, dim3((nwave + 3) / 4 + (ntiny + 31) / 32), dim3(256), 0, st, a, begin, nwave, ntiny);
 }
 void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
 {
