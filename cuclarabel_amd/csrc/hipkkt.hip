@@ -69,6 +69,7 @@ struct Launch {
     int ntiny;                  // one-wave launches: the last ntiny fronts have f <= 8 (eight to a wave in the solves)
     int tile_begin, ntiles;     // Schur tiles of this launch's fronts
     int tinv_begin, tinv_count, tinv_ncmax;   // this launch's supernodes that need T = L11^{-1}
+    int level;                  // tree level: a level has at most one block-class launch, followed by its one-wave launch
 };
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
@@ -363,10 +364,21 @@ private:
         int ncount = top_count;
         if (ntl > 0 && w_pending && late_launches > 0 && late_launches < ntl) { ntl = late_launches; ncount = late_count; }
         const size_t first_w = nl - std::min(nl, late_launches);    // fronts from here on get their W late (w_pending)
+        // a level's block-class launch and the one-wave launch behind it (sched order) go out as one launch
+        static const bool no_merge = std::getenv("HIPKKT_NO_LEVEL_MERGE") != nullptr;
+        auto pair_at = [&](size_t q) {      // launches q (block-class) and q + 1 (one-wave) belong to one level
+            return !no_merge && q + 1 + ntl < nl && !launches[q].small && launches[q + 1].small &&
+                   launches[q].level == launches[q + 1].level;
+        };
         for (size_t q = 0; q + ntl < nl; ++q) {
             const Launch& L = launches[q];
             if (q == first_w) wait_w(st);
-            if (L.small) {
+            if (pair_at(q)) {
+                const Launch& Ls = launches[q + 1];
+                if (q + 1 == first_w) wait_w(st);
+                launch_fwd_level(a, L.begin, L.count, Ls.count - Ls.ntiny, Ls.ntiny, L.solve_bs, L.lds_solve, st);
+                ++q;
+            } else if (L.small) {
                 launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st);
             } else {
                 launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
@@ -379,7 +391,11 @@ private:
         }
         for (size_t q = nl - ntl; q-- > 0;) {
             const Launch& L = launches[q];
-            if (L.small) {
+            if (q > 0 && pair_at(q - 1)) {
+                const Launch& Lb = launches[q - 1];
+                launch_bwd_level(a, Lb.begin, Lb.count, L.count - L.ntiny, L.ntiny, Lb.solve_bs, Lb.lds_solve, st);
+                --q;
+            } else if (L.small) {
                 launch_bwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st);
             } else {
                 launch_bwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
@@ -519,7 +535,9 @@ private:
             int f = front_size(s), nc = ncols(s), nb = f - nc;
             return f <= kSmallFrontMax && f * nc + nb * nb <= kSmallSliceMax;
         };
+        int level_no = -1;
         for (const Level& lv : S.levels) {
+            ++level_no;
             std::vector<int> small, big;
             for (int t = lv.begin; t < lv.end; ++t) {
                 int s = S.level_sn[t];
@@ -546,6 +564,7 @@ private:
                 L.begin = (int)sched.size();
                 L.count = (int)v.size();
                 L.small = cls == 1;
+                L.level = level_no;
                 L.ntiny = cls == 1 ? ntiny_level : 0;
                 int fmax = 0, slice = 0;
                 for (int s : v) {

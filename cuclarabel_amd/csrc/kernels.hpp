@@ -149,6 +149,9 @@ void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
 // one launch for a level's one-wave fronts [begin, begin + nwave) and the tiny fronts behind them (single right-hand side)
 void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st);
 void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st);
+// one launch for a whole level: nblock block-class fronts at [begin, ..), then nwave one-wave, then ntiny tiny fronts
+void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st);
+void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st);
 
 // several right-hand sides: work vectors row-major N x KP / sum(nb) x KP (KP = columns rounded up to 16)
 // iperm[caller's index] = permuted index

@@ -38,7 +38,7 @@ __device__ inline double wave_reduce_sum(double v)
 __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = bx * 4 + wv;
+    const int item = bx * (int)(blockDim.x >> 6) + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + item];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int co
 __device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int item = bx * 4 + wv;
+    const int item = bx * (int)(blockDim.x >> 6) + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + item];
@@ -136,7 +136,7 @@ constexpr int kTinyFront = 8;
 __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int count, int bx)
 {
     const int sub = threadIdx.x & 7;                                 // row inside the front
-    const int item = bx * 32 + (threadIdx.x >> 3);
+    const int item = bx * (int)(blockDim.x >> 3) + (threadIdx.x >> 3);
     const bool live = item < count;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_fwd_tiny(SolveArgs A, int begin, int co
 __device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int count, int bx)
 {
     const int sub = threadIdx.x & 7;
-    const int item = bx * 32 + (threadIdx.x >> 3);
+    const int item = bx * (int)(blockDim.x >> 3) + (threadIdx.x >> 3);
     const bool live = item < count;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
@@ -227,14 +227,14 @@ __global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int n
 // Work is cut into items of 8 columns x 64 rows, 8 independent loads per lane in flight; partial
 // sums are combined in a fixed order (bit-reproducible).
 template <int BS>
-__global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
+__device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, int bx, int by)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const FrontDesc fd = T.desc[begin + bx];
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
@@ -242,9 +242,9 @@ __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
     const int fpad = (f + 3) & ~3;
     double* y = smem;                        // fpad
     double* part = smem + fpad;              // nks * fpad
-    const double* __restrict__ bcol = A.b + blockIdx.y * A.ld_b;          // right-hand side column blockIdx.y
-    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
-    double* __restrict__ uvec = A.uvec + blockIdx.y * A.ld_uvec;
+    const double* __restrict__ bcol = A.b + by * A.ld_b;          // right-hand side column by
+    double* __restrict__ xp = A.xp + by * A.ld_xp;
+    double* __restrict__ uvec = A.uvec + by * A.ld_uvec;
 
     // gather: right-hand side entry plus the children's contributions to each row, in child order
     for (int i = tid; i < f; i += BS) {
@@ -312,14 +312,20 @@ __device__ inline void bwd_items(const double* __restrict__ Wt, int nc, int f, c
 }
 
 template <int BS>
-__global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
+__global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
+{
+    fwd_block_body<BS>(A, begin, blockIdx.x, blockIdx.y);
+}
+
+template <int BS>
+__device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, int bx, int by)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const FrontDesc fd = T.desc[begin + bx];
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
     const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
     double* z = smem;
     double* part = smem + fpad;
-    double* __restrict__ xp = A.xp + blockIdx.y * A.ld_xp;
-    double* __restrict__ out = A.out + blockIdx.y * A.ld_out;
+    double* __restrict__ xp = A.xp + by * A.ld_xp;
+    double* __restrict__ out = A.out + by * A.ld_out;
 
     // z = [D^{-1} y_s ; -x_below]
     for (int i = tid; i < f; i += BS)
@@ -343,6 +349,30 @@ __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
         xp[c0 + j] = v;
         out[T.perm[c0 + j]] = v;
     }
+}
+template <int BS>
+__global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
+{
+    bwd_block_body<BS>(A, begin, blockIdx.x, blockIdx.y);
+}
+// A level's block-class, one-wave and tiny fronts are independent of each other: one launch for all three (single
+// right-hand side) -- workgroups [0, nblock) take a block-class front each, the next ones BS/64 one-wave fronts
+// each, the last ones BS/8 tiny fronts each.  Saves a launch (~5 us of pure latency) per sweep and level.
+template <int BS>
+__global__ __launch_bounds__(BS) void k_fwd_level(SolveArgs A, int begin, int nblock, int nwave, int ntiny)
+{
+    const int bx = blockIdx.x, nwb = (nwave + BS / 64 - 1) / (BS / 64);
+    if (bx < nblock) fwd_block_body<BS>(A, begin, bx, 0);
+    else if (bx < nblock + nwb) fwd_wave_body(A, begin + nblock, nwave, bx - nblock, 0);
+    else fwd_tiny_body(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
+}
+template <int BS>
+__global__ __launch_bounds__(BS) void k_bwd_level(SolveArgs A, int begin, int nblock, int nwave, int ntiny)
+{
+    const int bx = blockIdx.x, nwb = (nwave + BS / 64 - 1) / (BS / 64);
+    if (bx < nblock) bwd_block_body<BS>(A, begin, bx, 0);
+    else if (bx < nblock + nwb) bwd_wave_body(A, begin + nblock, nwave, bx - nblock, 0);
+    else bwd_tiny_body(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
 }
 
 struct ItemRegs { double m[8]; };
@@ -756,6 +786,14 @@ static void init_solve_lds()
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_block<kSolveBS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_level<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_level<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_level<kSolveBS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_level<kSolveBS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_winv), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     // this kernel also has a static LDS word: leave room for it
@@ -784,6 +822,28 @@ void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hi
         // bs = 128: a wide level of small fronts -- more fronts in flight per CU matter more than waves per front
         if (bs == 128) hipLaunchKernelGGL(k_fwd_block<128>, dim3(count, nrhs), dim3(128), lds, st, a, begin);
         else hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
+    }
+}
+void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st)
+{
+    init_solve_lds();
+    if (bs == 128) {
+        const int grid = nblock + (nwave + 1) / 2 + (ntiny + 15) / 16;
+        hipLaunchKernelGGL(k_fwd_level<128>, dim3(grid), dim3(128), lds, st, a, begin, nblock, nwave, ntiny);
+    } else {
+        const int grid = nblock + (nwave + kSolveBS / 64 - 1) / (kSolveBS / 64) + (ntiny + kSolveBS / 8 - 1) / (kSolveBS / 8);
+        hipLaunchKernelGGL(k_fwd_level<kSolveBS>, dim3(grid), dim3(kSolveBS), lds, st, a, begin, nblock, nwave, ntiny);
+    }
+}
+void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st)
+{
+    init_solve_lds();
+    if (bs == 128) {
+        const int grid = nblock + (nwave + 1) / 2 + (ntiny + 15) / 16;
+        hipLaunchKernelGGL(k_bwd_level<128>, dim3(grid), dim3(128), lds, st, a, begin, nblock, nwave, ntiny);
+    } else {
+        const int grid = nblock + (nwave + kSolveBS / 64 - 1) / (kSolveBS / 64) + (ntiny + kSolveBS / 8 - 1) / (kSolveBS / 8);
+        hipLaunchKernelGGL(k_bwd_level<kSolveBS>, dim3(grid), dim3(kSolveBS), lds, st, a, begin, nblock, nwave, ntiny);
     }
 }
 void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st)
