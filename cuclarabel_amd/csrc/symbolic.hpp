@@ -28,8 +28,10 @@ struct SymbolicOptions {
     int relax_cols[3] = {8, 32, 128};
     double relax_zeros[4] = {1.0, 0.5, 0.15, 0.05};
     // a supernode's panel (f x nc doubles) is kept LDS-resident while it is factorised: wider
-    // supernodes are split into a chain so that f*nc <= panel_cap (0 = no splitting)
-    int64_t panel_cap = 17344;
+    // supernodes are split into a chain so that f*nc <= panel_cap (0 = no splitting).  The panel kernel's LDS holds
+    // 19 374 doubles of panel beside its block buffers (factor_kernels.hip: panel_lds_bytes); every split is one more
+    // level of the schedule, so the cap sits just under that (cfg2: 31 levels at 17 344, 29 at 19 200)
+    int64_t panel_cap = 19200;
     const int64_t* user_perm = nullptr;
 };
 
