@@ -179,10 +179,15 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
         std::vector<std::vector<int>> kids(nfs);
         for (int s = 0; s < nfs; ++s) if (fs_parent[s] >= 0) kids[fs_parent[s]].push_back(s);
         auto trap = [](double nc, double nb) { return nc * (nc + 1) / 2 + nc * nb; };
+        // Every level of the tree is a round of dependent launches in the numeric phase, so the HEIGHT of the
+        // amalgamated tree matters more than its zeros: the child with the tallest subtree is tried first and with
+        // relax_tall times the usual zero allowance (absorbing it takes one level off the path through this node);
+        // the other children follow, widest first, with the plain allowance -- after the tall child has widened the
+        // parent they are less likely to pile up zeros than if they had gone first.
+        std::vector<int> hgt(nfs, 1);         // height of the amalgamated subtree under each node
         for (int p = 0; p < nfs; ++p) {       // postorder: children have smaller ids
-            // try the children, largest-first so wide children merge before narrow ones pile up zeros
             auto& ks = kids[p];
-            std::sort(ks.begin(), ks.end(), [&](int a, int b) { return fs_nc[a] > fs_nc[b]; });
+            std::sort(ks.begin(), ks.end(), [&](int a, int b) { return hgt[a] != hgt[b] ? hgt[a] > hgt[b] : fs_nc[a] > fs_nc[b]; });
             std::vector<int> newkids;
             for (int c : ks) {
                 double nc = (double)fs_nc[c] + fs_nc[p], nb = fs_nb[p];
@@ -190,11 +195,12 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
                 double truennz = (trap(fs_nc[c], fs_nb[c]) - fs_zeros[c]) + (trap(fs_nc[p], fs_nb[p]) - fs_zeros[p]);
                 double zeros = total - truennz;
                 double frac = zeros / total;
+                const double mult = (c == ks[0]) ? opt.relax_tall : 1.0;
                 bool ok;
-                if (nc <= opt.relax_cols[0]) ok = frac <= opt.relax_zeros[0];
-                else if (nc <= opt.relax_cols[1]) ok = frac <= opt.relax_zeros[1];
-                else if (nc <= opt.relax_cols[2]) ok = frac <= opt.relax_zeros[2];
-                else ok = frac <= opt.relax_zeros[3];
+                if (nc <= opt.relax_cols[0]) ok = frac <= opt.relax_zeros[0] * mult;
+                else if (nc <= opt.relax_cols[1]) ok = frac <= opt.relax_zeros[1] * mult;
+                else if (nc <= opt.relax_cols[2]) ok = frac <= opt.relax_zeros[2] * mult;
+                else ok = frac <= opt.relax_zeros[3] * mult;
                 if (ok) {
                     merged[c] = p;
                     fs_nc[p] = (int)nc;
@@ -205,7 +211,7 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
                 }
             }
             ks.swap(newkids);
-            for (int c : ks) fs_parent[c] = p;
+            for (int c : ks) { fs_parent[c] = p; hgt[p] = std::max(hgt[p], hgt[c] + 1); }
         }
     }
     auto rep = [&](int s) { while (merged[s] != s) s = merged[s]; return s; };

@@ -27,6 +27,7 @@ struct SymbolicOptions {
     // has <= relax_cols[k] columns and the fraction of explicit zeros stays <= relax_zeros[k]
     int relax_cols[3] = {8, 32, 128};
     double relax_zeros[4] = {1.0, 0.5, 0.15, 0.05};
+    double relax_tall = 2.0;     // the allowance is this much larger for the child with the tallest subtree
     // a supernode's panel (f x nc doubles) is kept LDS-resident while it is factorised: wider
     // supernodes are split into a chain so that f*nc <= panel_cap (0 = no splitting).  The panel kernel's LDS holds
     // 19 374 doubles of panel beside its block buffers (factor_kernels.hip: panel_lds_bytes); every split is one more
