@@ -244,6 +244,10 @@ __device__ inline double fast_recip(double d)
     return r;          // d = 0 or not finite: NaN (the caller only asks whether the result is finite)
 }
 constexpr int NB = 16;
+// The panel lives in LDS as a TRAPEZOID: column j holds rows j .. f-1, columns back to back.  Entry (i, j), i >= j,
+// sits at i + pcol(j, f); nothing above the diagonal is ever stored or read.  That is f*nc - nc(nc-1)/2 doubles
+// instead of f*nc: a 231 x 87 panel fits where the rectangle would have to be split (one more tree level).
+__device__ __forceinline__ int pcol(int j, int f) { return (j * (2 * f - 1 - j)) >> 1; }
 constexpr int kBdCols = 128;       // trailing columns per block whose d*L copy is kept (nc - 16 <= 128 enforced by host)
 
 // apply the extend-add items [i0, i1) (whole columns, owned by this wave) into the LDS panel P (ld f):
@@ -279,7 +283,7 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
                 const int tcol = __builtin_amdgcn_readlane(mine.tcol, j);
                 const bool ok = lane < cnt;
                 v[q] = ok ? upd[uoff + lane] : 0.0;
-                tg[q] = ok ? T.rel[relstart + lane] + tcol * f : -1;
+                tg[q] = ok ? T.rel[relstart + lane] + pcol(tcol, f) : -1;
             }
 #pragma unroll
             for (int q = 0; q < IF; ++q) {
@@ -316,7 +320,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     const long long clk0 = A.stamps ? clock64() : 0;
     // ---- 1. zero the panel (and fetch the pivot signs: the serial diagonal step must not wait for global memory)
     for (int k = tid; k < nc; k += BS) sgn[k] = (double)T.psign[c0 + k];
-    for (int i = tid; i < f * nc; i += BS) P[i] = 0.0;
+    const int psize = f * nc - ((nc * (nc - 1)) >> 1);
+    for (int i = tid; i < psize; i += BS) P[i] = 0.0;
     __syncthreads();
     HIPKKT_STAMP(A, 1);
     // ---- 2. scatter K, four entries per thread in flight
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     __syncthreads();
     if (A.eps) {
         const double eps = *A.eps;
-        for (int k = tid; k < nc; k += BS) P[k + k * f] += eps * sgn[k];
+        for (int k = tid; k < nc; k += BS) P[k + pcol(k, f)] += eps * sgn[k];
     }
     __syncthreads();
     HIPKKT_STAMP(A, 2);
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = 4 * g + q;
-            a4[q] = (i < w && j <= i) ? P[(kb + i) + (kb + j) * f] : 0.0;
+            a4[q] = (i < w && j <= i) ? P[(kb + i) + pcol(kb + j, f)] : 0.0;
             lout[q] = 0.0;
             vout[q] = 0.0;
         }
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = 4 * g + q;
-            if (i < w && j <= i) P[(kb + i) + (kb + j) * f] = lout[q];          // scaled L below, d on the diagonal
+            if (i < w && j <= i) P[(kb + i) + pcol(kb + j, f)] = lout[q];       // scaled L below, d on the diagonal
             if (i < w && j < i) Lb[i * NB + j] = vout[q];                       // d_j L(i,j): what the rows below need
         }
         if (lane < w) A.Dinv[c0 + kb + lane] = dimine;
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         auto trsm_row = [&](const int i) {
             double l[NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) l[j] = (j < w) ? P[i + (kb + j) * f] : 0.0;
+            for (int j = 0; j < NB; ++j) l[j] = (j < w) ? P[i + pcol(kb + j, f)] : 0.0;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (j < w) {
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) if (j < w) P[i + (kb + j) * f] = l[j];
+            for (int j = 0; j < NB; ++j) if (j < w) P[i + pcol(kb + j, f)] = l[j];
         };
         const int ml = lane & 15, mk = lane >> 4;
         // C(16 x 16 tile at rows g0 + 16 tr, columns g0 + 16 tc) -= L(rows, block) * (d L(cols, block))'
@@ -474,16 +479,18 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int k = 4 * kk + mk;
-                av[kk] = (i0 + ml < f && k < w) ? P[(i0 + ml) + (kb + k) * f] : 0.0;
-                bv[kk] = (j0 + ml < nc && k < w) ? P[(j0 + ml) + (kb + k) * f] * sh_d[k] : 0.0;
+                const int cbk = pcol(kb + k, f);
+                av[kk] = (i0 + ml < f && k < w) ? P[(i0 + ml) + cbk] : 0.0;
+                bv[kk] = (j0 + ml < nc && k < w) ? P[(j0 + ml) + cbk] * sh_d[k] : 0.0;
             }
             d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+            const int ccol = pcol(min(j0 + ml, nc - 1), f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + mk + 4 * r, col = j0 + ml;
-                if (row < f && col < nc && row >= col) P[row + col * f] -= acc[r];
+                if (row < f && col < nc && row >= col) P[row + ccol] -= acc[r];
             }
         };
         const int nfirst = min(NB, Tr);                       // rows of the next diagonal block (or the last rows)
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     // ---- 5. write L and D (lower part of the panel)
     for (int idx = tid; idx < f * nc; idx += BS) {
         const int j = idx / f, r = idx - j * f;
-        if (r >= j) F[idx] = P[idx];
+        if (r >= j) F[idx] = P[r + pcol(j, f)];
     }
     __syncthreads();
     HIPKKT_STAMP(A, 5);

@@ -574,8 +574,8 @@ private:
                     if (!(cls == 1 && f <= 8)) slice = std::max(slice, f * nc + nb * nb);     // (tiny fronts: own kernel)
                 }
                 L.slice = (slice + 1) & ~1;
-                int pmax = 0;
-                for (int s : v) pmax = std::max(pmax, front_size(s) * ncols(s));
+                int pmax = 0;                       // LDS doubles of the largest panel: a trapezoid (panel kernel)
+                for (int s : v) pmax = std::max(pmax, front_size(s) * ncols(s) - ncols(s) * (ncols(s) - 1) / 2);
                 L.nbk = kMaxNbk;
                 L.bs_panel = fmax > 128 ? 1024 : (fmax > 96 ? 512 : 256);
                 L.lds_panel = panel_lds_bytes(fmax, pmax);
@@ -640,7 +640,23 @@ private:
         d_child_idx.upload(S.child_idx);
         d_kptr.upload(S.kptr);
         d_ksrc.upload(S.ksrc);
-        d_kdst.upload(S.kdst);
+        {
+            // the panel kernel keeps a block-class front as a trapezoid in LDS (factor_kernels.hip: pcol): its K
+            // entries get their packed position; one-wave fronts keep lrow + lcol*f
+            std::vector<int> kd(S.kdst);
+            for (const Launch& L : launches) {
+                if (L.small) continue;
+                for (int q = L.begin; q < L.begin + L.count; ++q) {
+                    const int s = sched[q];
+                    const int f = front_size(s);
+                    for (int64_t e = S.kptr[s]; e < S.kptr[s + 1]; ++e) {
+                        const int lcol = kd[e] / f, lrow = kd[e] - lcol * f;
+                        kd[e] = lrow + (int)(((int64_t)lcol * (2 * f - 1 - lcol)) >> 1);
+                    }
+                }
+            }
+            d_kdst.upload(kd);
+        }
         d_sched.upload(sched);
         d_tiles.upload(tiles);
         {

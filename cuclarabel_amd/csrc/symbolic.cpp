@@ -322,6 +322,9 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
             while (a < c1) {
                 int64_t fa = (c1 - a) + nb;
                 int64_t wd = std::max<int64_t>(1, std::min<int64_t>(c1 - a, opt.panel_cap / fa));
+                // the panel is held as a trapezoid (column j from its diagonal down): fa*w - w(w-1)/2 doubles
+                while (wd < c1 - a && fa * (wd + 1) - (wd + 1) * wd / 2 <= opt.panel_cap) ++wd;
+                wd = std::min<int64_t>(wd, opt.panel_max_cols);
                 // avoid a sliver at the end: balance the remaining columns over the remaining chunks
                 int64_t rem = c1 - a;
                 if (wd < rem) { int64_t parts = (rem + wd - 1) / wd; wd = (rem + parts - 1) / parts; }

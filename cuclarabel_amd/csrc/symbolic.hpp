@@ -29,10 +29,12 @@ struct SymbolicOptions {
     double relax_zeros[4] = {1.0, 0.5, 0.15, 0.05};
     double relax_tall = 2.0;     // the allowance is this much larger for the child with the tallest subtree
     // a supernode's panel (f x nc doubles) is kept LDS-resident while it is factorised: wider
-    // supernodes are split into a chain so that f*nc <= panel_cap (0 = no splitting).  The panel kernel's LDS holds
+    // supernodes are split into a chain so that the panel's trapezoid f*nc - nc(nc-1)/2 <= panel_cap (0 = no
+    // splitting).  The panel kernel's LDS holds
     // 19 374 doubles of panel beside its block buffers (factor_kernels.hip: panel_lds_bytes); every split is one more
     // level of the schedule, so the cap sits just under that (cfg2: 31 levels at 17 344, 29 at 19 200)
     int64_t panel_cap = 19200;
+    int panel_max_cols = 128;    // and no panel is wider than this (per-column LDS arrays of the panel and W kernels)
     const int64_t* user_perm = nullptr;
 };
 
