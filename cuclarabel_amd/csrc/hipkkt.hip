@@ -103,6 +103,7 @@ public:
         if (st.nd_leaf_size > 0) opt.nd_leaf_size = st.nd_leaf_size;
         opt.user_perm = st.user_perm;
         if (const char* pc = std::getenv("HIPKKT_PANEL_CAP")) opt.panel_cap = std::atoll(pc);
+        if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
         // user_perm arrives in the caller's index base; analyse() applies `base` to it
         analyse(N, colptr, rowval, base, opt, S);
         dyn_eps = st.dynamic_regularization_eps;
@@ -1148,6 +1149,7 @@ int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* row
         opt.ordering = ordering;
         if (nd_leaf_size > 0) opt.nd_leaf_size = nd_leaf_size;
         if (const char* pc = std::getenv("HIPKKT_PANEL_CAP")) opt.panel_cap = std::atoll(pc);
+        if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
         Symbolic S;
         analyse((int)N, colptr, rowval, base, opt, S);
         if (perm_out) for (int64_t i = 0; i < N; ++i) perm_out[i] = S.perm[i];

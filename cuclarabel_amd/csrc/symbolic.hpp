@@ -34,7 +34,8 @@ struct SymbolicOptions {
     // 19 374 doubles of panel beside its block buffers (factor_kernels.hip: panel_lds_bytes); every split is one more
     // level of the schedule, so the cap sits just under that (cfg2: 31 levels at 17 344, 29 at 19 200)
     int64_t panel_cap = 19200;
-    int panel_max_cols = 128;    // and no panel is wider than this (per-column LDS arrays of the panel and W kernels)
+    int panel_max_cols = 96;     // and no panel is wider than this: k_winv stages L11 (nc x nc) in LDS, and with 96
+                                 // columns two of its workgroups share a CU (cfg2: same 18 levels as with 128, 2 % faster)
     const int64_t* user_perm = nullptr;
 };
 
