@@ -420,11 +420,11 @@ __device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long lon
 // Everything that does not depend on other fronts is fetched BEFORE the flag wait and parked in
 // registers: the wave's matrix items (up to PF per sweep), the row's gather-list indices, b, D^{-1},
 // the ancestors' row indices.  After the flag only the handed-over values themselves are loaded.
-constexpr int kTopPF = 4;        // forward items per wave kept in registers (8 doubles each)
-constexpr int kTopPB = 5;        // backward items per wave
+constexpr int kTopPF = 7;        // forward items per wave kept in registers (8 doubles each)
+constexpr int kTopPB = 7;        // backward items per wave
 
 template <int BS>
-__global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop, int nflag)
+__global__ __launch_bounds__(BS, 2) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop, int nflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int sh_ok;
@@ -467,7 +467,10 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int
 #pragma unroll
             for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
         }
-        int gsrc[4] = {-1, -1, -1, -1};
+        constexpr int GP = 12;             // gather sources per row whose indices are fetched before the wait: the
+        int gsrc[GP];                      // separator rows near the top collect a dozen small children each
+#pragma unroll
+        for (int q = 0; q < GP; ++q) gsrc[q] = -1;
         int64_t g0 = 0, g1 = 0;
         double bmine = 0.0;
         if (tid < f) {
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int
             g0 = T.gl_ptr[lc];
             g1 = T.gl_ptr[lc + 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
+            for (int q = 0; q < GP; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
             if (tid < nc) bmine = A.b[T.perm[c0 + tid]];
         }
         if (tid == 0) sh_ok = 1;
@@ -493,13 +496,13 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve(SolveArgs A, int begin, int
         if (!sh_ok) return;
         // ---- gather (only the handed-over values are loaded now)
         if (tid < f) {
-            double u[4];
+            double u[GP];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
+            for (int q = 0; q < GP; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
             double v = bmine;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v += u[q];
-            for (int64_t g = g0 + 4; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+            for (int q = 0; q < GP; ++q) v += u[q];
+            for (int64_t g = g0 + GP; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
             y[tid] = v;
         }
         for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
