@@ -259,8 +259,10 @@ __device__ inline int64_t uniform_i64(int64_t v)
     const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
+// SLICED: the workgroup holds the top nc rows and the front rows [r_lo, r_lo + rs) only (local row nc + r - r_lo)
+template <bool SLICED>
 __device__ inline void apply_items_panel(const TreeDev& T, const double* __restrict__ upd, double* P, int f,
-                                         int64_t i0_, int64_t i1_, int lane)
+                                         int64_t i0_, int64_t i1_, int lane, int nc, int r_lo, int rs)
 {
     // the range is the same for every lane
     const int64_t i0 = uniform_i64(i0_), i1 = uniform_i64(i1_);
@@ -270,6 +272,8 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
         // with v_readlane as the pieces are issued -- no scalar-load latency per batch
         const ExtItem mine = T.items[min(ii + lane, i1 - 1)];
         const int lo = (int)(mine.uoff & 0xffffffff), hi = (int)(mine.uoff >> 32);
+        // (sliced: a piece wholly below the top block and outside this slice's rows brings nothing)
+        const int mycnt = (SLICED && mine.rfirst >= nc && (mine.rlast < r_lo || mine.rfirst >= r_lo + rs)) ? 0 : mine.cnt;
         const int nhere = (int)min((int64_t)64, i1 - ii);
         for (int q0 = 0; q0 < nhere; q0 += IF) {
             double v[IF];
@@ -279,11 +283,17 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
                 const int j = min(q0 + q, 63);
                 const int64_t uoff = ((int64_t)__builtin_amdgcn_readlane(hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, j);
                 const int relstart = __builtin_amdgcn_readlane(mine.relstart, j);
-                const int cnt = (q0 + q < nhere) ? __builtin_amdgcn_readlane(mine.cnt, j) : 0;
+                const int cnt = (q0 + q < nhere) ? __builtin_amdgcn_readlane(mycnt, j) : 0;
                 const int tcol = __builtin_amdgcn_readlane(mine.tcol, j);
                 const bool ok = lane < cnt;
                 v[q] = ok ? upd[uoff + lane] : 0.0;
-                tg[q] = ok ? T.rel[relstart + lane] + pcol(tcol, f) : -1;
+                if (!SLICED) {
+                    tg[q] = ok ? T.rel[relstart + lane] + pcol(tcol, f) : -1;
+                } else {
+                    int r = ok ? T.rel[relstart + lane] : -1;
+                    if (r >= nc) r = (r >= r_lo && r < r_lo + rs) ? nc + (r - r_lo) : -1;
+                    tg[q] = r >= 0 ? r + pcol(tcol, f) : -1;
+                }
             }
 #pragma unroll
             for (int q = 0; q < IF; ++q) {
@@ -293,7 +303,12 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
     }
 }
 
-template <int BS>
+// SLICED: a panel too tall for one CU's LDS is cut into ROW slices, one workgroup each (TreeDev::sdesc).  Every slice
+// holds the top nc x nc block plus its share of the rows below and factors the top block itself, so the slices
+// never talk to each other: the diagonal blocks are computed redundantly (they sit on every slice's critical path
+// anyway), the substitution and the trailing update only ever combine a row with the top block.  Inside the kernel
+// a slice is simply a front with f = nc + (rows of the slice); only assembly and the final store map rows.
+template <int BS, bool SLICED>
 __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -301,9 +316,15 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const FrontDesc fd = SLICED ? T.sdesc[begin + blockIdx.x] : T.desc[begin + blockIdx.x];
     const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int f = nc + nb;
+    const int ff = nc + nb;                                        // rows of the whole front
+    const int nsl = SLICED ? (fd.pad & 0xffff) : 1, sl = SLICED ? (fd.pad >> 16) : 0;
+    const int rsmax = (nb + nsl - 1) / nsl;
+    const int r_lo = nc + sl * rsmax;                              // front row of this slice's first row below the top
+    const int rs = SLICED ? max(0, min(rsmax, ff - r_lo)) : nb;
+    const int f = nc + rs;                                         // rows held here
+    const bool first = !SLICED || sl == 0;                         // writes what all slices compute alike
     double* __restrict__ F = A.fronts + fd.front_off;
 
     // block data is double-buffered by block parity: wave 0 factors diagonal block k+1 while the other waves
@@ -339,6 +360,17 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = src[q] >= 0 ? A.Kval[src[q]] : 0.0;
+            if (SLICED) {
+                // (sliced fronts keep kdst = lrow + lcol * ff)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (dst[q] < 0) continue;
+                    const int lc = dst[q] / ff;
+                    int r = dst[q] - lc * ff;
+                    if (r >= nc) r = (r >= r_lo && r < r_lo + rs) ? nc + (r - r_lo) : -1;
+                    dst[q] = r >= 0 ? r + pcol(lc, f) : -1;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (dst[q] >= 0) P[dst[q]] = v[q];
         }
@@ -356,7 +388,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         constexpr int SPW = 16 / NW > 0 ? 16 / NW : 1;      // slices per wave
         if (wv * SPW < 16) {
             const int64_t i0 = wc[wv * SPW], i1 = wc[min(16, (wv + 1) * SPW)];
-            if (i1 > i0) apply_items_panel(T, A.upd, P, f, i0, i1, lane);
+            if (i1 > i0) apply_items_panel<SLICED>(T, A.upd, P, f, i0, i1, lane, nc, r_lo, rs);
         }
     }
     HIPKKT_STAMP(A, 3);
@@ -427,8 +459,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             if (i < w && j <= i) P[(kb + i) + pcol(kb + j, f)] = lout[q];       // scaled L below, d on the diagonal
             if (i < w && j < i) Lb[i * NB + j] = vout[q];                       // d_j L(i,j): what the rows below need
         }
-        if (lane < w) A.Dinv[c0 + kb + lane] = dimine;
-        if (lane == 0) {
+        if (first && lane < w) A.Dinv[c0 + kb + lane] = dimine;
+        if (first && lane == 0) {
             if (nreg) atomicAdd(&A.flags[0], nreg);
             if (bad) A.flags[1] = 1;
         }
@@ -527,7 +559,13 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     // ---- 5. write L and D (lower part of the panel)
     for (int idx = tid; idx < f * nc; idx += BS) {
         const int j = idx / f, r = idx - j * f;
-        if (r >= j) F[idx] = P[r + pcol(j, f)];
+        if (!SLICED) {
+            if (r >= j) F[idx] = P[r + pcol(j, f)];
+        } else if (r >= nc) {
+            F[(r_lo + r - nc) + (int64_t)j * ff] = P[r + pcol(j, f)];
+        } else if (first && r >= j) {
+            F[r + (int64_t)j * ff] = P[r + pcol(j, f)];
+        }
     }
     __syncthreads();
     HIPKKT_STAMP(A, 5);
@@ -692,9 +730,10 @@ static void init_factor_lds()
     static bool done = false;
     if (done) return;
     done = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -714,9 +753,15 @@ void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds,
 {
     if (count <= 0) return;
     init_factor_lds();
-    if (bs == 1024) hipLaunchKernelGGL(k_panel<1024>, dim3(count), dim3(1024), lds, st, a, begin);
-    else if (bs == 512) hipLaunchKernelGGL(k_panel<512>, dim3(count), dim3(512), lds, st, a, begin);
-    else hipLaunchKernelGGL(k_panel<256>, dim3(count), dim3(256), lds, st, a, begin);
+    if (bs == 1024) hipLaunchKernelGGL((k_panel<1024, false>), dim3(count), dim3(1024), lds, st, a, begin);
+    else if (bs == 512) hipLaunchKernelGGL((k_panel<512, false>), dim3(count), dim3(512), lds, st, a, begin);
+    else hipLaunchKernelGGL((k_panel<256, false>), dim3(count), dim3(256), lds, st, a, begin);
+}
+void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, hipStream_t st)
+{
+    if (count <= 0) return;
+    init_factor_lds();
+    hipLaunchKernelGGL((k_panel<1024, true>), dim3(count), dim3(1024), lds, st, a, begin);
 }
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st)
 {

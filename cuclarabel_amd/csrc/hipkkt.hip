@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -69,6 +70,9 @@ struct Launch {
     int ntiny;                  // one-wave launches: the last ntiny fronts have f <= 8 (eight to a wave in the solves)
     int tile_begin, ntiles;     // Schur tiles of this launch's fronts
     int tinv_begin, tinv_count, tinv_ncmax;   // this launch's supernodes that need T = L11^{-1}
+    int nsliced;                // the last nsliced fronts of a block-class launch are factorised in row slices ...
+    int slice_begin, slice_count;   // ... their slice records in d_sdesc
+    size_t lds_sliced;
     int level;                  // tree level: a level has at most one block-class launch, followed by its one-wave launch
 };
 
@@ -106,10 +110,20 @@ public:
         if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
         // user_perm arrives in the caller's index base; analyse() applies `base` to it
         analyse(N, colptr, rowval, base, opt, S);
+        panel_cap = opt.panel_cap;
+        panel_max_slices = std::max(1, opt.panel_max_slices);
         dyn_eps = st.dynamic_regularization_eps;
         dyn_delta = st.dynamic_regularization_delta;
         build_schedule();
         upload(dsigns);
+        if (std::getenv("HIPKKT_VERBOSE")) {
+            int nblock = 0, nsl_fronts = 0;
+            for (const Launch& L : launches) if (!L.small) { nblock += L.count; nsl_fronts += L.nsliced; }
+            std::fprintf(stderr, "[hipkkt] N %d, %d supernodes in %zu levels (%zu launches), %d block-class fronts, %d of them in "
+                         "%zu row slices; persistent solve set: last %zu launches, %d fronts on %d workgroups\n",
+                         S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
+                         top_count, top_grid);
+        }
     }
 
     // Both sequences are static (no pivoting, fixed structure), so they can be captured once into
@@ -298,7 +312,8 @@ private:
                 launch_front_tiny(a, L.begin + L.count - L.ntiny, L.ntiny, st);
             } else {
                 a.nbk = L.nbk;
-                launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, st);
+                launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
+                launch_panel_sliced(a, L.slice_begin, L.slice_count, L.lds_sliced, st);
                 if (L.tinv_count > 0 && side) {
                     HIP_CHECK(hipEventRecord(ev_fork, st));
                     HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
@@ -497,6 +512,10 @@ private:
     DBuf<int64_t> d_sitems;      // SubItem = 2 x int64
     DBuf<int64_t> d_tile_cut;
     DBuf<int64_t> d_desc;        // FrontDesc = 8 x int64
+    DBuf<int64_t> d_sdesc;       // FrontDesc per row slice of the sliced panels
+    std::vector<std::array<int, 3>> slice_list;   // (supernode, slice, slices) in launch order
+    int64_t panel_cap = 0;
+    int panel_max_slices = 1;
     DBuf<int> d_spos, d_sn_parent, top_flags;
     size_t top_launches = 0, late_launches = 0, top_lds = 0;
     int top_count = 0, late_count = 0, top_grid = 0, top_epoch = 0;
@@ -515,7 +534,7 @@ private:
         t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
         t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p; t.udst = d_udst.p;
         t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
-        t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p; t.desc = (const FrontDesc*)d_desc.p;
+        t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p; t.desc = (const FrontDesc*)d_desc.p; t.sdesc = (const FrontDesc*)d_sdesc.p;
         t.spos = d_spos.p; t.sn_parent = d_sn_parent.p;
         return t;
     }
@@ -531,6 +550,7 @@ private:
         launches.clear();
         tiles.clear();
         tinv_list.clear();
+        slice_list.clear();
         tile_base.assign(S.nsuper, -1);
         auto ncols = [&](int s) { return S.sn_start[s + 1] - S.sn_start[s]; };
         auto is_small = [&](int s) {
@@ -552,10 +572,19 @@ private:
                 big.insert(big.end(), small.begin(), small.end());
                 small.clear();
             }
+            auto slices_of = [&](int s) {        // row slices the panel kernel needs for this front (1: fits one CU)
+                if (panel_cap <= 0) return 1;
+                const int nc = ncols(s), nb = front_size(s) - nc;
+                const int r = panel_slices_needed(nc, nb, panel_cap, std::min(panel_max_slices, std::max(1, nb)));
+                if (r == 0) throw std::runtime_error("panel does not fit LDS even in row slices (panel_cap too large?)");
+                return r;
+            };
             auto work = [&](int s) { return (double)front_size(s) * front_size(s) * ncols(s); };
             auto by_work = [&](int a, int b) { double wa = work(a), wb = work(b); return wa != wb ? wa > wb : a < b; };
             std::sort(small.begin(), small.end(), by_work);
             std::sort(big.begin(), big.end(), by_work);
+            // fronts factorised in row slices go to the end of the block-class launch (own panel kernel launch)
+            std::stable_partition(big.begin(), big.end(), [&](int s) { return slices_of(s) == 1; });
             // the tiny fronts (f <= 8) go to the end of the one-wave launch: the solves give them their own kernel
             std::stable_partition(small.begin(), small.end(), [&](int s) { return front_size(s) > 8; });
             const int ntiny_level = (int)std::count_if(small.begin(), small.end(), [&](int s) { return front_size(s) <= 8; });
@@ -576,12 +605,28 @@ private:
                 }
                 L.slice = (slice + 1) & ~1;
                 int pmax = 0;                       // LDS doubles of the largest panel: a trapezoid (panel kernel)
-                for (int s : v) pmax = std::max(pmax, front_size(s) * ncols(s) - ncols(s) * (ncols(s) - 1) / 2);
+                int64_t smax = 0;
+                L.nsliced = 0;
+                L.slice_begin = (int)slice_list.size();
+                for (int s : v) {
+                    const int r = cls == 0 ? slices_of(s) : 1;
+                    const int nc = ncols(s), nb = front_size(s) - nc;
+                    if (r == 1) {
+                        pmax = std::max(pmax, front_size(s) * nc - nc * (nc - 1) / 2);
+                    } else {
+                        ++L.nsliced;
+                        smax = std::max(smax, panel_slice_doubles(nc, nb, r));
+                        for (int q = 0; q < r; ++q) slice_list.push_back({s, q, r});
+                    }
+                }
+                L.slice_count = (int)slice_list.size() - L.slice_begin;
+                L.lds_sliced = L.nsliced ? panel_lds_bytes(0, (int)smax) : 0;
                 L.nbk = kMaxNbk;
                 L.bs_panel = fmax > 128 ? 1024 : (fmax > 96 ? 512 : 256);
                 L.lds_panel = panel_lds_bytes(fmax, pmax);
                 if (!L.small && L.lds_panel > kLdsCap)
                     throw std::runtime_error("panel does not fit LDS (panel_cap too large?)");
+                if (L.lds_sliced > kLdsCap) throw std::runtime_error("panel slice does not fit LDS (panel_cap too large?)");
                 int ncmax = 0;
                 for (int s : v) ncmax = std::max(ncmax, ncols(s));
                 L.lds_solve = L.small ? 0 : solve_lds_bytes(fmax, ncmax);
@@ -647,7 +692,7 @@ private:
             std::vector<int> kd(S.kdst);
             for (const Launch& L : launches) {
                 if (L.small) continue;
-                for (int q = L.begin; q < L.begin + L.count; ++q) {
+                for (int q = L.begin; q < L.begin + L.count - L.nsliced; ++q) {      // (sliced fronts keep lrow + lcol*f)
                     const int s = sched[q];
                     const int f = front_size(s);
                     for (int64_t e = S.kptr[s]; e < S.kptr[s + 1]; ++e) {
@@ -683,6 +728,15 @@ private:
             std::vector<int64_t> rawd(desc.size() * 8);
             std::memcpy(rawd.data(), desc.data(), desc.size() * sizeof(FrontDesc));
             d_desc.upload(rawd);
+            std::vector<int> pos_of(S.nsuper, -1);
+            for (size_t q = 0; q < sched.size(); ++q) pos_of[sched[q]] = (int)q;
+            std::vector<int64_t> raws(std::max<size_t>(slice_list.size(), 1) * 8, 0);
+            for (size_t q = 0; q < slice_list.size(); ++q) {
+                FrontDesc d = desc[(size_t)pos_of[slice_list[q][0]]];
+                d.pad = (slice_list[q][1] << 16) | slice_list[q][2];
+                std::memcpy(raws.data() + q * 8, &d, sizeof(FrontDesc));
+            }
+            d_sdesc.upload(raws);
             std::vector<int> spos(S.nsuper, -1);
             for (size_t q = 0; q < sched.size(); ++q) spos[sched[q]] = (int)q;
             d_spos.upload(spos);
@@ -804,8 +858,8 @@ private:
                                 it.uoff = S.upd_off[c] + (int64_t)b * nbc + a;
                                 it.relstart = (int)(S.rowptr[c] + a);
                                 it.cnt = std::min(64, nbc - a);
-                                it.child = c;
-                                it.b = b;
+                                it.rfirst = S.rel[S.rowptr[c] + a];
+                                it.rlast = S.rel[S.rowptr[c] + a + it.cnt - 1];
                                 it.tcol = r;
                                 it.pad = 0;
                                 items[(size_t)nxt[(size_t)S.sn_start[p] + r]++] = it;

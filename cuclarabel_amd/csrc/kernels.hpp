@@ -19,8 +19,8 @@ struct ExtItem {                 // a piece (<= 64 rows) of one child update col
     int64_t uoff;                // offset in the update store of the piece's first entry U_c(a, b)
     int relstart;                // index into rel[] of the child's row a
     int cnt;                     // rows in the piece
-    int child;
-    int b;
+    int rfirst, rlast;           // parent-local target rows of the piece's first and last entry (row slices skip
+                                 // pieces that miss their row range without touching rel[])
     int tcol;                    // parent-local column this item lands in
     int pad;
 };
@@ -44,7 +44,7 @@ struct FrontDesc {               // everything a kernel needs to know about one 
     int nc;                      // columns
     int nb;                      // rows below
     int nk;                      // K entries
-    int pad;
+    int pad;                     // row-sliced panels (TreeDev::sdesc): slice << 16 | number of slices
 };
 
 struct TreeDev {                 // device copies of the symbolic structure
@@ -63,6 +63,7 @@ struct TreeDev {                 // device copies of the symbolic structure
     const int* sched;            // supernodes in launch order (level by level, size class inside)
     const int* spos;             // supernode -> position in sched
     const int* sn_parent;        // assembly tree
+    const FrontDesc* sdesc;      // row slices of the panels too tall for one CU's LDS, one record per slice (k_panel SLICED)
     const FrontDesc* desc;       // same order: one 64-byte record per launch slot (one scalar load instead of a
                                  // chain of dependent index loads at the head of every kernel)
     const signed char* psign;    // N: expected pivot sign, permuted order
@@ -141,6 +142,8 @@ constexpr int kSmallSliceMax = 1536;       // ... and f*nc + nb*nb <= this many 
 void launch_front_wave(const FactorArgs& a, int begin, int count, int slice_doubles, hipStream_t st);
 void launch_front_tiny(const FactorArgs& a, int begin, int count, hipStream_t st);     // fronts with f <= 8, eight to a wave
 void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
+// row slices of the panels too tall for one CU (TreeDev::sdesc[begin ..]), one 1024-thread workgroup each
+void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, hipStream_t st);
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st);
 size_t panel_lds_bytes(int fmax, int panel_max);
 // nrhs > 1: grid.y = right-hand side column, strides in SolveArgs::ld_*

@@ -420,7 +420,7 @@ __device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long lon
 // Everything that does not depend on other fronts is fetched BEFORE the flag wait and parked in
 // registers: the wave's matrix items (up to PF per sweep), the row's gather-list indices, b, D^{-1},
 // the ancestors' row indices.  After the flag only the handed-over values themselves are loaded.
-constexpr int kTopPF = 7;        // forward items per wave kept in registers (8 doubles each)
+constexpr int kTopPF = 7;        // forward items per wave kept in registers (8 doubles each; 2 waves per SIMD: 256 VGPRs)
 constexpr int kTopPB = 7;        // backward items per wave
 
 template <int BS>
@@ -1312,9 +1312,16 @@ int top_solve_capacity(size_t lds)
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<512>, 512, lds) != hipSuccess) return 0;
-    // MI355X_MICROARCH.md (residency): 256-thread blocks are admitted up to
-    // min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) per CU; this kernel has ~106 SGPRs -> 6 such blocks
-    // = 3 of its 512-thread blocks, so the VGPR-limited API answer (2) is the binding one.  Keep 6 % spare.
+    // The kernel is built for 2 waves per SIMD (__launch_bounds__(512, 2): up to 256 VGPRs, it takes ~177 for the
+    // parked matrix items), so ONE 512-thread workgroup per CU is resident: the API answer.  (Measured: a 128-VGPR
+    // build with two workgroups per CU and fewer parked items is 7 % slower, with as many it spills: 40 % slower.)
+    // MI355X_MICROARCH.md (residency) caps 256-thread blocks at min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) per
+    // CU: 3 of these 512-thread blocks at ~106 SGPRs, so the register-limited API answer binds.  Keep 6 % spare.
+    if (std::getenv("HIPKKT_VERBOSE")) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_top_solve<512>)) == hipSuccess)
+            std::fprintf(stderr, "[hipkkt] k_top_solve: %d registers, %zu B dynamic LDS -> %d workgroup(s) per CU\n", fa.numRegs, lds, per_cu);
+    }
     per_cu = per_cu > 3 ? 3 : per_cu;
     return (int)(per_cu * prop.multiProcessorCount * 0.94);
 }

@@ -321,10 +321,20 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
             int a = c0;
             while (a < c1) {
                 int64_t fa = (c1 - a) + nb;
-                int64_t wd = std::max<int64_t>(1, std::min<int64_t>(c1 - a, opt.panel_cap / fa));
-                // the panel is held as a trapezoid (column j from its diagonal down): fa*w - w(w-1)/2 doubles
-                while (wd < c1 - a && fa * (wd + 1) - (wd + 1) * wd / 2 <= opt.panel_cap) ++wd;
-                wd = std::min<int64_t>(wd, opt.panel_max_cols);
+                // widest panel (<= panel_max_cols) whose LDS image fits: a trapezoid in one workgroup, or row slices
+                // in up to panel_max_slices workgroups (symbolic.hpp: panel_slice_doubles)
+                int64_t wd = std::min<int64_t>(c1 - a, opt.panel_max_cols);
+                auto solve_fits = [&](int64_t w) {
+                    const int64_t fp = (fa + 3) & ~(int64_t)3, wp = (w + 3) & ~(int64_t)3;
+                    return fp * (1 + (w + 7) / 8) <= opt.solve_cap && fp + ((fa + 7) / 8) * wp <= opt.solve_cap;
+                };
+                while (wd > 1 && (panel_slices_needed(wd, fa - wd, opt.panel_cap, std::max(1, opt.panel_max_slices)) == 0 ||
+                                  !solve_fits(wd))) --wd;
+                // slices cost a second launch per level and redundant diagonal work: only where they save a level,
+                // i.e. where the unsliced width would need more chunks for the remaining columns
+                int64_t w1 = wd;
+                while (w1 > 1 && panel_slices_needed(w1, fa - w1, opt.panel_cap, 1) == 0) --w1;
+                if (w1 >= opt.panel_slice_below || (c1 - a + w1 - 1) / w1 <= (c1 - a + wd - 1) / wd) wd = w1;
                 // avoid a sliver at the end: balance the remaining columns over the remaining chunks
                 int64_t rem = c1 - a;
                 if (wd < rem) { int64_t parts = (rem + wd - 1) / wd; wd = (rem + parts - 1) / parts; }

@@ -19,6 +19,20 @@ struct Graph {            // full symmetric pattern, no diagonal
 
 enum OrderingKind { ORDER_AMD = 0, ORDER_ND = 1, ORDER_NATURAL = 2, ORDER_USER = 3 };
 
+// LDS doubles of one row slice of a panel: the top nc x nc triangle (every slice keeps and factors its own copy) plus
+// the slice's share of the nb rows below, nc doubles each.  slices = 1 is the whole panel as a trapezoid.
+inline int64_t panel_slice_doubles(int64_t nc, int64_t nb, int64_t slices)
+{
+    return nc * (nc + 1) / 2 + ((nb + slices - 1) / slices) * nc;
+}
+// fewest row slices with which an f x nc panel fits cap doubles of LDS (0: it does not with max_slices)
+inline int panel_slices_needed(int64_t nc, int64_t nb, int64_t cap, int max_slices)
+{
+    for (int r = 1; r <= max_slices; ++r)
+        if (panel_slice_doubles(nc, nb, r) <= cap) return r;
+    return 0;
+}
+
 struct SymbolicOptions {
     int ordering = ORDER_ND;
     double amd_dense_scale = 1.5;     // directldl_qdldl.jl:24
@@ -34,6 +48,15 @@ struct SymbolicOptions {
     // 19 374 doubles of panel beside its block buffers (factor_kernels.hip: panel_lds_bytes); every split is one more
     // level of the schedule, so the cap sits just under that (cfg2: 31 levels at 17 344, 29 at 19 200)
     int64_t panel_cap = 19200;
+    // A panel too tall for one CU is cut into ROW slices, one workgroup (CU) each: every slice holds the top nc x nc
+    // block and factors it redundantly, so the slices never talk to each other (factor_kernels.hip, k_panel SLICED).
+    // That keeps tall fronts wide -- a 1531-row front takes 96 columns per level instead of 12.
+    int panel_max_slices = 16;
+    int panel_slice_below = 48;  // ... and only for fronts whose unsliced panel would be narrower than this (cfg2's
+                                 // 289-row fronts take 70+ columns unsliced: slicing them costs more than it saves)
+    // the solve kernels keep a front's vector and its partial sums in LDS: (1 + ceil(nc/8)) * f doubles forward,
+    // f + ceil(f/8) * nc backward (solve_kernels.hip: solve_lds_bytes) -- a very tall front must stay narrow for them
+    int64_t solve_cap = 20000;
     int panel_max_cols = 96;     // and no panel is wider than this: k_winv stages L11 (nc x nc) in LDS, and with 96
                                  // columns two of its workgroups share a CU (cfg2: same 18 levels as with 128, 2 % faster)
     const int64_t* user_perm = nullptr;

@@ -582,7 +582,7 @@ sys.path.insert(0, {root!r})
 from cuclarabel_amd import problems
 from cuclarabel_amd.kktsolver import HipKKTSolver
 from tests.oracle_bindings import make_oracle
-pb = problems.config2(n=6000)
+pb = {maker}
 ks = HipKKTSolver(pb.P, pb.A, pb.cones)
 assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
 o = make_oracle(pb, perm=ks.perm())
@@ -598,7 +598,8 @@ for _ in range(4):
     assert ok
     worst = max(worst, max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()))
 print("levels", ks.info["nlevels"], "worst", worst)
-assert worst < 1e-9
+from cuclarabel_amd.cones import PSDTriangleConeT
+assert worst < (1e-7 if any(isinstance(c, PSDTriangleConeT) for c in pb.cones) else 1e-9)
 print("SMALL GRID OK")
 """
 
@@ -613,7 +614,24 @@ def test_persistent_top_with_fewer_workgroups_than_fronts(cap, mult):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HIPKKT_TOP_CAP=str(cap), HIPKKT_TOP_MULT=str(mult))
-    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root)], env=env, cwd=root,
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker="problems.config2(n=6000)")],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SMALL GRID OK" in r.stdout
+
+
+@pytest.mark.parametrize("maker,cap", [("problems.config2(n=6000)", 2500), ("problems.config3(nblocks=4, blk=150)", 1500),
+                                       ("problems.config5(n=120, npsd=6, psd_dim=8, nsoc=4, soc_dim=12)", 1200)])
+def test_row_sliced_panels(maker, cap):
+    """Panels too tall for one CU's LDS are factorised in row slices, one workgroup each, every slice redoing the
+    top block (k_panel SLICED).  A small HIPKKT_PANEL_CAP (read at handle creation) forces slices on small problems;
+    the solutions must still match the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPKKT_PANEL_CAP=str(cap))
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SMALL GRID OK" in r.stdout
