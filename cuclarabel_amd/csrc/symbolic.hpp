@@ -52,7 +52,7 @@ struct SymbolicOptions {
     // block and factors it redundantly, so the slices never talk to each other (factor_kernels.hip, k_panel SLICED).
     // That keeps tall fronts wide -- a 1531-row front takes 96 columns per level instead of 12.
     int panel_max_slices = 16;
-    int panel_slice_below = 48;  // ... and only for fronts whose unsliced panel would be narrower than this (cfg2's
+    int panel_slice_below = 64;  // ... and only for fronts whose unsliced panel would be narrower than this (cfg2's
                                  // 289-row fronts take 70+ columns unsliced: slicing them costs more than it saves)
     // the solve kernels keep a front's vector and its partial sums in LDS: (1 + ceil(nc/8)) * f doubles forward,
     // f + ceil(f/8) * nc backward (solve_kernels.hip: solve_lds_bytes) -- a very tall front must stay narrow for them
