@@ -755,9 +755,9 @@ private:
                 late_count = cnt;
                 if (late_launches < 3) { late_launches = 0; late_count = 0; }
             }
-            // persistent top: the longest suffix of block-class launches none of which holds more fronts than the
-            // device keeps resident workgroups of the persistent kernel (a workgroup then has at most one front per
-            // level; k_top_solve walks its fronts in level order)
+            // persistent top: the longest suffix of block-class launches none of which holds more than 1.5 x as many
+            // fronts as the device keeps resident workgroups of the persistent kernel (a workgroup then has at most two
+            // fronts per level; k_top_solve walks its fronts in level order)
             top_launches = 0; top_count = 0; top_lds = 0; top_grid = 0;
             {
                 size_t lds = 0;
@@ -766,7 +766,8 @@ private:
                 const int cap = std::min(std::min(kTopMaxFronts, cap_env), top_solve_capacity(lds));
                 for (size_t q = launches.size(); q-- > 0;) {
                     const Launch& L = launches[q];
-                    static const double mult = std::getenv("HIPKKT_TOP_MULT") ? std::atof(std::getenv("HIPKKT_TOP_MULT")) : 1.0;
+                    // (measured on cfg2 with 240 workgroups: x1 0.313, x1.25-1.7 0.307, x2.5 0.319, x6 0.346 ms per solve)
+                    static const double mult = std::getenv("HIPKKT_TOP_MULT") ? std::atof(std::getenv("HIPKKT_TOP_MULT")) : 1.5;
                     if (L.small || L.count > mult * cap) break;
                     top_count += L.count;
                     top_lds = std::max(top_lds, L.lds_solve);
