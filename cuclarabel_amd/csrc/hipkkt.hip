@@ -986,7 +986,7 @@ static void fill_info(const Symbolic& S, hipkkt_info* info)
 
 struct PinnedScalars {
     double* h = nullptr;
-    PinnedScalars() { HIP_CHECK(hipHostMalloc((void**)&h, 8 * sizeof(double))); }
+    PinnedScalars() { HIP_CHECK(hipHostMalloc((void**)&h, 16 * sizeof(double))); }
     ~PinnedScalars() { if (h) (void)hipHostFree(h); }
 };
 
@@ -1492,8 +1492,8 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
         h->rx.alloc((size_t)K.n); h->rz.alloc((size_t)K.m);
         h->sbuf.alloc((size_t)K.m); h->zbuf.alloc((size_t)K.m); h->ybuf.alloc((size_t)K.m);
         h->partial.alloc(2 * (kNormParts + 1) + 8);
-        h->scal.alloc(8);
-        HIP_CHECK(hipMemset(h->scal.p, 0, 8 * sizeof(double)));
+        h->scal.alloc(16);               // [0] eps, [1] norme, [2] normb, [3] abort, [4] speculative norme, [8..11] update status
+        HIP_CHECK(hipMemset(h->scal.p, 0, 16 * sizeof(double)));
         h->pin.reset(new PinnedScalars);
         // cones
         {
@@ -1587,15 +1587,15 @@ static int kkt_update_device(hipkkt_kkt_t h)
     h->eng->factor(h->Kval.p, eps_ptr);          // K itself stays un-regularised (:283-291)
     h->prof.end(pf, h->stream);
     // read back: flags, eps, cone failure
-    int fl[2] = {0, 0};
-    int conefail = 0;
-    HIP_CHECK(hipMemcpyAsync(h->pin->h, h->scal.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(&conefail, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    h->eng->read_flags(fl);
-    h->last_eps = h->st.static_regularization_enable ? h->pin->h[0] : 0.0;
-    h->prof.acc.dynamic_regularizations += fl[0];
-    if (conefail) return HIPKKT_NUMERIC_FAILURE;
-    return fl[1] ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
+    // (one small kernel gathers the four words, one copy into pinned memory brings them over: three separate
+    // copies, two of them into pageable memory, cost ~60 us of idle GPU per update)
+    launch_collect_status(h->scal.p + 8, h->scal.p, h->fail.p, h->eng->flags_ptr(), h->stream);
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 8, h->scal.p + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->last_eps = h->st.static_regularization_enable ? h->pin->h[8] : 0.0;
+    h->prof.acc.dynamic_regularizations += (int64_t)h->pin->h[10];
+    if (h->pin->h[9] != 0.0) return HIPKKT_NUMERIC_FAILURE;
+    return h->pin->h[11] != 0.0 ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
 }
 
 int hipkkt_kkt_update_cones(hipkkt_kkt_t h, const double* Hs, const double* soc_u, const double* soc_v,

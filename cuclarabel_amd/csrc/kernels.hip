@@ -337,6 +337,21 @@ __global__ void k_zero_ints(int* __restrict__ p, int n)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
 }
+// the value update's status words in one place, so that ONE small copy brings them to the host
+__global__ void k_collect_status(double* __restrict__ dst, const double* __restrict__ eps, const int* __restrict__ conefail,
+                                 const int* __restrict__ flags)
+{
+    if (threadIdx.x == 0) {
+        dst[0] = eps ? eps[0] : 0.0;
+        dst[1] = conefail ? (double)conefail[0] : 0.0;
+        dst[2] = (double)flags[0];
+        dst[3] = (double)flags[1];
+    }
+}
+void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(64), 0, st, dst, eps, conefail, flags);
+}
 void launch_zero_ints(int* p, int n, hipStream_t st)
 {
     if (n <= 0) return;

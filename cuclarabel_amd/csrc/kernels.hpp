@@ -231,6 +231,8 @@ void launch_check_finite(const double* v, int n, int* flag, hipStream_t st);
 void launch_unpack_lhs(double* lhsx, double* lhsz, const double* x, int n, int m, hipStream_t st);
 // p[0..n) = 0 with a kernel: a small hipMemsetAsync stalls the stream for ~40 us on this stack
 void launch_zero_ints(int* p, int n, hipStream_t st);
+// dst[0..3] = {eps[0], conefail[0], flags[0], flags[1]} (null pointers read as 0)
+void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st);
 
 // ---- cone scalings on the device (update_scaling! + get_Hs!, src/cones/coneops_*.jl)
 struct ConeDev {
