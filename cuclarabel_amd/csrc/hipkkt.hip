@@ -622,7 +622,8 @@ private:
                 L.slice_count = (int)slice_list.size() - L.slice_begin;
                 L.lds_sliced = L.nsliced ? panel_lds_bytes(0, (int)smax) : 0;
                 L.nbk = kMaxNbk;
-                L.bs_panel = fmax > 128 ? 1024 : (fmax > 96 ? 512 : 256);
+                // (swept on cfg2 after the tree got shorter and wider: 128 / 192 beat the earlier 96 / 128 by 2 %)
+                L.bs_panel = fmax > 192 ? 1024 : (fmax > 128 ? 512 : 256);
                 L.lds_panel = panel_lds_bytes(fmax, pmax);
                 if (!L.small && L.lds_panel > kLdsCap)
                     throw std::runtime_error("panel does not fit LDS (panel_cap too large?)");
