@@ -396,7 +396,7 @@ private:
                 launch_fwd_level(a, L.begin, L.count, Ls.count - Ls.ntiny, Ls.ntiny, L.solve_bs, L.lds_solve, st);
                 ++q;
             } else if (L.small) {
-                launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st);
+                launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, L.level == 0);
             } else {
                 launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
             }

@@ -150,7 +150,7 @@ size_t panel_lds_bytes(int fmax, int panel_max);
 void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
 void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
 // one launch for a level's one-wave fronts [begin, begin + nwave) and the tiny fronts behind them (single right-hand side)
-void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st);
+void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf = false);
 void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st);
 // one launch for a whole level: nblock block-class fronts at [begin, ..), then nwave one-wave, then ntiny tiny fronts
 void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st);

@@ -35,7 +35,7 @@ __device__ inline double wave_reduce_sum(double v)
 }
 
 // ------------------------------------------------------------------ small fronts, one wave each
-__device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by)
+__device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by, bool leaf = false)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int item = bx * (int)(blockDim.x >> 6) + wv;
@@ -52,7 +52,7 @@ __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int
 
     // gather: right-hand side entry plus the children's contributions to this row, in child order
     double y = (lane < nc) ? bcol[T.perm[c0 + lane]] : 0.0;
-    if (lane < f) {
+    if (!leaf && lane < f) {                  // (a leaf has no gather lists to look at)
         const int64_t lc = (int64_t)c0 + rp + lane;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
         for (int64_t g = g0; g < g1; ++g) y += uvec[T.gl_src[g]];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
 // 92 000 one-wave fronts have f <= 8).  A whole wave for each wastes 7/8 of the machine's wave slots, and
 // these kernels are bound by how many waves are in flight: eight fronts share a wave, eight lanes each.
 constexpr int kTinyFront = 8;
-__device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int count, int bx)
+__device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int count, int bx, bool leaf = false)
 {
     const int sub = threadIdx.x & 7;                                 // row inside the front
     const int item = bx * (int)(blockDim.x >> 3) + (threadIdx.x >> 3);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
     double y = (sub < nc) ? A.b[T.perm[c0 + sub]] : 0.0;
-    if (sub < f) {
+    if (!leaf && sub < f) {
         const int64_t lc = (int64_t)c0 + rp + sub;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
         for (int64_t g = g0; g < g1; ++g) y += A.uvec[T.gl_src[g]];
@@ -203,11 +203,12 @@ __global__ __launch_bounds__(256) void k_bwd_tiny(SolveArgs A, int begin, int co
 }
 // A level's one-wave and tiny fronts are independent of each other: one launch for both (the first nwb workgroups
 // take the one-wave fronts [begin, begin + nwave), the others the tiny fronts behind them) saves a launch per sweep
-__global__ __launch_bounds__(256) void k_fwd_small(SolveArgs A, int begin, int nwave, int ntiny)
+// leaf: the fronts have no children (tree level 0), so no gather lists are read
+__global__ __launch_bounds__(256) void k_fwd_small(SolveArgs A, int begin, int nwave, int ntiny, int leaf)
 {
     const int nwb = (nwave + 3) >> 2;
-    if ((int)blockIdx.x < nwb) fwd_wave_body(A, begin, nwave, blockIdx.x, 0);
-    else fwd_tiny_body(A, begin + nwave, ntiny, blockIdx.x - nwb);
+    if ((int)blockIdx.x < nwb) fwd_wave_body(A, begin, nwave, blockIdx.x, 0, leaf != 0);
+    else fwd_tiny_body(A, begin + nwave, ntiny, blockIdx.x - nwb, leaf != 0);
 }
 __global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int nwave, int ntiny)
 {
@@ -849,14 +850,10 @@ void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int 
         hipLaunchKernelGGL(k_bwd_level<kSolveBS>, dim3(grid), dim3(kSolveBS), lds, st, a, begin, nblock, nwave, ntiny);
     }
 }
-void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st)
+void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf)
 {
-    if (nwave <= 0 || ntiny <= 0) {
-        launch_fwd(a, begin, nwave, 64, 0, st, 1);
-        launch_fwd(a, begin + nwave, ntiny, 8, 0, st, 1);
-        return;
-    }
-    hipLaunchKernelGGL(k_fwd_small, dim3((nwave + 3) / 4 + (ntiny + 31) / 32), dim3(256), 0, st, a, begin, nwave, ntiny);
+    if (nwave + ntiny <= 0) return;
+    hipLaunchKernelGGL(k_fwd_small, dim3((nwave + 3) / 4 + (ntiny + 31) / 32), dim3(256), 0, st, a, begin, nwave, ntiny, leaf ? 1 : 0);
 }
 void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st)
 {
