@@ -138,8 +138,7 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
 //  same operation order as k_front_wave; these are most of a KKT tree's leaves, and a wave apiece leaves the
 //  machine short of wave slots (the kernel is bound by waves in flight, not by bytes).
 // =====================================================================================
-constexpr int kTinyF = 8;
-constexpr int kTinySlice = 128;        // doubles: f*nc + nb*nb <= 8*8 + 7*7
+constexpr int kTinySlice = 128;        // doubles: f*nc + nb*nb <= 8*8 + 7*7 (f <= 8)
 __global__ __launch_bounds__(256) void k_front_tiny(FactorArgs A, int begin, int count)
 {
     __shared__ __attribute__((aligned(16))) double smem_t[32 * kTinySlice];
