@@ -105,3 +105,16 @@ def test_problem_generators_are_reproducible_and_interior():
     p5 = problems.config5(n=200, npsd=3, psd_dim=5, nsoc=2, soc_dim=8)
     assert make_oracle(p5).update_scaling(p5.s0, p5.z0)
     assert p5.m == 3 * 15 + 2 * 8
+
+
+def test_schedule_height_does_not_regress():
+    """Every tree level is a round of dependent launches on the GPU, so the height of the supernodal tree after
+    amalgamation (tallest child first) and panel splitting (trapezoid capacity, row slices for tall fronts) is a
+    first-order performance figure.  Pin it on two structures, with some slack for retuning."""
+    for pb, max_levels, max_stored_ratio in ((problems.config2(n=20000), 20, 1.6),
+                                             (problems.config3(nblocks=8, blk=300), 10, 1.1)):
+        nsoc = sum(1 for c in pb.cones if isinstance(c, SecondOrderConeT) and c.dim > 4)
+        K = make_oracle(pb, perm=np.arange(pb.n + pb.m + 2 * nsoc)).K()
+        _, info = _lib.symbolic_analyse(K, ordering=_lib.ORDER_ND)
+        assert info["nlevels"] <= max_levels, info
+        assert info["nnzL_stored"] <= max_stored_ratio * info["nnzL"], info      # explicit zeros stay bounded
