@@ -518,14 +518,21 @@ __global__ __launch_bounds__(BS, 2) void k_top_solve(SolveArgs A, int begin, int
             const int it = wv + p * NW;
             if (it < nitF) item_apply(rf[p], y, f, nc, part, fpad, it, nrb, lane);
         }
-        for (int it = wv + kTopPF * NW; it < nitF; it += NW) {
-            const int ks = it / nrb, rb = it - ks * nrb;
-            const int r = rb * 64 + lane, k0 = 8 * ks;
-            ItemRegs rr;
-            const bool live = !(rb * 64 + 63 < k0);
+        // (tall fronts: the items beyond the parked ones, three at a time -- 24 loads per lane in flight)
+        for (int it0 = wv + kTopPF * NW; it0 < nitF; it0 += 3 * NW) {
+            ItemRegs rr[3];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rr.m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
-            item_apply(rr, y, f, nc, part, fpad, it, nrb, lane);
+            for (int u = 0; u < 3; ++u) {
+                const int it = it0 + u * NW;
+                const int ks = it / nrb, rb = it - ks * nrb;
+                const int r = rb * 64 + lane, k0 = 8 * ks;
+                const bool live = it < nitF && !(rb * 64 + 63 < k0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rr[u].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (it0 + u * NW < nitF) item_apply(rr[u], y, f, nc, part, fpad, it0 + u * NW, nrb, lane);
         }
         __syncthreads();
         for (int i = tid; i < f; i += BS) {
@@ -595,17 +602,29 @@ __global__ __launch_bounds__(BS, 2) void k_top_solve(SolveArgs A, int begin, int
                 if (j < nc) part[rs * ncpad + j] = acc;
             }
         }
-        for (int it = wv + kTopPB * NW; it < nitB; it += NW) {
-            const int rs = it / ncb, cb = it - rs * ncb;
-            const int j = cb * 64 + lane, r0 = 8 * rs;
-            const bool live = !(r0 + 7 < cb * 64);
-            double acc = 0.0;
-            double m[8];
+        for (int it0 = wv + kTopPB * NW; it0 < nitB; it0 += 3 * NW) {
+            double m[3][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+            for (int u = 0; u < 3; ++u) {
+                const int it = it0 + u * NW;
+                const int rs = it / ncb, cb = it - rs * ncb;
+                const int j = cb * 64 + lane, r0 = 8 * rs;
+                const bool live = it < nitB && !(r0 + 7 < cb * 64);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = fma(m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-            if (j < nc) part[rs * ncpad + j] = acc;
+                for (int q = 0; q < 8; ++q) m[u][q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int it = it0 + u * NW;
+                if (it < nitB) {
+                    const int rs = it / ncb, cb = it - rs * ncb;
+                    const int j = cb * 64 + lane, r0 = 8 * rs;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+                    if (j < nc) part[rs * ncpad + j] = acc;
+                }
+            }
         }
         __syncthreads();
         for (int j = tid; j < nc; j += BS) {
