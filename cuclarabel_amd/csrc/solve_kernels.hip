@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int n
 // (L^{-1} restricted to a front is [T 0; -M I], and its transpose gives the backward form.)
 // Work is cut into items of 8 columns x 64 rows, 8 independent loads per lane in flight; partial
 // sums are combined in a fixed order (bit-reproducible).
+constexpr int kItemsInFlight = 2;     // matrix items (8 loads per lane each) a wave of the block solve kernels fetches at a time
 template <int BS>
 __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, int bx, int by)
 {
@@ -266,20 +267,31 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
     }
     __syncthreads();
     const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6;
-    for (int it = wv; it < nrb * nks; it += NW) {
-        const int ks = it / nrb, rb = it - ks * nrb;
-        const int r = rb * 64 + lane, k0 = 8 * ks;
-        if (rb * 64 + 63 < k0) {                      // wholly above T's diagonal: zeros
-            if (r < f) part[ks * fpad + r] = 0.0;
-            continue;
+    // kItemsInFlight items at a time: their loads are independent, so a wave keeps 8 x kItemsInFlight of them in flight
+    constexpr int U = kItemsInFlight;
+    for (int it0 = wv; it0 < nrb * nks; it0 += U * NW) {
+        double m[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = it0 + u * NW;
+            const int ks = it / nrb, rb = it - ks * nrb;
+            const int r = rb * 64 + lane, k0 = 8 * ks;
+            const bool live = it < nrb * nks && !(rb * 64 + 63 < k0);      // (wholly above T's diagonal: zeros)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[u][q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
         }
-        double m[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) m[q] = (r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
-        double acc = 0.0;
+        for (int u = 0; u < U; ++u) {
+            const int it = it0 + u * NW;
+            if (it < nrb * nks) {
+                const int ks = it / nrb, rb = it - ks * nrb;
+                const int r = rb * 64 + lane, k0 = 8 * ks;
+                double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc = fma(m[q], (k0 + q < nc) ? y[k0 + q] : 0.0, acc);
-        if (r < f) part[ks * fpad + r] = acc;
+                for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (k0 + q < nc) ? y[k0 + q] : 0.0, acc);
+                if (r < f) part[ks * fpad + r] = acc;
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < f; i += BS) {
@@ -295,20 +307,30 @@ __device__ inline void bwd_items(const double* __restrict__ Wt, int nc, int f, c
                                  int wv, int NW, int lane)
 {
     const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3;
-    for (int it = wv; it < ncb * nrs; it += NW) {
-        const int rs = it / ncb, cb = it - rs * ncb;
-        const int j = cb * 64 + lane, r0 = 8 * rs;
-        if (r0 + 7 < cb * 64) {                        // rows above the column block's diagonal: zeros
-            if (j < nc) part[rs * ncpad + j] = 0.0;
-            continue;
+    constexpr int U = kItemsInFlight;
+    for (int it0 = wv; it0 < ncb * nrs; it0 += U * NW) {
+        double m[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = it0 + u * NW;
+            const int rs = it / ncb, cb = it - rs * ncb;
+            const int j = cb * 64 + lane, r0 = 8 * rs;
+            const bool live = it < ncb * nrs && !(r0 + 7 < cb * 64);       // (rows above the column block's diagonal: zeros)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[u][q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
         }
-        double m[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) m[q] = (j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
-        double acc = 0.0;
+        for (int u = 0; u < U; ++u) {
+            const int it = it0 + u * NW;
+            if (it < ncb * nrs) {
+                const int rs = it / ncb, cb = it - rs * ncb;
+                const int j = cb * 64 + lane, r0 = 8 * rs;
+                double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc = fma(m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-        if (j < nc) part[rs * ncpad + j] = acc;
+                for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+                if (j < nc) part[rs * ncpad + j] = acc;
+            }
+        }
     }
 }
 
