@@ -74,21 +74,50 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
         const double eps = *A.eps;
         if (lane < nc) P[lane + lane * f] += eps * (double)T.psign[c0 + lane];
     }
-    // children, one after the other: panel part and pass-through part in one sweep
-    for (int ce = T.child_ptr[s]; ce < T.child_ptr[s + 1]; ++ce) {
-        const int c = T.child_idx[ce];
-        const int64_t crp = T.rowptr[c];
-        const int nbc = (int)(T.rowptr[c + 1] - crp);
-        const double* __restrict__ Uc = A.upd + T.upd_off[c];
-        const int* __restrict__ relc = T.rel + crp;
-        WAVE_FENCE();
-        for (int b = 0; b < nbc; ++b) {
-            const int rb = relc[b];
-            for (int a = b + lane; a < nbc; a += 64) {
-                const int ra = relc[a];
-                const double v = Uc[a + (int64_t)b * nbc];
-                if (rb < nc) P[ra + rb * f] += v;
-                else Us[(ra - nc) + (rb - nc) * nb] += v;
+    // children, one after the other: panel part and pass-through part in one sweep.  The children's headers (id, row
+    // range, update-block offset: a chain of three dependent loads) are fetched for 64 children at once, lane = child,
+    // and handed out with v_readlane: per child only the data rounds remain -- this kernel is bound by exactly that
+    // latency (a level-1 front has a dozen leaf children).
+    for (int ce0 = T.child_ptr[s]; ce0 < T.child_ptr[s + 1]; ce0 += 64) {
+        const int nch = min(64, T.child_ptr[s + 1] - ce0);
+        int h_crp = 0, h_nbc = 0, h_ulo = 0, h_uhi = 0;
+        if (lane < nch) {
+            const int c = T.child_idx[ce0 + lane];
+            const int64_t crp = T.rowptr[c];
+            const int64_t uo = T.upd_off[c];
+            h_crp = (int)crp;                                   // (row structure is int32-indexed: hipkkt.hip checks)
+            h_nbc = (int)(T.rowptr[c + 1] - crp);
+            h_ulo = (int)(uo & 0xffffffff);
+            h_uhi = (int)(uo >> 32);
+        }
+        for (int ci = 0; ci < nch; ++ci) {
+            const int crp = __builtin_amdgcn_readlane(h_crp, ci);
+            const int nbc = __builtin_amdgcn_readlane(h_nbc, ci);
+            const int64_t uo = ((int64_t)__builtin_amdgcn_readlane(h_uhi, ci) << 32) | (uint32_t)__builtin_amdgcn_readlane(h_ulo, ci);
+            const double* __restrict__ Uc = A.upd + uo;
+            const int* __restrict__ relc = T.rel + crp;
+            WAVE_FENCE();
+            if (nbc <= 10) {
+                // a small child: its whole lower triangle in ONE load round, lane = entry (a, b) -- distinct targets
+                int b = 0, rem = lane;                       // entry index -> (a, b): column b holds nbc - b entries
+                while (b < nbc && rem >= nbc - b) { rem -= nbc - b; ++b; }
+                if (b < nbc) {
+                    const int a = b + rem;
+                    const int ra = relc[a], rb = relc[b];
+                    const double v = Uc[a + (int64_t)b * nbc];
+                    if (rb < nc) P[ra + rb * f] += v;
+                    else Us[(ra - nc) + (rb - nc) * nb] += v;
+                }
+                continue;
+            }
+            for (int b = 0; b < nbc; ++b) {
+                const int rb = relc[b];
+                for (int a = b + lane; a < nbc; a += 64) {
+                    const int ra = relc[a];
+                    const double v = Uc[a + (int64_t)b * nbc];
+                    if (rb < nc) P[ra + rb * f] += v;
+                    else Us[(ra - nc) + (rb - nc) * nb] += v;
+                }
             }
         }
     }
