@@ -404,7 +404,7 @@ private:
         wait_w(st);
         if (ntl > 0) {
             const Launch& L0 = launches[nl - ntl];
-            launch_top_solve(a, L0.begin, ncount, std::min(top_grid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st);
+            launch_top_solve(a, L0.begin, ncount, std::min(top_grid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st, top_tall);
         }
         for (size_t q = nl - ntl; q-- > 0;) {
             const Launch& L = launches[q];
@@ -519,6 +519,7 @@ private:
     DBuf<int> d_spos, d_sn_parent, top_flags;
     size_t top_launches = 0, late_launches = 0, top_lds = 0;
     int top_count = 0, late_count = 0, top_grid = 0, top_epoch = 0;
+    bool top_tall = true;        // the persistent kernel's 1024-thread build (default) or its 512-thread one
     std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
     DBuf<int> d_gl_src, d_udst;
     std::vector<Launch> launches;
@@ -763,8 +764,10 @@ private:
             {
                 size_t lds = 0;
                 for (size_t q = launches.size(); q-- > 0 && !launches[q].small;) lds = std::max(lds, launches[q].lds_solve);
+                static const int tall_env = std::getenv("HIPKKT_TOP_TALL") ? std::atoi(std::getenv("HIPKKT_TOP_TALL")) : -1;
+                top_tall = tall_env != 0;           // the 1024-thread build unless HIPKKT_TOP_TALL=0 (solve_kernels.hip)
                 static const int cap_env = std::getenv("HIPKKT_TOP_CAP") ? std::atoi(std::getenv("HIPKKT_TOP_CAP")) : 1 << 30;
-                const int cap = std::min(std::min(kTopMaxFronts, cap_env), top_solve_capacity(lds));
+                const int cap = std::min(std::min(kTopMaxFronts, cap_env), top_solve_capacity(lds, top_tall));
                 for (size_t q = launches.size(); q-- > 0;) {
                     const Launch& L = launches[q];
                     // (measured on cfg2 with 240 workgroups: x1 0.313, x1.25-1.7 0.307, x2.5 0.319, x6 0.346 ms per solve)

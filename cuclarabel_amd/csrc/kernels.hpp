@@ -128,9 +128,10 @@ constexpr int kMaxNbk = 16;
 size_t solve_lds_bytes(int fmax, int ncmax);
 // persistent kernel over the top `count` fronts (schedule positions begin ..): forward then backward sweep
 constexpr int kTopMaxFronts = 480;
-int top_solve_capacity(size_t lds);   // resident workgroups the device guarantees for the persistent kernel
+int top_solve_capacity(size_t lds, bool tall);   // resident workgroups the device guarantees for the persistent kernel
+                                                // (tall: its 1024-thread build for sets with very tall fronts)
 void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
-                      hipStream_t st);
+                      hipStream_t st, bool tall);
 // max_blocks > 0: at most that many workgroups (each walks several supernodes)
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks = 0);

@@ -443,11 +443,12 @@ __device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long lon
 // Everything that does not depend on other fronts is fetched BEFORE the flag wait and parked in
 // registers: the wave's matrix items (up to PF per sweep), the row's gather-list indices, b, D^{-1},
 // the ancestors' row indices.  After the flag only the handed-over values themselves are loaded.
-constexpr int kTopPF = 7;        // forward items per wave kept in registers (8 doubles each; 2 waves per SIMD: 256 VGPRs)
-constexpr int kTopPB = 7;        // backward items per wave
-
-template <int BS>
-__global__ __launch_bounds__(BS, 2) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop, int nflag)
+// Two builds: 1024 threads with 4 items per wave parked (4 waves per SIMD, 128 VGPRs; 5 spill) -- the default: sixteen
+// waves keep twice the loads in flight and park 64 items per workgroup (cfg2 0.303 -> 0.291 ms per solve, cfg3 0.263
+// -> 0.246, cfg5 with its 1.2 MB fronts 1.56 -> 1.31); and 512 threads with 7 parked (2 waves per SIMD, ~177 VGPRs),
+// kept selectable (HIPKKT_TOP_TALL=0).
+template <int BS, int kTopPF, int kTopPB>
+__global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop, int nflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int sh_ok;
@@ -842,7 +843,9 @@ static void init_solve_lds()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_winv), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     // this kernel also has a static LDS word: leave room for it
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<512, 7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<1024, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
     (void)hipGetLastError();
 }
@@ -1343,32 +1346,39 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     else hipLaunchKernelGGL(k_bwd_block_m<512>, dim3(count, KP / kMultiCB), dim3(512), lds, st, a, begin, KP);
 }
 
-int top_solve_capacity(size_t lds)
+int top_solve_capacity(size_t lds, bool tall)
 {
     init_solve_lds();
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<512>, 512, lds) != hipSuccess) return 0;
-    // The kernel is built for 2 waves per SIMD (__launch_bounds__(512, 2): up to 256 VGPRs, it takes ~177 for the
-    // parked matrix items), so ONE 512-thread workgroup per CU is resident: the API answer.  (Measured: a 128-VGPR
-    // build with two workgroups per CU and fewer parked items is 7 % slower, with as many it spills: 40 % slower.)
-    // MI355X_MICROARCH.md (residency) caps 256-thread blocks at min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) per
-    // CU: 3 of these 512-thread blocks at ~106 SGPRs, so the register-limited API answer binds.  Keep 6 % spare.
+    const void* fn = tall ? reinterpret_cast<const void*>(k_top_solve<1024, 4, 4>) : reinterpret_cast<const void*>(k_top_solve<512, 7, 7>);
+    const hipError_t e = tall ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<1024, 4, 4>, 1024, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<512, 7, 7>, 512, lds);
+    if (e != hipSuccess) return 0;
+    // Either build has ONE workgroup per CU resident: the 1024-thread one fills a CU's wave slots at 128 VGPRs, the
+    // 512-thread one is built for 2 waves per SIMD (~177 VGPRs).  (Measured: a 128-VGPR 512-thread build with two
+    // workgroups per CU and fewer parked items is 7 % slower than that, with as many it spills: 40 % slower.)  MI355X_MICROARCH.md (residency) caps 256-thread blocks at
+    // min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) per CU, i.e. 3 x 512 threads at ~106 SGPRs: the
+    // register-limited API answer binds.  Keep 6 % spare.
     if (std::getenv("HIPKKT_VERBOSE")) {
         hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_top_solve<512>)) == hipSuccess)
-            std::fprintf(stderr, "[hipkkt] k_top_solve: %d registers, %zu B dynamic LDS -> %d workgroup(s) per CU\n", fa.numRegs, lds, per_cu);
+        if (hipFuncGetAttributes(&fa, fn) == hipSuccess)
+            std::fprintf(stderr, "[hipkkt] k_top_solve<%d>: %d registers, %zu B dynamic LDS -> %d workgroup(s) per CU\n", tall ? 1024 : 512,
+                         fa.numRegs, lds, per_cu);
     }
     per_cu = per_cu > 3 ? 3 : per_cu;
     return (int)(per_cu * prop.multiProcessorCount * 0.94);
 }
 void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
-                      hipStream_t st)
+                      hipStream_t st, bool tall)
 {
     if (count <= 0 || grid <= 0 || nflag < count) return;
     init_solve_lds();
-    hipLaunchKernelGGL(k_top_solve<512>, dim3(std::min(grid, count)), dim3(512), lds, st, a, begin, flags, epoch, count, nflag);
+    if (tall)
+        hipLaunchKernelGGL((k_top_solve<1024, 4, 4>), dim3(std::min(grid, count)), dim3(1024), lds, st, a, begin, flags, epoch, count, nflag);
+    else
+        hipLaunchKernelGGL((k_top_solve<512, 7, 7>), dim3(std::min(grid, count)), dim3(512), lds, st, a, begin, flags, epoch, count, nflag);
 }
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks)
