@@ -230,6 +230,7 @@ private:
         a.xp = xp_m.p;
         a.uvec = uvec_m.p;
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
+        a.tk_pos = nullptr; a.tk_sl = nullptr; a.tbase = nullptr; a.xf = nullptr;
         for (const Launch& L : launches) launch_fwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
         for (size_t q = launches.size(); q-- > 0;) {
             const Launch& L = launches[q];
@@ -372,6 +373,7 @@ private:
         a.xp = xp.p;
         a.uvec = uvec.p;
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
+        a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         const size_t nl = launches.size();
         // the persistent kernel covers the last ntl launches.  Right after a factorisation the W of the narrow top is
@@ -404,7 +406,15 @@ private:
         wait_w(st);
         if (ntl > 0) {
             const Launch& L0 = launches[nl - ntl];
-            launch_top_solve(a, L0.begin, ncount, std::min(top_grid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st, top_tall);
+            if (top_ntask > 0) {
+                // the set holds very tall fronts: the (front, slice) kernel; positions count from the full set's first front
+                const Launch& Lfull = launches[nl - top_launches];
+                const int pos0 = top_count - ncount;
+                launch_top_solve_sliced(a, Lfull.begin, pos0, h_tbase[(size_t)pos0], top_ntask, top_sgrid, top_slds, top_flags.p,
+                                        top_nflag, ++top_epoch, st);
+            } else {
+                launch_top_solve(a, L0.begin, ncount, std::min(top_grid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st, top_tall);
+            }
         }
         for (size_t q = nl - ntl; q-- > 0;) {
             const Launch& L = launches[q];
@@ -459,13 +469,13 @@ private:
 
 public:
     // device word set by the persistent kernel when one of its bounded waits expired (nullptr: no such kernel)
-    const int* top_abort_word() const { return (top_flags.p && top_launches > 0) ? top_flags.p + 2 * top_count : nullptr; }
+    const int* top_abort_word() const { return (top_flags.p && top_launches > 0) ? top_flags.p + 2 * top_nflag : nullptr; }
     // The caller has synchronised and found the abort word set: clear it and never use the kernel again.
     void top_gave_up()
     {
         top_disabled = true;
         release_top();
-        launch_zero_ints(top_flags.p + 2 * top_count, 1, stream);
+        launch_zero_ints(top_flags.p + 2 * top_nflag, 1, stream);
         std::fprintf(stderr, "[hipkkt] persistent top-of-tree kernel gave up waiting (GPU shared with another "
                              "resident kernel?); falling back to one launch per level\n");
     }
@@ -517,6 +527,11 @@ private:
     int64_t panel_cap = 0;
     int panel_max_slices = 1;
     DBuf<int> d_spos, d_sn_parent, top_flags;
+    DBuf<int> d_tk_pos, d_tk_sl, d_tbase;      // tasks of k_top_solve_sliced (SolveArgs::tk_*); empty unless the set has tall fronts
+    DBuf<double> xf;
+    std::vector<int> h_tbase;
+    int top_ntask = 0, top_nflag = 0, top_sgrid = 0;
+    size_t top_slds = 0;
     size_t top_launches = 0, late_launches = 0, top_lds = 0;
     int top_count = 0, late_count = 0, top_grid = 0, top_epoch = 0;
     bool top_tall = true;        // the persistent kernel's 1024-thread build (default) or its 512-thread one
@@ -780,7 +795,45 @@ private:
                 top_grid = std::min(cap, top_count);
             }
             if (top_launches < 3) { top_launches = 0; top_count = 0; top_grid = 0; }     // not worth a special kernel
-            top_flags.alloc((size_t)2 * std::max(top_count, 1) + 4);
+            top_ntask = 0;
+            top_nflag = std::max(top_count, 1);
+            {
+                // Sets with very tall fronts (solve matrix > 3 x slice_kb: far more than a CU should stream per hop) run the
+                // (front, slice) kernel: such a front is cut into slices of ~slice_kb (at most 8), the others are one task
+                static const int slice_kb = std::getenv("HIPKKT_SOLVE_SLICE_KB") ? std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_KB")) : 200;
+                std::vector<int> tp, ts;
+                h_tbase.assign((size_t)top_count + 1, 0);
+                const int b0 = top_launches ? launches[launches.size() - top_launches].begin : 0;
+                bool any_sliced = false;
+                size_t slds = 0;
+                for (int p = 0; p < top_count; ++p) {
+                    const int sn = sched[(size_t)b0 + p];
+                    const int f = front_size(sn), nc = S.sn_start[sn + 1] - S.sn_start[sn], nb = f - nc;
+                    const int64_t wbytes = (int64_t)f * nc * 8;
+                    int R = 1;
+                    if (slice_kb > 0 && wbytes > (int64_t)3 * slice_kb * 1024)      // (cfg3's 395 KB fronts are faster whole)
+                        R = (int)std::min<int64_t>(8, (wbytes + (int64_t)slice_kb * 1024 - 1) / ((int64_t)slice_kb * 1024));
+                    R = std::max(1, std::min(R, std::max(1, nb)));
+                    any_sliced = any_sliced || R > 1;
+                    h_tbase[(size_t)p] = (int)tp.size();
+                    for (int q = 0; q < R; ++q) { tp.push_back(p); ts.push_back(q | (R << 8)); }
+                    const size_t nloc = (size_t)nc + (size_t)((nb + R - 1) / R) + 8;
+                    const size_t fwd = (size_t)((nc + 3) & ~3) + nloc * (1 + (size_t)((nc + 7) >> 3));
+                    const size_t bwd = (size_t)((f + 3) & ~3) + 16 * 16;
+                    slds = std::max(slds, std::max(fwd, bwd) * sizeof(double));
+                }
+                h_tbase[(size_t)top_count] = (int)tp.size();
+                if (any_sliced && top_count > 0) {
+                    top_ntask = (int)tp.size();
+                    top_nflag = top_ntask;
+                    top_slds = slds;
+                    top_sgrid = std::min(top_solve_sliced_capacity(slds), top_ntask);
+                    d_tk_pos.upload(tp); d_tk_sl.upload(ts); d_tbase.upload(h_tbase);
+                    xf.alloc((size_t)S.N);
+                    if (top_sgrid <= 0) top_ntask = 0;
+                }
+            }
+            top_flags.alloc((size_t)2 * std::max(top_nflag, 1) + 4);
             HIP_CHECK(hipMemset(top_flags.p, 0, top_flags.n * sizeof(int)));
             tinv.alloc((size_t)toff[S.nsuper]);
             HIP_CHECK(hipMemset(tinv.p, 0, std::max<size_t>(tinv.n, 1) * sizeof(double)));

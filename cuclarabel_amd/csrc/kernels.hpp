@@ -121,6 +121,15 @@ struct SolveArgs {
     double* uvec;                // sum nb
     // several right-hand sides in one launch: column blockIdx.y lives at these strides (0 for one column)
     int64_t ld_b, ld_out, ld_xp, ld_uvec;
+    // k_top_solve_sliced (sets with very tall fronts): its tasks are (front, slice) pairs -- a front whose W is too
+    // large for one CU to stream per hop is cut into R slices (rows of W forward, columns of x backward) that never
+    // exchange anything.  Task t works on the front at set position tk_pos[t], slice tk_sl[t] & 0xff of tk_sl[t] >> 8;
+    // the tasks of position p are tbase[p] .. tbase[p+1]; xf keeps a front's forward solution while its backward
+    // slices overwrite xp.
+    const int* tk_pos;
+    const int* tk_sl;
+    const int* tbase;
+    double* xf;
 };
 
 constexpr int kSolveChunk = 128;  // diagonal chunk of the triangular solves: one wave, two unknowns per lane
@@ -132,6 +141,9 @@ int top_solve_capacity(size_t lds, bool tall);   // resident workgroups the devi
                                                 // (tall: its 1024-thread build for sets with very tall fronts)
 void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
                       hipStream_t st, bool tall);
+int top_solve_sliced_capacity(size_t lds);
+void launch_top_solve_sliced(const SolveArgs& a, int begin, int pos0, int task0, int task1, int grid, size_t lds, int* flags, int nflag,
+                             int epoch, hipStream_t st);
 // max_blocks > 0: at most that many workgroups (each walks several supernodes)
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks = 0);

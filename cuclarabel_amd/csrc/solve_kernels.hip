@@ -662,6 +662,487 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
     }
 }
 
+// ------------------------------------------------------------------ persistent kernel, sliced fronts
+// The same hand-over scheme as k_top_solve, for sets with very TALL fronts (cfg5: 1531 x 96 panels, 1.2 MB of W per
+// sweep through one CU).  Tasks are (front, slice) pairs (SolveArgs::tk_*): forward, slice sl of R owns the rows
+// [R0, R1) of W -- the top nc rows plus the first share of the rows below for slice 0, a share of the rows below for
+// the others -- and gathers the top nc entries of y itself; backward, it owns a run of columns of x and reads them
+// from W with lanes over rows (x_j = sum_r W(r,j) z_r: per-lane partial sums over the wave's row blocks, one wave
+// reduction per column, waves combined through LDS in a fixed order), building z itself, the top part from xf (the
+// forward solution slice 0 left there) so that siblings may overwrite xp meanwhile.  The slices of a front never
+// exchange anything; a parent waits for all slices of a child, a child for all slices of its parent.  As in
+// k_top_solve everything static (matrix entries, gather indices, b, D^{-1}, row indices) is parked before the wait.
+constexpr int kSlPF = 2;         // forward items per wave parked (the kernel must fit 128 VGPRs)
+constexpr int kSlGP = 4;         // gather indices per row parked
+template <int BS>
+__global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int begin, int pos0, int task0, int task1, int* flags,
+                                                             int epoch, int nflag)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int sh_ok;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = BS / 64;
+    const TreeDev& T = A.T;
+    const int me = blockIdx.x, G = gridDim.x;
+    int* flag_f = flags;
+    int* flag_b = flags + nflag;
+    int* abort_word = flags + 2 * nflag;
+    const long long t0 = wall_clock64();
+    const long long limit = 5000000;
+
+    // ================= forward =================
+    int tk = task0 + me;
+    for (; tk < task1; tk += G) {
+        const int pos = A.tk_pos[tk];
+        const int slr = A.tk_sl[tk];
+        const int sl = slr & 0xff, R = slr >> 8;
+        if (R == 1) {
+            // an ordinary front of the set: exactly k_top_solve's forward step (flags per task)
+            const FrontDesc fd = T.desc[begin + pos];
+            const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+            const int64_t rp = fd.rp;
+            const int f = nc + nb;
+            const double* __restrict__ W = A.tinv + fd.w_off;
+            const int fpad = (f + 3) & ~3;
+            double* y = smem;
+            double* part = smem + fpad;
+            // ---- preload
+            const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6, nitF = nrb * nks;
+            ItemRegs rf[4];
+    #pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int it = wv + p * NW;
+                const int ks = it / nrb, rb = it - ks * nrb;
+                const int r = rb * 64 + lane, k0 = 8 * ks;
+                const bool live = it < nitF && !(rb * 64 + 63 < k0);
+    #pragma unroll
+                for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+            }
+            constexpr int GP = 12;             // gather sources per row whose indices are fetched before the wait: the
+            int gsrc[GP];                      // separator rows near the top collect a dozen small children each
+    #pragma unroll
+            for (int q = 0; q < GP; ++q) gsrc[q] = -1;
+            int64_t g0 = 0, g1 = 0;
+            double bmine = 0.0;
+            if (tid < f) {
+                const int64_t lc = (int64_t)c0 + rp + tid;
+                g0 = T.gl_ptr[lc];
+                g1 = T.gl_ptr[lc + 1];
+    #pragma unroll
+                for (int q = 0; q < GP; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
+                if (tid < nc) bmine = A.b[T.perm[c0 + tid]];
+            }
+            if (tid == 0) sh_ok = 1;
+            __syncthreads();
+            if (wv == 0) {
+                // children inside the persistent set: poll their forward flags, lanes over children
+                bool ok = true;
+                for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
+                    const int cp = T.spos[T.child_idx[e]] - begin;
+                    if (cp >= pos0)
+                        for (int q = A.tbase[cp]; q < A.tbase[cp + 1]; ++q) ok = wait_flag(flag_f + q, epoch, abort_word, t0, limit) && ok;
+                }
+                if (!ok) sh_ok = 0;
+            }
+            __syncthreads();
+            if (!sh_ok) return;
+            // ---- gather (only the handed-over values are loaded now)
+            if (tid < f) {
+                double u[GP];
+    #pragma unroll
+                for (int q = 0; q < GP; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
+                double v = bmine;
+    #pragma unroll
+                for (int q = 0; q < GP; ++q) v += u[q];
+                for (int64_t g = g0 + GP; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+                y[tid] = v;
+            }
+            for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
+                double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
+                const int64_t lc = (int64_t)c0 + rp + i;
+                for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+                y[i] = v;
+            }
+            __syncthreads();
+    #pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int it = wv + p * NW;
+                if (it < nitF) item_apply(rf[p], y, f, nc, part, fpad, it, nrb, lane);
+            }
+            // (tall fronts: the items beyond the parked ones, three at a time -- 24 loads per lane in flight)
+            for (int it0 = wv + 4 * NW; it0 < nitF; it0 += 3 * NW) {
+                ItemRegs rr[3];
+    #pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int it = it0 + u * NW;
+                    const int ks = it / nrb, rb = it - ks * nrb;
+                    const int r = rb * 64 + lane, k0 = 8 * ks;
+                    const bool live = it < nitF && !(rb * 64 + 63 < k0);
+    #pragma unroll
+                    for (int q = 0; q < 8; ++q) rr[u].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+                }
+    #pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (it0 + u * NW < nitF) item_apply(rr[u], y, f, nc, part, fpad, it0 + u * NW, nrb, lane);
+            }
+            __syncthreads();
+            for (int i = tid; i < f; i += BS) {
+                double v = 0.0;
+                for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
+                if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
+                else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    
+            continue;
+        }
+        const FrontDesc fd = T.desc[begin + pos];
+        const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+        const int64_t rp = fd.rp;
+        const int f = nc + nb;
+        const double* __restrict__ W = A.tinv + fd.w_off;
+        const int rsz = (nb + R - 1) / R;
+        const int r_lo = nc + sl * rsz;
+        const int rs = max(0, min(rsz, f - r_lo));
+        const int R0 = sl == 0 ? 0 : r_lo, R1 = r_lo + rs;          // this slice's rows of W
+        const int nloc = R1 - R0, nlocp = (nloc + 3) & ~3, ncp = (nc + 3) & ~3;
+        double* ytop = smem;                                         // y of the top nc rows
+        double* yloc = smem + ncp;                                   // y of the slice's rows (slice 0: starts with the top ones)
+        double* part = yloc + nlocp;
+        // ---- parked: matrix items
+        const int nks = (nc + 7) >> 3, nrb = (nloc + 63) >> 6, nit = nrb * nks;
+        ItemRegs rf[kSlPF];
+#pragma unroll
+        for (int p = 0; p < kSlPF; ++p) {
+            const int it = wv + p * NW;
+            const int ks = it / nrb, rb = it - ks * nrb;
+            const int lr = rb * 64 + lane, k0 = 8 * ks;
+            const bool live = it < nit && lr < nloc;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && k0 + q < nc) ? W[(R0 + lr) + (int64_t)(k0 + q) * f] : 0.0;
+        }
+        // ---- parked: gather lists of the slice's rows (thread = row, two rows per thread at most) and, for the other
+        // slices, of the top rows (threads 0 .. nc-1)
+        int gs[2][kSlGP];
+        int64_t g0[2] = {0, 0}, g1[2] = {0, 0};
+        double bm[2] = {0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+#pragma unroll
+            for (int q = 0; q < kSlGP; ++q) gs[x][q] = -1;
+            const int lr = tid + x * BS;
+            if (lr < nloc) {
+                const int row = R0 + lr;
+                const int64_t lc = (int64_t)c0 + rp + row;
+                g0[x] = T.gl_ptr[lc];
+                g1[x] = T.gl_ptr[lc + 1];
+#pragma unroll
+                for (int q = 0; q < kSlGP; ++q) gs[x][q] = (g0[x] + q < g1[x]) ? T.gl_src[g0[x] + q] : -1;
+                if (row < nc) bm[x] = A.b[T.perm[c0 + row]];
+            }
+        }
+        int gt[kSlGP];
+        int64_t gt0 = 0, gt1 = 0;
+        double bt = 0.0;
+#pragma unroll
+        for (int q = 0; q < kSlGP; ++q) gt[q] = -1;
+        if (sl != 0 && tid < nc) {
+            const int64_t lc = (int64_t)c0 + rp + tid;
+            gt0 = T.gl_ptr[lc];
+            gt1 = T.gl_ptr[lc + 1];
+#pragma unroll
+            for (int q = 0; q < kSlGP; ++q) gt[q] = (gt0 + q < gt1) ? T.gl_src[gt0 + q] : -1;
+            bt = A.b[T.perm[c0 + tid]];
+        }
+        if (tid == 0) sh_ok = 1;
+        __syncthreads();
+        if (wv == 0) {
+            bool ok = true;
+            for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
+                const int cp = T.spos[T.child_idx[e]] - begin;
+                if (cp >= pos0)
+                    for (int q = A.tbase[cp]; q < A.tbase[cp + 1]; ++q) ok = wait_flag(flag_f + q, epoch, abort_word, t0, limit) && ok;
+            }
+            if (!ok) sh_ok = 0;
+        }
+        __syncthreads();
+        if (!sh_ok) return;
+        // ---- gather: only the handed-over values are loaded now
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int lr = tid + x * BS;
+            if (lr < nloc) {
+                double u[kSlGP];
+#pragma unroll
+                for (int q = 0; q < kSlGP; ++q) u[q] = gs[x][q] >= 0 ? LD_AGENT_F64(A.uvec + gs[x][q]) : 0.0;
+                double v = bm[x];
+#pragma unroll
+                for (int q = 0; q < kSlGP; ++q) v += u[q];
+                for (int64_t g = g0[x] + kSlGP; g < g1[x]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+                yloc[lr] = v;
+                if (sl == 0 && lr < nc) ytop[lr] = v;
+            }
+        }
+        for (int lr = tid + 2 * BS; lr < nloc; lr += BS) {              // (slices taller than 2 x BS rows: none with R <= 8)
+            const int row = R0 + lr;
+            double v = (row < nc) ? A.b[T.perm[c0 + row]] : 0.0;
+            const int64_t lc = (int64_t)c0 + rp + row;
+            for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+            yloc[lr] = v;
+            if (sl == 0 && lr < nc) ytop[lr] = v;
+        }
+        if (sl != 0 && tid < nc) {
+            double u[kSlGP];
+#pragma unroll
+            for (int q = 0; q < kSlGP; ++q) u[q] = gt[q] >= 0 ? LD_AGENT_F64(A.uvec + gt[q]) : 0.0;
+            double v = bt;
+#pragma unroll
+            for (int q = 0; q < kSlGP; ++q) v += u[q];
+            for (int64_t g = gt0 + kSlGP; g < gt1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+            ytop[tid] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < kSlPF; ++p) {
+            const int it = wv + p * NW;
+            if (it < nit) {
+                const int ks = it / nrb, rb = it - ks * nrb;
+                const int lr = rb * 64 + lane, k0 = 8 * ks;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = fma(rf[p].m[q], (k0 + q < nc) ? ytop[k0 + q] : 0.0, acc);
+                if (lr < nloc) part[ks * nlocp + lr] = acc;
+            }
+        }
+        for (int it0 = wv + kSlPF * NW; it0 < nit; it0 += 3 * NW) {
+            double m[3][8];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int it = it0 + u * NW;
+                const int ks = it / nrb, rb = it - ks * nrb;
+                const int lr = rb * 64 + lane, k0 = 8 * ks;
+                const bool live = it < nit && lr < nloc;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[u][q] = (live && k0 + q < nc) ? W[(R0 + lr) + (int64_t)(k0 + q) * f] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int it = it0 + u * NW;
+                if (it < nit) {
+                    const int ks = it / nrb, rb = it - ks * nrb;
+                    const int lr = rb * 64 + lane, k0 = 8 * ks;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (k0 + q < nc) ? ytop[k0 + q] : 0.0, acc);
+                    if (lr < nloc) part[ks * nlocp + lr] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        for (int lr = tid; lr < nloc; lr += BS) {
+            double v = 0.0;
+            for (int ks = 0; ks < nks; ++ks) v += part[ks * nlocp + lr];
+            const int row = R0 + lr;
+            if (row < nc) { ST_AGENT_F64(A.xp + c0 + row, v); ST_AGENT_F64(A.xf + c0 + row, v); }
+            else ST_AGENT_F64(A.uvec + rp + row - nc, yloc[lr] - v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ================= backward =================
+    for (tk -= G; tk >= task0; tk -= G) {
+        const int pos = A.tk_pos[tk];
+        const int slr = A.tk_sl[tk];
+        const int sl = slr & 0xff, R = slr >> 8;
+        if (R == 1) {
+            // an ordinary front: exactly k_top_solve's backward step.  (Its own forward solution is still in xp: only
+            // sliced fronts are overwritten by siblings.)
+            const FrontDesc fd = T.desc[begin + pos];
+            const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+            const int64_t rp = fd.rp;
+            const int f = nc + nb;
+            const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;
+            const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
+            double* z = smem;
+            double* part = smem + fpad;
+            // ---- preload
+            const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3, nitB = ncb * nrs;
+            ItemRegs rbk[4];
+    #pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int it = wv + p * NW;
+                const int rs = it / ncb, cb = it - rs * ncb;
+                const int j = cb * 64 + lane, r0 = 8 * rs;
+                const bool live = it < nitB && !(r0 + 7 < cb * 64);
+    #pragma unroll
+                for (int q = 0; q < 8; ++q) rbk[p].m[q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+            }
+            int ridx = -1;
+            double dinv = 0.0;
+            if (tid < nc) dinv = A.Dinv[c0 + tid];
+            else if (tid < f) ridx = T.rows[rp + tid - nc];
+            if (tid == 0) sh_ok = 1;
+            __syncthreads();
+            if (wv == 0) {
+                bool ok = true;
+                const int par = T.sn_parent[s];
+                if (lane == 0 && par >= 0) {
+                    const int pp = T.spos[par] - begin;        // the parent of a front of the set is in the set
+                    for (int q = A.tbase[pp]; q < A.tbase[pp + 1]; ++q) ok = wait_flag(flag_b + q, epoch, abort_word, t0, limit) && ok;
+                }
+                if (!ok) sh_ok = 0;
+            }
+            __syncthreads();
+            if (!sh_ok) return;
+            if (tid < nc) z[tid] = LD_AGENT_F64(A.xp + c0 + tid) * dinv;
+            else if (tid < f) z[tid] = -LD_AGENT_F64(A.xp + ridx);
+            for (int i = tid + BS; i < f; i += BS)
+                z[i] = (i < nc) ? LD_AGENT_F64(A.xp + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
+            __syncthreads();
+    #pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int it = wv + p * NW;
+                if (it < nitB) {
+                    const int rs = it / ncb, cb = it - rs * ncb;
+                    const int j = cb * 64 + lane, r0 = 8 * rs;
+                    double acc = 0.0;
+    #pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+                    if (j < nc) part[rs * ncpad + j] = acc;
+                }
+            }
+            for (int it0 = wv + 4 * NW; it0 < nitB; it0 += 3 * NW) {
+                double m[3][8];
+    #pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int it = it0 + u * NW;
+                    const int rs = it / ncb, cb = it - rs * ncb;
+                    const int j = cb * 64 + lane, r0 = 8 * rs;
+                    const bool live = it < nitB && !(r0 + 7 < cb * 64);
+    #pragma unroll
+                    for (int q = 0; q < 8; ++q) m[u][q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+                }
+    #pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int it = it0 + u * NW;
+                    if (it < nitB) {
+                        const int rs = it / ncb, cb = it - rs * ncb;
+                        const int j = cb * 64 + lane, r0 = 8 * rs;
+                        double acc = 0.0;
+    #pragma unroll
+                        for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
+                        if (j < nc) part[rs * ncpad + j] = acc;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < nc; j += BS) {
+                double v = 0.0;
+                for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
+                ST_AGENT_F64(A.xp + c0 + j, v);
+                A.out[T.perm[c0 + j]] = v;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag_b + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    
+            continue;
+        }
+        const FrontDesc fd = T.desc[begin + pos];
+        const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+        const int64_t rp = fd.rp;
+        const int f = nc + nb;
+        const double* __restrict__ W = A.tinv + fd.w_off;
+        const int csz = (nc + R - 1) / R;
+        const int j0 = sl * csz, ncl = max(0, min(csz, nc - j0));      // this slice's columns of x
+        const int fpad = (f + 3) & ~3;
+        double* z = smem;
+        double* part = smem + fpad;                                     // NW x 16
+        const int nrb = (f + 63) >> 6;
+        // ---- parked: the first 16-column chunk's entries of the wave's first row block; row indices; D^{-1}
+        constexpr int CW = 8;                                           // columns per pass (register budget)
+        double pm[CW];
+        {
+            const int r = wv * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) pm[c] = (c < ncl && r < f) ? W[r + (int64_t)(j0 + c) * f] : 0.0;
+        }
+        int ridx[2] = {-1, -1};
+        double dinv[2] = {0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int i = tid + x * BS;
+            if (i < nc) dinv[x] = A.Dinv[c0 + i];
+            else if (i < f) ridx[x] = T.rows[rp + i - nc];
+        }
+        if (tid == 0) sh_ok = 1;
+        __syncthreads();
+        if (wv == 0) {
+            bool ok = true;
+            const int par = T.sn_parent[s];
+            if (lane == 0 && par >= 0) {
+                const int pp = T.spos[par] - begin;
+                for (int q = A.tbase[pp]; q < A.tbase[pp + 1]; ++q) ok = wait_flag(flag_b + q, epoch, abort_word, t0, limit) && ok;
+            }
+            if (!ok) sh_ok = 0;
+        }
+        __syncthreads();
+        if (!sh_ok) return;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int i = tid + x * BS;
+            if (i < nc) z[i] = LD_AGENT_F64(A.xf + c0 + i) * dinv[x];
+            else if (i < f) z[i] = -LD_AGENT_F64(A.xp + ridx[x]);
+        }
+        for (int i = tid + 2 * BS; i < f; i += BS)
+            z[i] = (i < nc) ? LD_AGENT_F64(A.xf + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
+        __syncthreads();
+        for (int cc = 0; cc < ncl; cc += CW) {
+            const int ncc = min(CW, ncl - cc);
+            double acc[CW];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) acc[c] = 0.0;
+            int x = 0;
+            for (int rb = wv; rb < nrb; rb += NW, ++x) {
+                const int r = rb * 64 + lane;
+                const double zl = r < f ? z[r] : 0.0;
+                if (cc == 0 && x == 0) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) acc[c] = fma(pm[c], zl, acc[c]);
+                } else {
+                    double m[CW];
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) m[c] = (c < ncc && r < f) ? W[r + (int64_t)(j0 + cc + c) * f] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) acc[c] = fma(m[c], zl, acc[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const double sum = wave_reduce_sum(acc[c]);
+                if (lane == 0) part[wv * 16 + c] = sum;
+            }
+            __syncthreads();
+            if (tid < ncc) {
+                double v = 0.0;
+                for (int w = 0; w < NW; ++w) v += part[w * 16 + tid];
+                const int j = j0 + cc + tid;
+                ST_AGENT_F64(A.xp + c0 + j, v);
+                A.out[T.perm[c0 + j]] = v;
+            }
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag_b + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------ W = [L11^{-1} ; L21 L11^{-1}]
 // Runs once after the factorisation, all supernodes in parallel (off the critical path of the tree).
 // L11 (unit lower, nc x nc) is staged in LDS and inverted in place, blocked bottom-up:
@@ -846,6 +1327,8 @@ static void init_solve_lds()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<512, 7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<1024, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve_sliced<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               150 * 1024);
     (void)hipGetLastError();
 }
@@ -1379,6 +1862,25 @@ void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t
         hipLaunchKernelGGL((k_top_solve<1024, 4, 4>), dim3(std::min(grid, count)), dim3(1024), lds, st, a, begin, flags, epoch, count, nflag);
     else
         hipLaunchKernelGGL((k_top_solve<512, 7, 7>), dim3(std::min(grid, count)), dim3(512), lds, st, a, begin, flags, epoch, count, nflag);
+}
+int top_solve_sliced_capacity(size_t lds)
+{
+    init_solve_lds();
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve_sliced<1024>, 1024, lds) != hipSuccess) return 0;
+    per_cu = per_cu > 1 ? 1 : per_cu;
+    return (int)(per_cu * prop.multiProcessorCount * 0.94);
+}
+void launch_top_solve_sliced(const SolveArgs& a, int begin, int pos0, int task0, int task1, int grid, size_t lds, int* flags, int nflag,
+                             int epoch, hipStream_t st)
+{
+    const int ntask = task1 - task0;
+    if (ntask <= 0 || grid <= 0 || nflag < task1) return;
+    init_solve_lds();
+    hipLaunchKernelGGL(k_top_solve_sliced<1024>, dim3(std::min(grid, ntask)), dim3(1024), lds, st, a, begin, pos0, task0, task1, flags,
+                       epoch, nflag);
 }
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks)

@@ -635,3 +635,20 @@ def test_row_sliced_panels(maker, cap):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SMALL GRID OK" in r.stdout
+
+
+@pytest.mark.parametrize("maker,kb", [("problems.config2(n=6000)", 8), ("problems.config3(nblocks=4, blk=150)", 16),
+                                      ("problems.config5(n=120, npsd=6, psd_dim=8, nsoc=4, soc_dim=12)", 4)])
+def test_sliced_persistent_solve(maker, kb):
+    """Sets with very tall fronts run k_top_solve_sliced: a front is cut into (front, slice) tasks -- rows of W forward,
+    columns of x backward -- that never exchange anything.  A small HIPKKT_SOLVE_SLICE_KB (read at handle creation)
+    forces slices on small problems; the solutions must still match the oracle and the grid must drain."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb))
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SMALL GRID OK" in r.stdout
