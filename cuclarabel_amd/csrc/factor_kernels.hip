@@ -755,14 +755,17 @@ size_t panel_lds_bytes(int fmax, int panel_max)
 
 static void init_factor_lds()
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_wave), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static PerDeviceOnce once;
+    once.run([]() {
+        hipError_t e = hipSuccess;
+        auto set = [&](auto k) { if (e == hipSuccess) e = set_max_lds(k, 160 * 1024); };
+        set(k_panel<256, false>);
+        set(k_panel<512, false>);
+        set(k_panel<1024, false>);
+        set(k_panel<1024, true>);
+        set(k_front_wave);
+        return e;
+    });
 }
 
 void launch_front_tiny(const FactorArgs& a, int begin, int count, hipStream_t st)

@@ -26,7 +26,6 @@ namespace hipkkt {
 
 static thread_local std::string g_last_error;
 
-struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 #define HIP_CHECK(expr)                                                                          \
@@ -120,9 +119,9 @@ public:
             int nblock = 0, nsl_fronts = 0;
             for (const Launch& L : launches) if (!L.small) { nblock += L.count; nsl_fronts += L.nsliced; }
             std::fprintf(stderr, "[hipkkt] N %d, %d supernodes in %zu levels (%zu launches), %d block-class fronts, %d of them in "
-                         "%zu row slices; persistent solve set: last %zu launches, %d fronts on %d workgroups\n",
+                         "%zu row slices; persistent solve set: last %zu launches, %d fronts on %d workgroups, %d (front, slice) tasks\n",
                          S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
-                         top_count, top_grid);
+                         top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask);
         }
     }
 
@@ -1446,13 +1445,14 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
         if (n + m == 0) throw ArgError("empty problem");
         std::unique_ptr<hipkkt_kkt_s> h(new hipkkt_kkt_s);
         if (settings) h->st = *settings; else hipkkt_default_settings(&h->st);
-        h->device = select_device(h->st);
-        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        // host-side assembly first: a malformed (P, A, cones) is an argument error whether or not a device is there
         try {
             assemble_kkt(n, m, Pcolptr, Prowval, Pnzval, Acolptr, Arowval, Anzval, ncones, kinds, dims, base, h->K);
         } catch (const std::runtime_error& e) {
             throw ArgError(e.what());
         }
+        h->device = select_device(h->st);
+        HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         KKTAssembly& K = h->K;
         hipkkt_settings st = h->st;
         if (st.ordering == HIPKKT_ORDER_USER && !st.user_perm) throw ArgError("ORDER_USER needs user_perm");

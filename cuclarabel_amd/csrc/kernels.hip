@@ -726,13 +726,8 @@ void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, 
     if (m > 0) hipLaunchKernelGGL(k_cone_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, s, z, m);
     if (C.nsoc > 0) hipLaunchKernelGGL(k_cone_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, s, z);
     if (C.npsd > 0) {
-        static bool once = false;
-        if (!once) {
-            once = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cone_psd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      150 * 1024);
-            (void)hipGetLastError();
-        }
+        static PerDeviceOnce once;
+        once.run([]() { return set_max_lds(k_cone_psd, 150 * 1024); });
         const size_t lds = (size_t)6 * C.psd_kmax * C.psd_kmax * sizeof(double);
         hipLaunchKernelGGL(k_cone_psd, dim3(C.npsd), dim3(256), lds, st, C, S, s, z);
     }

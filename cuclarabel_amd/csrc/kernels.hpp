@@ -12,8 +12,41 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <mutex>
+#include <stdexcept>
+#include <string>
 
 namespace hipkkt {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };   // -> HIPKKT_ERR_HIP at the C ABI
+
+// Function attributes (hipFuncSetAttribute) are per DEVICE, and a process may hold handles on several devices and
+// drive them from several threads: run `fn` once per device ordinal, under a lock; `fn` returns a hipError_t and a
+// failure throws (the C ABI turns that into a negative return code) instead of leaving a kernel that cannot launch.
+class PerDeviceOnce {
+    std::mutex mu_;
+    uint64_t done_[4] = {0, 0, 0, 0};       // 256 device ordinals
+public:
+    template <class F>
+    void run(F&& fn)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) throw HipError("hipGetDevice failed");
+        std::lock_guard<std::mutex> lk(mu_);
+        if (done_[dev >> 6] >> (dev & 63) & 1) return;
+        const hipError_t e = fn();
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            throw HipError(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+        }
+        done_[dev >> 6] |= (uint64_t)1 << (dev & 63);
+    }
+};
+template <class K>
+inline hipError_t set_max_lds(K kernel, int bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 struct ExtItem {                 // a piece (<= 64 rows) of one child update column that lands in a panel column; 32 bytes
     int64_t uoff;                // offset in the update store of the piece's first entry U_c(a, b)

@@ -51,6 +51,24 @@ void assemble_kkt(int64_t n64, int64_t m64, const int64_t* Pp, const int64_t* Pi
     K.p = 2 * K.nsparse;
     const int N = K.N = n + m + K.p;
 
+    // ---- the caller's CSC arrays: a wrong index_base or a malformed colptr must end as an argument error, not as
+    // host writes out of bounds further down
+    auto check_csc = [&](const char* what, const int64_t* cp, const int64_t* ri, const double* vx, int64_t nrows) {
+        if (!cp) throw std::runtime_error(std::string("kkt: ") + what + " colptr is null");
+        if (cp[0] != base) throw std::runtime_error(std::string("kkt: ") + what + " colptr[0] does not equal index_base");
+        for (int j = 0; j < n; ++j)
+            if (cp[j + 1] < cp[j]) throw std::runtime_error(std::string("kkt: ") + what + " colptr is not non-decreasing");
+        const int64_t nnz = cp[n] - base;
+        if (nnz >= ((int64_t)1 << 31)) throw std::runtime_error(std::string("kkt: ") + what + " has too many entries");
+        if (nnz > 0 && (!ri || !vx)) throw std::runtime_error(std::string("kkt: ") + what + " rowval / nzval is null");
+        for (int64_t q = 0; q < nnz; ++q) {
+            const int64_t r = ri[q] - base;
+            if (r < 0 || r >= nrows) throw std::runtime_error(std::string("kkt: ") + what + " row index out of range");
+        }
+    };
+    check_csc("P", Pp, Pi, Px, n);
+    check_csc("A", Ap, Ai, Ax, m);
+
     // ---- column lengths
     std::vector<int64_t> len((size_t)N, 0);
     const int64_t nnzP = Pp[n] - base, nnzA = Ap[n] - base;

@@ -1302,35 +1302,25 @@ constexpr int kSolveBS = 512;
 
 static void init_solve_lds()
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_block<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_block<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_block<kSolveBS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_block<kSolveBS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_level<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_level<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_level<kSolveBS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd_level<kSolveBS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_winv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    // this kernel also has a static LDS word: leave room for it
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<512, 7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve<1024, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_top_solve_sliced<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024);
-    (void)hipGetLastError();
+    static PerDeviceOnce once;
+    once.run([]() {
+        hipError_t e = hipSuccess;
+        auto set = [&](auto k, int bytes) { if (e == hipSuccess) e = set_max_lds(k, bytes); };
+        set(k_fwd_block<128>, 160 * 1024);
+        set(k_bwd_block<128>, 160 * 1024);
+        set(k_fwd_block<kSolveBS>, 160 * 1024);
+        set(k_bwd_block<kSolveBS>, 160 * 1024);
+        set(k_fwd_level<128>, 160 * 1024);
+        set(k_bwd_level<128>, 160 * 1024);
+        set(k_fwd_level<kSolveBS>, 160 * 1024);
+        set(k_bwd_level<kSolveBS>, 160 * 1024);
+        set(k_winv, 160 * 1024);
+        // these kernels also have a static LDS word: leave room for it
+        set(k_top_solve<512, 7, 7>, 150 * 1024);
+        set(k_top_solve<1024, 4, 4>, 150 * 1024);
+        set(k_top_solve_sliced<1024>, 150 * 1024);
+        return e;
+    });
 }
 
 size_t solve_lds_bytes(int fmax, int ncmax)

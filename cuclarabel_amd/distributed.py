@@ -42,7 +42,14 @@ def gather_records(local_records, n_problems, width, device=None):
     (n_problems, width) tensor ordered by problem index on every rank.  Message size is
     O(n_problems * width * 8 B): latency-bound, topology irrelevant."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    per_rank = (n_problems + world - 1) // world
+    # rows per rank = the LARGEST share any rank holds: a weighted (LPT) assignment may give one rank more than
+    # ceil(n_problems / world) problems, so the size is agreed on with one MAX all-reduce instead of assumed
+    per_rank = len(local_records)
+    if world > 1:
+        cnt = torch.tensor([per_rank], dtype=torch.int64, device=device)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        per_rank = int(cnt.item())
+    per_rank = max(per_rank, 1)
     buf = torch.full((per_rank, width), float("nan"), dtype=torch.float64, device=device)
     for k, rec in enumerate(local_records):
         buf[k, :] = torch.as_tensor(rec, dtype=torch.float64)

@@ -50,6 +50,38 @@ def test_create_without_gpu_fails_loudly_not_silently():
         HipKKTSolver(pb.P, pb.A, pb.cones)          # no CPU fallback
 
 
+def test_malformed_csc_is_an_argument_error_not_a_crash():
+    """A wrong index_base or a broken colptr / row index must come back as HIPKKT_ERR_ARG (-1) from the host-side
+    assembly (before any device call, so this runs without a GPU), never as out-of-bounds host writes."""
+    from cuclarabel_amd._lib import f64, i64, ptr
+    L = _lib.lib()
+    n, m = 3, 2
+    Pp, Pi, Px = i64([0, 1, 2, 3]), i64([0, 1, 2]), f64([1.0, 1.0, 1.0])
+    Ap, Ai, Ax = i64([0, 1, 2, 2]), i64([0, 1]), f64([1.0, 1.0])
+    kinds, dims = np.array([1], dtype=np.int32), i64([2])
+
+    def create(Pp=Pp, Pi=Pi, Ap=Ap, Ai=Ai, base=0):
+        h = C.c_void_p()
+        rc = L.hipkkt_kkt_create(C.byref(h), n, m, ptr(Pp), ptr(Pi), ptr(Px), ptr(Ap), ptr(Ai), ptr(Ax), 1,
+                                 ptr(kinds), ptr(dims), None, base)
+        if rc == 0:
+            L.hipkkt_kkt_destroy(h)
+        return rc, L.hipkkt_last_error().decode()
+
+    for kw, what in ((dict(base=1), "index_base"),                           # 0-based arrays declared 1-based
+                     (dict(Pp=i64([0, 2, 1, 3])), "non-decreasing"),
+                     (dict(Pi=i64([0, -1, 2])), "row index out of range"),
+                     (dict(Pi=i64([0, 1, 5])), "row index out of range"),
+                     (dict(Ai=i64([0, 2])), "row index out of range"),
+                     (dict(Ap=i64([0, 1, 0, 2])), "non-decreasing"),
+                     (dict(Pi=i64([0, 0, 2]), Pp=i64([0, 1, 2, 3])), None)):  # fine: P(0,1) is upper triangular
+        rc, msg = create(**kw)
+        if what is None:
+            assert rc in (0, -2), (rc, msg)           # valid input: success on a GPU box, HIP error without a device
+        else:
+            assert rc == -1 and what in msg, (kw, rc, msg)
+
+
 @pytest.mark.parametrize("ordering", [_lib.ORDER_AMD, _lib.ORDER_ND, _lib.ORDER_NATURAL])
 def test_symbolic_analysis_matches_oracle_symbolic(ordering):
     pb = problems.config2(n=3000)

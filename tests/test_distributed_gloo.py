@@ -18,14 +18,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_problems, q):
+def _worker(rank, world, port, n_problems, q, weights=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cuclarabel_amd import problems
         from tests.oracle_bindings import make_oracle
-        mine = assign_problems(n_problems, world, rank)
+        mine = assign_problems(n_problems, world, rank, weights=weights)
         recs = []
         for j in mine:
             # each rank works on its own independent SOCP (cfg4's generator, tiny): the oracle stands
@@ -64,6 +64,27 @@ def test_two_rank_sharding_and_record_gather():
     assert np.all(table[:, 1] == 1.0)
     assert np.all(np.isfinite(table[:, 3]))
     assert out[0][3] == out[1][3] == 2.0          # MAX over ranks
+
+
+def test_skewed_weights_with_record_gather():
+    """LPT with weights [10, 1, 1, 1] on 2 ranks gives rank 1 three problems, more than ceil(4 / 2): the record
+    gather must size its buffer from the largest share, not from n_problems / world."""
+    world, weights = 2, [10.0, 1.0, 1.0, 1.0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, len(weights), q, weights)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    assert out[0][1] == [0] and out[1][1] == [1, 2, 3]
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert list(out[0][2][:, 0]) == [0, 1, 2, 3]
+    assert np.all(out[0][2][:, 1] == 1.0)
 
 
 def test_weighted_assignment_balances_and_is_a_partition():

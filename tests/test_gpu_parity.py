@@ -219,6 +219,17 @@ def test_update_P_A_vs_fresh():
         out.append((x, z))
     np.testing.assert_allclose(out[0][0], out[1][0], atol=1e-7)     # data_updating.jl:28
     np.testing.assert_allclose(out[0][1], out[1][1], atol=1e-7)
+    # the oracle driven the same way (kktsolver_update_P!/A!, kktsolver_directldl.jl:374-386, then the next update)
+    o = _oracle_for(pb, ks)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    o.kktsolver_update_P(Px2); o.kktsolver_update_A(Ax2)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    np.testing.assert_allclose(ks.KKT().data, o.K().data, rtol=1e-12, atol=1e-300)
+    o.kktsolver_setrhs(rx, rz)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok
+    scale = max(np.abs(xo).max(), np.abs(zo).max())
+    assert max(np.abs(out[0][0] - xo).max(), np.abs(out[0][1] - zo).max()) / scale < 1e-9
 
 
 def test_solve_with_lhs_nothing():
@@ -372,6 +383,14 @@ def test_block_diagonal_batch_equals_the_individual_problems():
         scale = max(np.abs(x).max(), np.abs(z).max())
         assert np.abs(X[ox:ox + pb.n] - x).max() / scale < 1e-9
         assert np.abs(Z[oz:oz + pb.m] - z).max() / scale < 1e-9
+        # and each block against the oracle on that problem alone
+        o = _oracle_for(pb, k1)
+        assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+        o.kktsolver_setrhs(rx, rz)
+        ok, xo, zo = o.kktsolver_solve()
+        assert ok
+        so = max(np.abs(xo).max(), np.abs(zo).max())
+        assert max(np.abs(X[ox:ox + pb.n] - xo).max(), np.abs(Z[oz:oz + pb.m] - zo).max()) / so < 1e-9
         ox += pb.n
         oz += pb.m
 
@@ -604,6 +623,16 @@ print("SMALL GRID OK")
 """
 
 
+def _schedule_line(stderr):
+    """The HIPKKT_VERBOSE schedule summary of the handle (hipkkt.hip, LDLEngine constructor) as a dict."""
+    import re
+    m = re.search(r"(\d+) block-class fronts, (\d+) of them in (\d+) row slices; persistent solve set: last (\d+) launches, "
+                  r"(\d+) fronts on (\d+) workgroups, (\d+) \(front, slice\) tasks", stderr)
+    assert m, stderr
+    keys = ("block_fronts", "sliced_fronts", "row_slices", "top_launches", "top_fronts", "top_grid", "top_tasks")
+    return dict(zip(keys, map(int, m.groups())))
+
+
 @pytest.mark.parametrize("cap,mult", [(3, 1.0), (5, 64.0)])
 def test_persistent_top_with_fewer_workgroups_than_fronts(cap, mult):
     """The persistent kernel over the top of the tree walks several fronts per workgroup (k_top_solve: positions me,
@@ -613,11 +642,14 @@ def test_persistent_top_with_fewer_workgroups_than_fronts(cap, mult):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_TOP_CAP=str(cap), HIPKKT_TOP_MULT=str(mult))
+    env = dict(os.environ, HIPKKT_TOP_CAP=str(cap), HIPKKT_TOP_MULT=str(mult), HIPKKT_VERBOSE="1")
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker="problems.config2(n=6000)")],
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SMALL GRID OK" in r.stdout
+    sched = _schedule_line(r.stderr)
+    assert "gave up" not in r.stderr, r.stderr                       # the grid drained: no bounded wait expired
+    assert sched["top_fronts"] > sched["top_grid"] == cap, sched     # several fronts per workgroup, as forced
 
 
 @pytest.mark.parametrize("maker,cap", [("problems.config2(n=6000)", 2500), ("problems.config3(nblocks=4, blk=150)", 1500),
@@ -630,11 +662,14 @@ def test_row_sliced_panels(maker, cap):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_PANEL_CAP=str(cap))
+    env = dict(os.environ, HIPKKT_PANEL_CAP=str(cap), HIPKKT_VERBOSE="1")
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SMALL GRID OK" in r.stdout
+    assert "gave up" not in r.stderr, r.stderr
+    sched = _schedule_line(r.stderr)
+    assert sched["sliced_fronts"] > 0 and sched["row_slices"] > sched["sliced_fronts"], sched    # the sliced path ran
 
 
 @pytest.mark.parametrize("maker,kb", [("problems.config2(n=6000)", 8), ("problems.config3(nblocks=4, blk=150)", 16),
@@ -647,8 +682,40 @@ def test_sliced_persistent_solve(maker, kb):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb))
+    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb), HIPKKT_VERBOSE="1")
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SMALL GRID OK" in r.stdout
+    assert "gave up" not in r.stderr, r.stderr
+    sched = _schedule_line(r.stderr)
+    assert sched["top_tasks"] > sched["top_fronts"] > 0, sched       # (front, slice) tasks: k_top_solve_sliced was selected
+
+
+def test_json_problem_file_drives_the_c_abi(tmp_path):
+    """SURVEY.md section 8 f3: a problem saved in the reference's on-disk format (save_to_file, json.jl:118-156;
+    round trip test/UnitTests/test_json.jl:14-25) is loaded back and driven through the C ABI on the GPU; the
+    solve must match the oracle on the loaded data, and the loaded data must be the data that was saved."""
+    _, HipKKTSolver, _ = _hip()
+    from cuclarabel_amd import jsonio
+    pb = problems.small_mixed(seed=71)
+    path = str(tmp_path / "problem.json")
+    jsonio.save_problem(path, pb.P, pb.q, pb.A, pb.b, pb.cones)
+    P, q, A, b, cones, _ = jsonio.load_problem(path)
+    assert (P != sp.triu(pb.P)).nnz == 0 and (A != pb.A).nnz == 0
+    np.testing.assert_array_equal(q, pb.q)
+    np.testing.assert_array_equal(b, pb.b)
+    assert [(type(c).__name__, c.dim) for c in cones] == [(type(c).__name__, c.dim) for c in pb.cones]
+    ks = HipKKTSolver(P, A, cones)
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    from tests.oracle_bindings import OracleKKT
+    o = OracleKKT(P, A, cones, perm=ks.perm())
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    ks.kktsolver_setrhs(-q, b)                      # the constant right-hand side of kkt_update! (kktsystem.jl:87-88)
+    o.kktsolver_setrhs(-q, b)
+    x, z = np.zeros(pb.n), np.zeros(pb.m)
+    assert ks.kktsolver_solve(x, z)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok
+    scale = max(np.abs(xo).max(), np.abs(zo).max())
+    assert max(np.abs(x - xo).max(), np.abs(z - zo).max()) / scale < 1e-9
