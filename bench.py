@@ -42,15 +42,42 @@ def algorithmic_bytes(info):
     return dict(solve=B_solve, spmv=B_spmv, update=B_upd, factor=B_fact)
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def native_oracle():
+    """Build the oracle -O3 -march=native ON THIS BOX (BASELINE.md section 2's protocol) into a scratch directory and
+    point tests/oracle_bindings at it; falls back to the portable in-tree build if the compiler is missing.
+    Must run before tests.oracle_bindings is first imported.  Returns the build's description."""
+    import subprocess
+    import tempfile
+    if "tests.oracle_bindings" in sys.modules:
+        return "as loaded earlier"
+    out = os.path.join(tempfile.mkdtemp(prefix="kktoracle_"), "libkktoracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", "NATIVE_OUT=" + out])
+        os.environ["KKT_ORACLE_SO"] = out
+        return "gcc -O3 -march=native -ffp-contract=off, built on this host"
+    except (subprocess.CalledProcessError, OSError):
+        so = os.path.join(ROOT, "oracle", "libkktoracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        return "gcc -O3 -ffp-contract=off (portable build; native build failed)"
+
+
 def cpu_baseline(pb, n_units):
     """The oracle (C restatement of the reference's QDLDL path, 1 thread, AMD ordering) timed on
     this box's host: `n_units` IPM-iteration units after one warm-up.  TEST INFRASTRUCTURE used
     only as the reported baseline, never as the thing measured."""
-    import subprocess
     import numpy as np
-    so = os.path.join(ROOT, "oracle", "libkktoracle.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    build = native_oracle()
     from tests.oracle_bindings import make_oracle
     from cuclarabel_amd import _lib
     o0 = make_oracle(pb, perm=np.arange(pb.n + pb.m + 2 * sum(1 for c in pb.cones if c.kind == 2 and c.dim > 4)))
@@ -74,8 +101,9 @@ def cpu_baseline(pb, n_units):
     times = sorted(times[2:])
     med = times[len(times) // 2]
     return dict(value=1.0 / med, unit="KKT factorize+solve/s", cores=1, kind="port",
-                sample=f"{n_units} timed units (+2 warm-ups) of the same workload, median; oracle/libkktoracle.so "
-                       f"(scalar up-looking LDL', AMD ordering, nnzL={o.nnzL}), host threads=1 of {os.cpu_count()}",
+                sample=f"{n_units} timed units (+2 warm-ups) of the same workload, median; oracle/kkt_oracle.c "
+                       f"({build}; scalar up-looking LDL', AMD ordering, nnzL={o.nnzL}), host {host_cpu_model()}, "
+                       f"threads=1 of {os.cpu_count()}",
                 ms_per_unit=med * 1e3)
 
 
@@ -157,6 +185,7 @@ def run_configs(args):
                    ir_rounds_per_unit=prof["ir_iterations"] / args.steps,
                    factor_TFLOPs=info["factor_flops"] / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12)
         if not args.no_cpu_baseline:
+            native_oracle()
             from tests.oracle_bindings import make_oracle           # the cpu_baseline leg: checker and baseline only
             pb, ks, st = pbs[0], sol[0], state[0]
             o0 = make_oracle(pb, perm=np.arange(info["N"]))
@@ -183,15 +212,63 @@ def run_configs(args):
 
 
 
+def spawn_workers(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) through
+    torch.distributed.run, BEFORE this process has touched the GPU or imported torch.  The parent only relays the
+    children's output and exit code; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
+def traffic_summary():
+    """HBM traffic per phase from the separate `rocprofv3 --pmc` passes of this same command
+    (scripts/profile_bench.sh -> profiles/*_traffic_summary.json).  A summary is used only when it says which
+    kernel sources it was measured on and they are the sources of this tree: after any kernel or schedule change
+    the old figure would be silently stale next to freshly measured times."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cuclarabel_amd", "csrc", "*.[ch]*"))):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(open(f, "rb").read())
+    src = h.hexdigest()[:16]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_summary.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("csrc_sha16") == src:
+            return t, os.path.basename(f), src
+    return None, None, src
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=100_000, help="primal dimension of the SOCP (BASELINE: 100000)")
+    ap.add_argument("--mode", default="iter", choices=["iter", "problems", "rhs"],
+                    help="iter (default, the headline): cfg2, one instance per rank, weak scaling.  problems: cfg4's "
+                         "batch of --problems independent SOCPs (n=10k) dealt to the ranks, block-diagonal handles of "
+                         "--per-handle, records gathered over RCCL, strong scaling.  rhs: --nrhs right-hand sides "
+                         "against cfg2's factor dealt to the ranks, one all-gather of the solutions, strong scaling "
+                         "(SURVEY.md section 8e)")
+    ap.add_argument("--n", type=int, default=None, help="primal dimension (default: 100000 for cfg2, 10000 for cfg4)")
+    ap.add_argument("--problems", type=int, default=64)
+    ap.add_argument("--per-handle", type=int, default=8)
+    ap.add_argument("--nrhs", type=int, default=512)
     ap.add_argument("--ordering", default="nd", choices=["nd", "amd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-units", type=int, default=10)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the ranks rendezvous over gloo and exercise the launch / barrier / gather plumbing "
+                         "with an empty step (CPU test of the --gpus N path); the JSON line carries dry_run: true")
     ap.add_argument("--configs", default=None,
                     help="e.g. 1,2,3,4,4b,5: time every listed BASELINE configuration on one GPU (one JSON line each) "
                          "instead of the headline run")
@@ -200,6 +277,8 @@ def main():
     args = ap.parse_args()
     if args.configs:
         return run_configs(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_workers(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -209,66 +288,187 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from cuclarabel_amd import _lib, problems
-    from cuclarabel_amd.kktsolver import HipKKTSolver
-
-    pb = problems.config2(seed=1002 + rank, n=args.n)
-    st = _lib.default_settings(device=local_rank,
-                               ordering=_lib.ORDER_ND if args.ordering == "nd" else _lib.ORDER_AMD)
-    t0 = time.perf_counter()
-    ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
-    setup_s = time.perf_counter() - t0
-    stream = torch.cuda.current_stream(dev)
-    ks.set_stream(stream.cuda_stream)
-
-    rng = np.random.default_rng(0)
-    d_s = torch.from_numpy(pb.s0).to(dev)
-    d_z = torch.from_numpy(pb.z0).to(dev)
-    rhs = [(torch.from_numpy(rng.standard_normal(pb.n)).to(dev), torch.from_numpy(rng.standard_normal(pb.m)).to(dev))
-           for _ in range(3)]
-    lx = torch.zeros(pb.n, dtype=torch.float64, device=dev)
-    lz = torch.zeros(pb.m, dtype=torch.float64, device=dev)
-
-    def step():
-        if not ks.kktsolver_update_from_sz_dev(d_s.data_ptr(), d_z.data_ptr()):
-            raise RuntimeError("factorisation failed")
-        for rx, rz in rhs:
-            ks.kktsolver_setrhs_dev(rx.data_ptr(), rz.data_ptr())
-            if not ks.kktsolver_solve_dev(lx.data_ptr(), lz.data_ptr()):
-                raise RuntimeError("solve failed")
+    from cuclarabel_amd.distributed import assign_problems, gather_columns, gather_records, reduce_max, shard_columns
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
+
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        return reduce_max(time.perf_counter() - t0, device=dev)      # MAX over ranks (RCCL, 8 bytes)
+
+    def make_solver(pb):
+        from cuclarabel_amd.kktsolver import HipKKTSolver
+        st = _lib.default_settings(device=local_rank, ordering=_lib.ORDER_ND if args.ordering == "nd" else _lib.ORDER_AMD)
+        ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
+        ks.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        return ks
+
+    def resident(pb, rng):
+        return dict(s=torch.from_numpy(pb.s0).to(dev), z=torch.from_numpy(pb.z0).to(dev),
+                    rhs=[(torch.from_numpy(rng.standard_normal(pb.n)).to(dev), torch.from_numpy(rng.standard_normal(pb.m)).to(dev))
+                         for _ in range(3)],
+                    lx=torch.zeros(pb.n, dtype=torch.float64, device=dev), lz=torch.zeros(pb.m, dtype=torch.float64, device=dev))
+
+    def unit(ks, st):
+        """one IPM iteration's KKT work: 1 update + refactor, 3 solves with refinement"""
+        if not ks.kktsolver_update_from_sz_dev(st["s"].data_ptr(), st["z"].data_ptr()):
+            raise RuntimeError("factorisation failed")
+        for rx, rz in st["rhs"]:
+            ks.kktsolver_setrhs_dev(rx.data_ptr(), rz.data_ptr())
+            if not ks.kktsolver_solve_dev(st["lx"].data_ptr(), st["lz"].data_ptr()):
+                raise RuntimeError("solve failed")
+
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic"}
+    if dry:
+        base["dry_run"] = True
+
+    # ------------------------------------------------------------------ mode problems (cfg4)
+    if args.mode == "problems":
+        n = args.n or 10_000
+        mine = assign_problems(args.problems, world, rank)            # independent problems: no data-path collective
+        groups = [mine[i:i + args.per_handle] for i in range(0, len(mine), args.per_handle)]
+        handles = []
+        if not dry:
+            rng = np.random.default_rng(0)
+            for g in groups:
+                pb = problems.block_diagonal([problems.config4(j=j, n=n) for j in g])
+                handles.append((make_solver(pb), resident(pb, rng), g))
+
+        def step():
+            for ks, st, _ in handles:
+                unit(ks, st)
+
+        elapsed = timed(step)
+        # per-problem records [index, status, refinement rounds of the last solve, N of its handle]: the one exchange
+        recs = []
+        for gi, g in enumerate(groups):
+            for j in g:
+                recs.append([j, 1.0, float(handles[gi][0].last_ir_iterations) if handles else 0.0,
+                             float(handles[gi][0].info["N"]) if handles else 0.0])
+        table = gather_records(recs, args.problems, 4, device=dev)
+        if rank == 0:
+            assert bool((table[:, 1] == 1.0).all()), "a problem is missing from the gathered records"
+            out = dict(base, metric="KKT factorize+solve/sec (fp64) per IPM iter, batch of %d independent SOCPs n=%d" % (args.problems, n),
+                       value=args.problems * args.steps / elapsed, unit="KKT factorize+solve/s",
+                       ms_per_step=elapsed / args.steps * 1e3, scaling="strong",
+                       config={"workload": "cfg4: %d independent SOCPs n=%d m=%d NN(%d)+%dxSOC(100), dealt round-robin to the ranks, "
+                                           "%d per block-diagonal handle; per problem 1 update + 1 LDL' refactor + 3 solves with IR per step"
+                                           % (args.problems, n, 2 * n, n, n // 100, args.per_handle),
+                               "problems_per_rank": len(mine), "handles_per_rank": len(groups),
+                               "parallelism": "independent problems per GPU, record all-gather over RCCL"})
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------ mode rhs (batched right-hand sides, cfg2's factor)
+    if args.mode == "rhs":
+        n = args.n or 100_000
+        k = args.nrhs
+        mine = shard_columns(k, world, rank)
+        km = len(mine)
+        pn = n if not dry else 64
+        if not dry:
+            pb = problems.config2(seed=1002, n=n)                     # the same K on every rank: the factor is replicated
+            ks = make_solver(pb)
+            if not ks.kktsolver_update_from_sz(pb.s0, pb.z0):
+                raise RuntimeError("factorisation failed")
+            g = torch.Generator(device="cpu").manual_seed(7)
+            RX = torch.randn(k, pb.n, dtype=torch.float64, generator=g)[mine].to(dev)       # row j = column j (contiguous)
+            RZ = torch.randn(k, pb.m, dtype=torch.float64, generator=g)[mine].to(dev)
+            LZ = torch.zeros(max(km, 1), pb.m, dtype=torch.float64, device=dev)
+        LX = torch.zeros(max(km, 1), pn, dtype=torch.float64, device=dev)
+        rounds = [0]
+
+        def step():
+            if km and not dry:
+                ok, ir = ks.kktsolver_solve_multi_dev(km, RX.data_ptr(), RZ.data_ptr(), LX.data_ptr(), LZ.data_ptr())
+                if not ok:
+                    raise RuntimeError("solve failed")
+                rounds[0] += int(ir.sum())
+            if world > 1:
+                gather_columns(LX, k)                                  # RCCL all-gather: the one exchange of this mode
+
+        elapsed = timed(step)
+        if rank == 0:
+            out = dict(base, metric="KKT solves/sec (fp64, with refinement) against one factorisation, %d right-hand sides" % k,
+                       value=k * args.steps / elapsed, unit="KKT solves/s", ms_per_step=elapsed / args.steps * 1e3,
+                       scaling="strong",
+                       config={"workload": "cfg2's factor (n=%d) replicated per rank; %d right-hand sides dealt round-robin, "
+                                           "hipkkt_kkt_solve_multi_dev on each share, solutions all-gathered" % (n, k),
+                               "columns_per_rank": km, "parallelism": "RHS columns per GPU, one all-gather over RCCL"})
+            if not dry:
+                info = ks.info
+                sweeps = 1.0 + rounds[0] / max(km * (args.steps + args.warmup), 1)
+                B = 2 * info["nnzL"] * 12 + km * 6 * info["N"] * 8         # SURVEY.md 8(d): B_solve(k)
+                gbs = B * sweeps / (elapsed / args.steps) / 1e9
+                out["roofline"] = dict(kernel="multi-column tri-solve", bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                                       frac=gbs / HBM_PEAK_GBS, traffic=None,
+                                       note="B_solve(k) = 2 nnz(L) 12 + k 6 N 8 per sweep pair, k = %d columns on this rank, "
+                                            "%.2f sweep pairs per column incl. refinement; whole call timed" % (km, sweeps))
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------ mode iter (the headline)
+    n = args.n or 100_000
+    if dry:
+        elapsed = timed(lambda: None)
+        if rank == 0:
+            print(json.dumps(dict(base, metric="KKT factorize+solve/sec (fp64) per IPM iter, 100k-var SOCP",
+                                  value=world * args.steps / max(elapsed, 1e-9), unit="KKT factorize+solve/s",
+                                  ms_per_step=elapsed / args.steps * 1e3, scaling="weak",
+                                  config={"workload": "dry run (no GPU work)"})), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    pb = problems.config2(seed=1002 + rank, n=n)
+    t0 = time.perf_counter()
+    ks = make_solver(pb)
+    setup_s = time.perf_counter() - t0
+    st = resident(pb, np.random.default_rng(0))
 
     for _ in range(args.warmup):
-        step()
+        unit(ks, st)
     ks.profile_enable(True)
     ks.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        unit(ks, st)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = reduce_max(time.perf_counter() - t0, device=dev)
     prof = ks.profile()
     ks.profile_enable(False)
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # RCCL, 8 bytes
-        elapsed = float(t.item())
 
     if rank == 0:
         info = ks.info
@@ -287,17 +487,9 @@ def main():
         phases["factor"]["flops"] = info["factor_flops"]
         phases["factor"]["achieved_TFLOPs"] = info["factor_flops"] / (phases["factor"]["avg_ms"] * 1e-3) / 1e12
         phases["factor"]["frac_fp64_mfma_peak"] = phases["factor"]["achieved_TFLOPs"] / FP64_MFMA_PEAK_TF
-        # HBM traffic per launch of a phase from the committed PMC passes of this same command
-        # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs: scripts/profile_bench.sh -> profiles/)
-        import glob
-        summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_summary.json")))
-        tsum, traffic_src = None, None
-        if summaries and pb.n == 100_000:
-            try:
-                tsum = json.load(open(summaries[-1]))
-                traffic_src = os.path.basename(summaries[-1])
-            except Exception:
-                tsum = None
+        tsum, traffic_src, src_hash = (None, None, None)
+        if pb.n == 100_000:
+            tsum, traffic_src, src_hash = traffic_summary()
 
         def roofline_of(phase):
             d = phases[phase]
@@ -313,19 +505,31 @@ def main():
                          frac=d["frac_fp64_mfma_peak"])
             r["note"] = ("phase = all kernel launches of one %s (a dependency chain over the elimination-tree levels, "
                          "so latency- rather than roofline-bound); algorithmic bytes/flops per SURVEY.md 8(d); "
-                         "traffic = FETCH_SIZE+WRITE_SIZE bytes per launch of the phase" % phase)
+                         "traffic = FETCH_SIZE+WRITE_SIZE bytes per launch of the phase from the committed PMC passes "
+                         "measured on these kernel sources (null: no summary for csrc hash %s)" % (phase, src_hash))
             return r
 
         dominant = max(("factor", "trisolve"), key=lambda k: phases[k]["total_ms"])
         roofline = roofline_of(dominant)
-        out = {
+        rt = roofline_of("trisolve")
+        # the same time against the reference ordering's fill (AMD: what QDLDL would hold) -- the ND ordering's extra
+        # fill is this build's own choice (tree height), so the fraction is quoted both ways
+        if args.ordering == "nd" and pb.n == 100_000:
+            try:
+                _, amd = _lib.symbolic_analyse(ks.KKT(), ordering=_lib.ORDER_AMD)
+                b_amd = 2 * amd["nnzL"] * 12 + 2 * (info["N"] + 1) * 4 + 6 * info["N"] * 8
+                rt["frac_vs_amd_fill"] = b_amd / (phases["trisolve"]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                rt["nnzL_amd"] = amd["nnzL"]
+            except Exception as e:                                       # diagnostic only
+                rt["frac_vs_amd_fill"] = None
+                rt["amd_note"] = str(e)
+        phase_sum = sum(phases[k]["total_ms"] for k in phases) / max(args.steps, 1)
+        out = dict(base, **{
             "metric": "KKT factorize+solve/sec (fp64) per IPM iter, 100k-var SOCP",
             "value": world * args.steps / elapsed,
             "unit": "KKT factorize+solve/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "scaling": "weak",
             "config": {"workload": "cfg2: random sparse SOCP n=%d m=%d NN(%d)+%dxSOC(100), P=diag, A 4 nnz/row local "
                                    "window; 1 update + 1 LDL' refactor + 3 solves with IR per step" %
                                    (pb.n, pb.m, pb.n, pb.n // 100),
@@ -334,11 +538,13 @@ def main():
                        "nsuper": info["nsuper"], "levels": info["nlevels"], "max_front": info["max_front"],
                        "factor_flops": info["factor_flops"], "ordering": args.ordering,
                        "ir_rounds_per_step": prof["ir_iterations"] / max(args.steps, 1),
-                       "setup_s": setup_s, "parallelism": "independent problems per GPU"},
+                       "setup_s": setup_s, "parallelism": "independent problems per GPU",
+                       "csrc_sha16": traffic_summary()[2]},
             "roofline": roofline,
-            "roofline_trisolve": roofline_of("trisolve"),      # the north-star's named roofline target
+            "roofline_trisolve": rt,      # the north-star's named roofline target
             "phases": phases,
-        }
+            "ms_per_step_outside_phases": elapsed / args.steps * 1e3 - phase_sum,
+        })
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pb, args.cpu_units)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

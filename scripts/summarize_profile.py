@@ -37,7 +37,7 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as out:
 bench = json.loads(open(os.path.join(src, "bench.json")).read())
 steps = bench["steps"] + bench["warmup"]
 TRI = ("k_fwd", "k_bwd", "k_top_solve")
-FAC = ("k_panel", "k_schur", "k_front_wave", "k_tinv", "k_winv")
+FAC = ("k_panel", "k_schur", "k_front", "k_subtree", "k_tinv", "k_winv")
 
 
 def total(prefixes, key):
@@ -61,7 +61,7 @@ tri_raw = (total(TRI, "fetch_kb") + total(TRI, "write_kb")) / ntri / 1024.0
 fac_raw = (total(FAC, "fetch_kb") + total(FAC, "write_kb")) / steps / 1024.0
 tri = (fetch_scale * total(TRI, "fetch_kb") + total(TRI, "write_kb")) / ntri / 1024.0
 fac = (fetch_scale * total(FAC, "fetch_kb") + total(FAC, "write_kb")) / steps / 1024.0
-summary = dict(tag=tag, steps_profiled=steps,
+summary = dict(tag=tag, steps_profiled=steps, csrc_sha16=bench["config"].get("csrc_sha16"),
                trisolve_hbm_MB_per_solve=tri, factor_hbm_MB_per_factorisation=fac,
                trisolve_hbm_MB_per_solve_uncorrected=tri_raw, factor_hbm_MB_per_factorisation_uncorrected=fac_raw,
                fetch_size_scale=fetch_scale, calibration=calib,

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(os.path.dirname(_HERE), "oracle", "libkktoracle.so")
+# KKT_ORACLE_SO: bench.py's cpu_baseline points this at the -march=native build it makes on the box it runs on
+_SO = os.environ.get("KKT_ORACLE_SO") or os.path.join(os.path.dirname(_HERE), "oracle", "libkktoracle.so")
 
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
