@@ -106,6 +106,7 @@ SYMBOLS = {
     "hipkkt_kkt_get_maps": (C.c_int, [_P] * 9),
     "hipkkt_kkt_get_perm": (C.c_int, [_P, _P]),
     "hipkkt_kkt_get_Hs": (C.c_int, [_P, _P]),
+    "hipkkt_kkt_get_scaling": (C.c_int, [_P, _P, _P, _P]),
     "hipkkt_kkt_last_regularizer": (C.c_double, [_P]),
     "hipkkt_kkt_last_ir_iterations": (C.c_int64, [_P]),
     "hipkkt_kkt_set_stream": (C.c_int, [_P, _P]),

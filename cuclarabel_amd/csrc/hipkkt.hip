@@ -1154,7 +1154,7 @@ struct hipkkt_kkt_s {
     int nsoc = 0, npsd = 0, psd_kmax = 1;
     DBuf<int> c_psdlist, c_psddim;
     DBuf<int64_t> c_psdaoff;
-    DBuf<double> psdA;
+    DBuf<double> psdA, psdR, psdRinv;
     bool has_psd = false, psd_too_big = false, scaling_valid = false;
     double last_eps = 0;
     int64_t last_ir = 0;
@@ -1184,7 +1184,7 @@ struct hipkkt_kkt_s {
     {
         ConeState S;
         S.w = w.p; S.eta = eta.p; S.u = soc_u.p; S.v = soc_v.p; S.eta2 = soc_eta2.p; S.Hs = Hs.p; S.fail = fail.p;
-        S.psdA = psdA.p;
+        S.psdA = psdA.p; S.psdR = psdR.p; S.psdRinv = psdRinv.p;
         S.lam = lam.p;
         return S;
     }
@@ -1587,7 +1587,7 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
                 }
                 h->npsd = (int)plist.size();
                 h->c_psdlist.upload(plist); h->c_psddim.upload(pdim); h->c_psdaoff.upload(paoff);
-                h->psdA.alloc((size_t)ao);
+                h->psdA.alloc((size_t)ao); h->psdR.alloc((size_t)ao); h->psdRinv.alloc((size_t)ao);
             }
             h->c_kind.upload(kind); h->c_off.upload(off); h->c_numel.upload(numel); h->c_boff.upload(boff);
             h->c_sidx.upload(sidx); h->c_soff.upload(soff); h->c_elem.upload(elem); h->c_soclist.upload(soclist);
@@ -2281,7 +2281,7 @@ int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, do
         const bool affine = steptype == 0;
         if (!launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, affine ? d_var_s : d_rhs_s,
                                d_var_z, d_rhs_z, m, affine, st))
-            throw ArgError("hipkkt_kkt_system_solve: the combined step covers zero, nonnegative and second-order cones");
+            throw ArgError("hipkkt_kkt_system_solve: unsupported cone kind");
         // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
         int rc = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
         if (rc != HIPKKT_OK) return rc;
@@ -2492,6 +2492,20 @@ int hipkkt_kkt_get_Hs(hipkkt_kkt_t h, double* Hs)
         if (!h || (h->K.nHs && !Hs)) throw ArgError("hipkkt_kkt_get_Hs: bad argument");
         HIP_CHECK(hipSetDevice(h->device));
         if (h->K.nHs) HIP_CHECK(hipMemcpyAsync(Hs, h->Hs.p, (size_t)h->K.nHs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_get_scaling(hipkkt_kkt_t h, double* lambda, double* psd_R, double* psd_Rinv)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        if (!h->scaling_valid) throw ArgError("hipkkt_kkt_get_scaling needs a device-side scaling (hipkkt_kkt_update_from_sz)");
+        HIP_CHECK(hipSetDevice(h->device));
+        if (lambda && h->K.m) HIP_CHECK(hipMemcpyAsync(lambda, h->lam.p, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (psd_R && h->psdR.n) HIP_CHECK(hipMemcpyAsync(psd_R, h->psdR.p, h->psdR.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (psd_Rinv && h->psdRinv.n) HIP_CHECK(hipMemcpyAsync(psd_Rinv, h->psdRinv.p, h->psdRinv.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return HIPKKT_OK;
     });

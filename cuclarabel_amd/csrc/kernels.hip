@@ -495,11 +495,16 @@ __global__ __launch_bounds__(64) void k_cone_soc(ConeDev C, ConeState S, const d
 // -------------------------------------------------------------------------------------
 //  PSD cones (coneops_psdtrianglecone.jl:78-161): one workgroup per cone, everything in LDS.
 //    S, Z from svec;  L1 = chol(S), L2 = chol(Z)  (failure => not interior);
-//    the reference takes the SVD of L2'L1 = U Lam V' and sets R = L1 V Lam^{-1/2}; only
-//    A = R R' = L1 V Lam^{-1} V' L1' enters Hs, and V Lam^2 V' = (L2'L1)'(L2'L1) = L1' Z L1 =: G, so
-//    A = L1 G^{-1/2} L1' with G^{-1/2} from a cyclic Jacobi eigen-decomposition of G (k <= 48).
-//    Hs = A (x)_s A (skron!, :502-540) is written straight into its packed upper triangle by a
-//    flat map over the t(t+1)/2 entries, t = k(k+1)/2.
+//    SVD of M = L2' L1 = U Lam V'  -- as the reference does (:118-121), NOT an eigen-decomposition of
+//    L1' Z L1 = M'M, whose eigenvalues are the squares of the singular values: forming it squares the condition
+//    number, and on late interior-point iterates (S, Z nearly complementary) the small singular values drop below
+//    eps ||M'M||.  The SVD is a one-sided (Hestenes) Jacobi on the columns of M, which computes every singular
+//    value to high RELATIVE accuracy; rotations in the round-robin order (a sweep is m - 1 steps of m/2 rotations
+//    on disjoint column pairs, eight lanes per pair, one barrier per step).
+//    lam = singular values sorted descending (LAPACK's order, dense_algebra.jl:219);
+//    R = L1 V Lam^{-1/2}, Rinv = Lam^{-1/2} U' L2' (:127-132); A = R R' (:135-141);
+//    Hs = A (x)_s A (skron!, :502-540) written straight into its packed upper triangle by a flat map over the
+//    t(t+1)/2 entries, t = k(k+1)/2.
 // -------------------------------------------------------------------------------------
 __device__ inline void svec_index(int idx, int& row, int& col)     // idx = col(col+1)/2 + row, row <= col
 {
@@ -515,15 +520,17 @@ __global__ __launch_bounds__(256) void k_cone_psd(ConeDev C, ConeState S, const 
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int sh_fail;
+    __shared__ double sh_off[32], sh_sv[kPsdMaxDim];
+    __shared__ int sh_rank[kPsdMaxDim];
     const int tid = threadIdx.x;
     const int c = C.psd_list[blockIdx.x];
     const int k = C.psd_dim[c], off = C.off[c];
     const int kk = k * k, t = k * (k + 1) / 2;
     double* Sm = smem;            // S -> L1 (lower)
-    double* Zm = smem + kk;       // Z
-    double* G = smem + 2 * kk;    // L1' Z L1 -> eigen work
-    double* V = smem + 3 * kk;    // eigenvectors
-    double* Tm = smem + 4 * kk;   // temporaries
+    double* Zm = smem + kk;       // Z -> L2 (lower)
+    double* M = smem + 2 * kk;    // L2' L1 -> U diag(sv) -> U
+    double* V = smem + 3 * kk;    // right singular vectors
+    double* Tm = smem + 4 * kk;   // R
     double* Am = smem + 5 * kk;   // A = R R'
     const double is2 = 0.70710678118654752440;
     if (tid == 0) sh_fail = 0;
@@ -538,128 +545,130 @@ __global__ __launch_bounds__(256) void k_cone_psd(ConeDev C, ConeState S, const 
         }
     }
     __syncthreads();
-    // Cholesky of S (in place -> L1) and a PD check of Z (its factor is not needed afterwards), right-looking
+    // Cholesky of S and of Z, in place, right-looking (:97-104)
     for (int pass = 0; pass < 2; ++pass) {
-        double* M = pass == 0 ? Sm : Tm;
-        if (pass == 1) { for (int i = tid; i < kk; i += 256) Tm[i] = Zm[i]; __syncthreads(); }
+        double* Mx = pass == 0 ? Sm : Zm;
         for (int j = 0; j < k; ++j) {
-            const double d = M[j + j * k];
+            const double d = Mx[j + j * k];
             if (!(d > 0.0)) { if (tid == 0) sh_fail = 1; }
             __syncthreads();
             if (sh_fail) break;
             const double sd = sqrt(d);
-            for (int i = j + 1 + tid; i < k; i += 256) M[i + j * k] /= sd;
-            if (tid == 0) M[j + j * k] = sd;
+            for (int i = j + 1 + tid; i < k; i += 256) Mx[i + j * k] /= sd;
+            if (tid == 0) Mx[j + j * k] = sd;
             __syncthreads();
             for (int idx = tid; idx < (k - j - 1) * (k - j - 1); idx += 256) {
                 const int a = j + 1 + idx / (k - j - 1), b = j + 1 + idx % (k - j - 1);
-                if (a >= b) M[a + b * k] -= M[a + j * k] * M[b + j * k];
+                if (a >= b) Mx[a + b * k] -= Mx[a + j * k] * Mx[b + j * k];
             }
             __syncthreads();
         }
         if (sh_fail) break;
     }
     if (sh_fail) { if (tid == 0) *S.fail = 1; return; }
-    for (int idx = tid; idx < kk; idx += 256) { const int r = idx % k, cl = idx / k; if (r < cl) Sm[idx] = 0.0; }
-    __syncthreads();
-    // G = L1' Z L1
-    for (int idx = tid; idx < kk; idx += 256) {          // Tm = Z L1
+    for (int idx = tid; idx < kk; idx += 256) {
         const int r = idx % k, cl = idx / k;
-        double acc = 0.0;
-        for (int q = cl; q < k; ++q) acc = fma(Zm[r + q * k], Sm[q + cl * k], acc);
-        Tm[idx] = acc;
+        if (r < cl) { Sm[idx] = 0.0; Zm[idx] = 0.0; }
     }
     __syncthreads();
+    // M = L2' L1 (:113-114), V = I
     for (int idx = tid; idx < kk; idx += 256) {
         const int r = idx % k, cl = idx / k;
         double acc = 0.0;
-        for (int q = r; q < k; ++q) acc = fma(Sm[q + r * k], Tm[q + cl * k], acc);
-        G[idx] = acc;
+        for (int q = (r > cl ? r : cl); q < k; ++q) acc = fma(Zm[q + r * k], Sm[q + cl * k], acc);
+        M[idx] = acc;
         V[idx] = (r == cl) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // Jacobi eigen-decomposition of G (symmetric) with the ROUND-ROBIN ordering: a sweep is m - 1 steps of m/2
-    // rotations on disjoint index pairs (the circle method; m = k rounded up to even, pairs with the dummy index skipped).
-    // Disjoint rotations commute, so a step's rotations are computed by m/2 threads at once and applied by the whole
-    // workgroup: three barriers per STEP instead of per rotation -- 10x fewer dependent rounds than the cyclic order
-    // for k = 20 (the kernel was 1 ms of cfg5's 18 ms unit).  G^{-1/2} is unique, so the result does not depend on
-    // the order beyond rounding.
-    __shared__ double sh_cs[24], sh_sn[24], sh_off[24];
-    __shared__ int sh_p[24], sh_q[24];
-    const int m = (k + 1) & ~1, npair = m / 2;
-    for (int sweep = 0; sweep < 30; ++sweep) {
+    // one-sided Jacobi: rotate column pairs (p, q) of M (and of V) until all columns are mutually orthogonal
+    const int m = (k + 1) & ~1, npair = m / 2;          // k <= 48: at most 24 pairs, eight lanes each
+    const int grp = tid >> 3, sub = tid & 7;
+    for (int sweep = 0; sweep < 60; ++sweep) {
         double myoff = 0.0;
         for (int step = 0; step < m - 1; ++step) {
-            if (tid < npair) {
+            if (grp < npair) {
                 int p, q;
-                if (tid == 0) { p = m - 1; q = step; }
-                else { p = (step + tid) % (m - 1); q = (step - tid + (m - 1)) % (m - 1); }
+                if (grp == 0) { p = m - 1; q = step; }
+                else { p = (step + grp) % (m - 1); q = (step - grp + (m - 1)) % (m - 1); }
                 if (p > q) { const int tmp = p; p = q; q = tmp; }
-                double cs = 1.0, sn = 0.0;
-                if (q < k) {                                           // (q == k: the dummy of an odd k)
-                    const double apq = G[p + q * k];
-                    const double app = G[p + p * k], aqq = G[q + q * k];
-                    const double scale = sqrt(fabs(app * aqq));
-                    if (fabs(apq) > 1e-17 * scale) {
-                        myoff = fmax(myoff, fabs(apq) / (scale > 0 ? scale : 1.0));
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
-                        cs = 1.0 / sqrt(1.0 + tt * tt);
-                        sn = cs * tt;
+                if (q < k) {                                           // (q == k: the dummy index of an odd k)
+                    double a = 0.0, b = 0.0, cc = 0.0;
+                    for (int i = sub; i < k; i += 8) {
+                        const double mp = M[i + p * k], mq = M[i + q * k];
+                        a = fma(mp, mp, a); b = fma(mq, mq, b); cc = fma(mp, mq, cc);
                     }
-                } else {
-                    q = p;                                             // identity on a single index
+#pragma unroll
+                    for (int o = 4; o > 0; o >>= 1) {
+                        a += __shfl_xor(a, o, 8); b += __shfl_xor(b, o, 8); cc += __shfl_xor(cc, o, 8);
+                    }
+                    const double ab = sqrt(a * b);
+                    if (!(fabs(cc) <= 1e-300 || fabs(cc) <= 1e-17 * ab)) {
+                        myoff = fmax(myoff, fabs(cc) / ab);
+                        const double zeta = (b - a) / (2.0 * cc);
+                        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                        for (int i = sub; i < k; i += 8) {
+                            const double mp = M[i + p * k], mq = M[i + q * k];
+                            M[i + p * k] = cs * mp - sn * mq;
+                            M[i + q * k] = sn * mp + cs * mq;
+                            const double vp = V[i + p * k], vq = V[i + q * k];
+                            V[i + p * k] = cs * vp - sn * vq;
+                            V[i + q * k] = sn * vp + cs * vq;
+                        }
+                    }
                 }
-                sh_p[tid] = p; sh_q[tid] = q; sh_cs[tid] = cs; sh_sn[tid] = sn;
             }
-            __syncthreads();
-            for (int idx = tid; idx < npair * k; idx += 256) {         // columns p, q of G and V, every pair at once
-                const int pr = idx / k, i = idx - pr * k;
-                const int p = sh_p[pr], q = sh_q[pr];
-                if (p == q) continue;
-                const double cs = sh_cs[pr], sn = sh_sn[pr];
-                const double gp = G[i + p * k], gq = G[i + q * k];
-                G[i + p * k] = cs * gp - sn * gq;
-                G[i + q * k] = sn * gp + cs * gq;
-                const double vp = V[i + p * k], vq = V[i + q * k];
-                V[i + p * k] = cs * vp - sn * vq;
-                V[i + q * k] = sn * vp + cs * vq;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < npair * k; idx += 256) {         // rows p, q of G
-                const int pr = idx / k, i = idx - pr * k;
-                const int p = sh_p[pr], q = sh_q[pr];
-                if (p == q) continue;
-                const double cs = sh_cs[pr], sn = sh_sn[pr];
-                const double gp = G[p + i * k], gq = G[q + i * k];
-                G[p + i * k] = cs * gp - sn * gq;
-                G[q + i * k] = sn * gp + cs * gq;
-            }
-            __syncthreads();
+            __syncthreads();               // the next step pairs the columns differently
         }
-        if (tid < npair) sh_off[tid] = myoff;
+        if (sub == 0 && grp < 32) sh_off[grp] = grp < npair ? myoff : 0.0;
         __syncthreads();
         double offn = 0.0;
         for (int i = 0; i < npair; ++i) offn = fmax(offn, sh_off[i]);   // uniform: every thread reads the same words
         __syncthreads();
         if (offn < 1e-15) break;
     }
-    // B = L1 V diag(g^{-1/4});  A = B B'
+    // singular values = column norms; U = M with unit columns; descending order like LAPACK's
+    if (tid < k) {
+        double nrm = 0.0;
+        for (int i = 0; i < k; ++i) nrm = fma(M[i + tid * k], M[i + tid * k], nrm);
+        sh_sv[tid] = sqrt(nrm);
+    }
+    __syncthreads();
+    if (tid < k) {
+        const double mine = sh_sv[tid];
+        int rank = 0;
+        for (int i = 0; i < k; ++i) rank += (sh_sv[i] > mine || (sh_sv[i] == mine && i < tid)) ? 1 : 0;
+        sh_rank[tid] = rank;
+        if (S.lam) S.lam[off + rank] = mine;                   // lam occupies the first k of the cone's t slots
+    }
+    if (S.lam) for (int i = k + tid; i < t; i += 256) S.lam[off + i] = 0.0;
+    __syncthreads();
+    // R = L1 V Lam^{-1/2} (columns in sorted order), Rinv = Lam^{-1/2} U' L2' (rows in sorted order)
+    double* Rout = S.psdR + C.psd_aoff[c];
+    double* Riout = S.psdRinv + C.psd_aoff[c];
     for (int idx = tid; idx < kk; idx += 256) {
         const int r = idx % k, cl = idx / k;
         double acc = 0.0;
         for (int q = 0; q <= r; ++q) acc = fma(Sm[r + q * k], V[q + cl * k], acc);
-        const double g = G[cl + cl * k];
-        Tm[idx] = acc / sqrt(sqrt(g));
+        const double sc = 1.0 / sqrt(sh_sv[cl]);
+        const double v = acc * sc;
+        Tm[r + sh_rank[cl] * k] = v;
+        Rout[r + sh_rank[cl] * k] = v;
+        // Rinv(row cl of the unsorted order, column r): (1/sqrt(s_cl)) (1/s_cl) sum_q M(q, cl) L2(r, q)
+        double acc2 = 0.0;
+        for (int q = 0; q <= r; ++q) acc2 = fma(M[q + cl * k], Zm[r + q * k], acc2);
+        Riout[sh_rank[cl] + r * k] = acc2 * sc / sh_sv[cl];
     }
     __syncthreads();
     double* Aout = S.psdA + C.psd_aoff[c];
     for (int idx = tid; idx < kk; idx += 256) {
         const int r = idx % k, cl = idx / k;
         double acc = 0.0;
-        for (int q = 0; q < k; ++q) acc = fma(Tm[r + q * k], Tm[cl + q * k], acc);
-        Am[idx] = acc;
-        Aout[idx] = acc;
+        if (r <= cl) {                                           // upper triangle (syrk 'U'), mirrored: exactly symmetric
+            for (int q = 0; q < k; ++q) acc = fma(Tm[r + q * k], Tm[cl + q * k], acc);
+            Am[r + cl * k] = acc; Am[cl + r * k] = acc;
+            Aout[r + cl * k] = acc; Aout[cl + r * k] = acc;
+        }
     }
     __syncthreads();
     // Hs = A (x)_s A, packed upper triangle (column-major over (row, col) with row <= col)
@@ -787,7 +796,7 @@ __global__ void k_sys_offset_elementwise(ConeDev C, ConeState S, double* __restr
             const int kind = C.kind[C.elem_cone[i]];
             if (kind == 0) o = 0.0;                     // coneops_zerocone.jl:137-150
             else if (kind == 1) o = ds[i] / z[i];       // coneops_nncone.jl:140-148
-            else continue;                              // second-order cones: k_sys_offset_soc
+            else continue;                              // second-order / PSD cones: k_sys_offset_soc / k_sys_offset_psd
         }
         konst[i] = o;
         workz[i] = o - rhs_z[i];
@@ -831,11 +840,60 @@ __global__ __launch_bounds__(64) void k_sys_offset_soc(ConeDev C, ConeState S, d
     }
 }
 
+// out = W'(lambda \ ds) for a PSD cone (_Delta_s_from_Delta_z_offset_symmetric!, coneops_symmetric_common.jl:39-52):
+// X = mat(ds); X(i, j) <- 2 X(i, j) / (lam_i + lam_j) (lambda_inv_circ_op!, coneops_psdtrianglecone.jl:335-353);
+// out = svec(R X R') (mul_W! with :T, :409-437).  One workgroup per cone.
+__global__ __launch_bounds__(256) void k_sys_offset_psd(ConeDev C, ConeState S, double* __restrict__ konst,
+                                                       double* __restrict__ workz, const double* __restrict__ ds,
+                                                       const double* __restrict__ rhs_z)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int c = C.psd_list[blockIdx.x];
+    const int k = C.psd_dim[c], off = C.off[c], kk = k * k, t = k * (k + 1) / 2;
+    double* X = smem;
+    double* Rm = smem + kk;
+    double* Tm = smem + 2 * kk;
+    const double is2 = 0.70710678118654752440;
+    const double* R = S.psdR + C.psd_aoff[c];
+    const double* lam = S.lam + off;
+    for (int idx = tid; idx < kk; idx += 256) Rm[idx] = R[idx];
+    for (int idx = tid; idx < t; idx += 256) {
+        int r, cl;
+        svec_index(idx, r, cl);
+        const double v = ds[off + idx] * (r == cl ? 1.0 : is2) * 2.0 / (lam[r] + lam[cl]);
+        X[r + cl * k] = v;
+        X[cl + r * k] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kk; idx += 256) {          // Tm = X R'
+        const int r = idx % k, cl = idx / k;
+        double acc = 0.0;
+        for (int q = 0; q < k; ++q) acc = fma(X[r + q * k], Rm[cl + q * k], acc);
+        Tm[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < t; idx += 256) {           // Y = R Tm, svec
+        int r, cl;
+        svec_index(idx, r, cl);
+        double a1 = 0.0, a2 = 0.0;
+        for (int q = 0; q < k; ++q) { a1 = fma(Rm[r + q * k], Tm[q + cl * k], a1); a2 = fma(Rm[cl + q * k], Tm[q + r * k], a2); }
+        const double o = (r == cl) ? a1 : (a1 + a2) * is2;
+        konst[off + idx] = o;
+        workz[off + idx] = o - rhs_z[off + idx];
+    }
+}
+
 bool launch_sys_offset(const ConeDev& C, const ConeState& S, double* konst, double* workz, const double* ds,
                        const double* z, const double* rhs_z, int m, bool affine, hipStream_t st)
 {
     if (m <= 0) return true;
-    if (!affine && C.npsd > 0) return false;
+    if (!affine && C.npsd > 0) {
+        static PerDeviceOnce once;
+        once.run([]() { return set_max_lds(k_sys_offset_psd, 150 * 1024); });
+        const size_t lds = (size_t)3 * C.psd_kmax * C.psd_kmax * sizeof(double);
+        hipLaunchKernelGGL(k_sys_offset_psd, dim3(C.npsd), dim3(256), lds, st, C, S, konst, workz, ds, rhs_z);
+    }
     hipLaunchKernelGGL(k_sys_offset_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, konst, workz, ds, z,
                        rhs_z, m, affine ? 1 : 0);
     if (!affine && C.nsoc > 0)

@@ -310,6 +310,8 @@ struct ConeState {
     double* eta2;                // nsparse
     double* Hs;                  // |Hs| positive blocks
     double* psdA;                // per PSD cone: A = R R' (k x k col-major), Hs = A (x)_s A
+    double* psdR;                // per PSD cone: R = L1 V Lam^{-1/2} and Rinv = Lam^{-1/2} U' L2' (k x k col-major, same
+    double* psdRinv;             //   offsets as psdA); the singular values Lam go to lam[off .. off + k), descending
     int* fail;                   // set to 1 when a point is not interior
 };
 constexpr int kPsdMaxDim = 48;   // largest PSD side handled by the in-LDS scaling kernel
@@ -319,8 +321,8 @@ void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double
 
 // ---- the reduced-system algebra around the three solves of an IPM iteration (kktsystem.jl:135-215), device-resident
 // konst = Delta_s_from_Delta_z_offset!(cones, ds, z) (coneops_compositecone.jl:185-202; zero :137-150, nonnegative
-// coneops_nncone.jl:140-148, second-order coneops_socone.jl:241-268), or a copy of s for the affine step;
-// workz = konst - rhs_z.  Returns false if the cone list holds a cone kind this routine does not cover (PSD).
+// coneops_nncone.jl:140-148, second-order coneops_socone.jl:241-268, PSD coneops_psdtrianglecone.jl:218-228), or a
+// copy of s for the affine step; workz = konst - rhs_z.  Returns false if the cone list holds a kind it does not cover.
 bool launch_sys_offset(const ConeDev& C, const ConeState& S, double* konst, double* workz, const double* ds,
                        const double* z, const double* rhs_z, int m, bool affine, hipStream_t st);
 // y = Symmetric(P) x for the leading n x n block of K (rows / columns < n of the full-CSR image)

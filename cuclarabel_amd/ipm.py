@@ -1,7 +1,7 @@
 """Interior-point test driver over the KKT-solver boundary.
 
 A host-side (numpy) restatement of the reference's IPM loop for Zero / Nonnegative /
-SecondOrder cones, without presolve, equilibration or chordal decomposition:
+SecondOrder / PSDTriangle cones, without presolve, equilibration or chordal decomposition:
 
     solve!                          /root/reference/src/solver.jl:189-380
     default start                   solver.jl:383-404, kktsystem.jl:95-132, variables.jl:196-237
@@ -11,6 +11,8 @@ SecondOrder cones, without presolve, equilibration or chordal decomposition:
     rhs construction                variables.jl:107-190
     step lengths                    variables.jl:13-45, coneops_nncone.jl:151-170, coneops_socone.jl:443-512
     NT scaling, W, lambda           coneops_nncone.jl:77-114, coneops_socone.jl:75-154,302-412
+    PSD cone                        coneops_psdtrianglecone.jl:8-44 (margins, shift), :78-143 (scaling), :164-254,
+                                    :299-466 (mul_Hs!, ds offsets, W / W^-1, Jordan product, step length)
 
 It exists to drive a KKT backend through exactly the call sequence Clarabel uses
 (`kktsolver_update!` -> constant-RHS solve -> affine solve -> combined solve, every iteration)
@@ -254,6 +256,109 @@ class _SOC(_Cone):
         return min(self._step(z, dz, amax), self._step(s, ds, amax))
 
 
+def _svec_to_mat(x, k):                                  # coneops_psdtrianglecone.jl:469-483
+    M = np.zeros((k, k))
+    iu = np.triu_indices(k)
+    # svec runs down the columns of the upper triangle: (row, col) with row <= col, column-major
+    order = np.lexsort((iu[0], iu[1]))
+    r, c = iu[0][order], iu[1][order]
+    v = np.where(r == c, x, x / np.sqrt(2.0))
+    M[r, c] = v
+    M[c, r] = v
+    return M
+
+
+def _mat_to_svec(M):                                     # :486-497
+    k = M.shape[0]
+    iu = np.triu_indices(k)
+    order = np.lexsort((iu[0], iu[1]))
+    r, c = iu[0][order], iu[1][order]
+    return np.where(r == c, M[r, c], (M[r, c] + M[c, r]) / np.sqrt(2.0))
+
+
+class _PSD(_Cone):
+    def __init__(self, spec, off):
+        super().__init__(spec, off)
+        self.k = spec.dim
+        self.diag = np.array([j * (j + 1) // 2 + j for j in range(self.k)], dtype=int)   # triangular_index - 1
+
+    @property
+    def degree(self):
+        return self.k
+
+    def margins(self, z):                                # :8-27
+        if self.n == 0:
+            return np.finfo(float).max, 0.0
+        e = np.linalg.eigvalsh(_svec_to_mat(z, self.k))
+        return float(e.min()), float(e[e > 0].sum())
+
+    def unit_shift(self, z, a, primal):                  # :30-44
+        z[self.diag] += a
+
+    def update_scaling(self, s, z):                      # :78-143
+        if self.n == 0:
+            return True
+        try:
+            L1 = np.linalg.cholesky(_svec_to_mat(s, self.k))
+            L2 = np.linalg.cholesky(_svec_to_mat(z, self.k))
+        except np.linalg.LinAlgError:
+            return False
+        U, sv, Vt = np.linalg.svd(L2.T @ L1)
+        self.lam = sv
+        isq = 1.0 / np.sqrt(sv)
+        self.R = (L1 @ Vt.T) * isq[None, :]
+        self.Rinv = isq[:, None] * (U.T @ L2.T)
+        return True
+
+    def _W(self, x):                                     # mul_W!(:N): R' X R
+        return _mat_to_svec(self.R.T @ _svec_to_mat(x, self.k) @ self.R)
+
+    def _Wt(self, x):                                    # mul_W!(:T): R X R'
+        return _mat_to_svec(self.R @ _svec_to_mat(x, self.k) @ self.R.T)
+
+    def _WinvT(self, x):                                 # mul_Winv!(:T): Rinv X Rinv'
+        return _mat_to_svec(self.Rinv @ _svec_to_mat(x, self.k) @ self.Rinv.T)
+
+    def affine_ds(self, s):                              # :189-204
+        out = np.zeros(self.n)
+        out[self.diag] = self.lam ** 2
+        return out
+
+    def combined_ds_shift(self, dz, ds, sigma_mu):       # coneops_symmetric_common.jl:2-36, circ_op! :361-382
+        Y = _svec_to_mat(self._WinvT(ds), self.k)
+        Z = _svec_to_mat(self._W(dz), self.k)
+        out = _mat_to_svec((Y @ Z + Z @ Y) / 2)
+        out[self.diag] -= sigma_mu
+        return out
+
+    def ds_from_dz_offset(self, ds, z):                  # :218-228, lambda_inv_circ_op! :335-353
+        X = _svec_to_mat(ds, self.k)
+        X = 2.0 * X / (self.lam[:, None] + self.lam[None, :])
+        return self._Wt(_mat_to_svec(X))
+
+    def mul_Hs(self, x):                                 # :164-187
+        return self._Wt(self._W(x))
+
+    def _step_component(self, d, amax):                  # :439-466
+        if self.n == 0:
+            return amax
+        isq = 1.0 / np.sqrt(self.lam)
+        M = _svec_to_mat(d, self.k) * isq[:, None] * isq[None, :]
+        g = float(np.linalg.eigvalsh(M).min())
+        return min(1.0 / -g, amax) if g < 0 else amax
+
+    def step_length(self, dz, ds, z, s, amax):           # :230-254
+        return min(self._step_component(self._W(dz), amax), self._step_component(self._WinvT(ds), amax))
+
+
+def adopt_device_scaling(cones, dev_scaling):
+    """Give the host PSD cone objects the (R, Rinv, lambda) triples `HipKKTSolver.scaling()` returns."""
+    it = iter(dev_scaling)
+    for c in cones:
+        if isinstance(c, _PSD):
+            c.R, c.Rinv, c.lam = next(it)
+
+
 def _make_cones(specs):
     out, off = [], 0
     for c in specs:
@@ -263,8 +368,10 @@ def _make_cones(specs):
             out.append(_NN(c, off))
         elif isinstance(c, SecondOrderConeT):
             out.append(_SOC(c, off))
+        elif isinstance(c, PSDTriangleConeT):
+            out.append(_PSD(c, off))
         else:
-            raise NotImplementedError("the IPM test driver covers Zero, Nonnegative and SecondOrder cones")
+            raise NotImplementedError("the IPM test driver covers Zero, Nonnegative, SecondOrder and PSDTriangle cones")
         off += c.numel
     return out
 
@@ -297,6 +404,12 @@ def identity_scaling_data(specs):
                         blk.append(1.0 if row == col else 0.0)
                 blk[0] = (np.sqrt(2.0) * 1.0 - 1.0) * (np.sqrt(2.0) * 1.0 + 1.0)
                 Hs.append(np.array(blk))
+        elif isinstance(c, PSDTriangleConeT):
+            # Hs = I (coneops_psdtrianglecone.jl:65-75), packed upper triangle of the t x t identity
+            t = c.numel
+            blk = np.zeros(t * (t + 1) // 2)
+            blk[[j * (j + 1) // 2 + j for j in range(t)]] = 1.0
+            Hs.append(blk)
         else:
             raise NotImplementedError
     cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0)
@@ -445,6 +558,11 @@ def solve(P, q, A, b, cone_specs, backend, settings=None):
         it += 1
         if system is not None:
             ok = system.update(s, z)                   # kkt_update!: scaling, refactor, constant-RHS solve
+            # The scaled space of a PSD cone is fixed only up to the signs of the singular vectors of L2'L1.  With the
+            # reduced system on the device, ITS scaling is the one the right-hand sides must be expressed in (in the
+            # reference one cone object serves both sides): adopt the device's R, Rinv, lambda.
+            if ok and any(isinstance(c, _PSD) and c.n for c in cones):
+                adopt_device_scaling(cones, backend.ks.scaling()[1])
         else:
             ok = backend.update(s, z)
             if ok:

@@ -191,6 +191,22 @@ class HipKKTSolver:
         check(_lib.lib().hipkkt_kkt_get_perm(self._h, ptr(out)), "hipkkt_kkt_get_perm")
         return out
 
+    def scaling(self):
+        """The NT scaling on the device: (lambda (m), [(R, Rinv, lam) per PSD cone])."""
+        ks = [c.dim for c in self.cones if c.kind == 3]
+        tot = sum(k * k for k in ks)
+        lam, R, Ri = np.zeros(max(self.m, 1)), np.zeros(max(tot, 1)), np.zeros(max(tot, 1))
+        check(_lib.lib().hipkkt_kkt_get_scaling(self._h, ptr(lam), ptr(R), ptr(Ri)), "hipkkt_kkt_get_scaling")
+        out, o, off = [], 0, 0
+        for c in self.cones:
+            if c.kind == 3:
+                k = c.dim
+                out.append((R[o:o + k * k].reshape(k, k, order="F").copy(), Ri[o:o + k * k].reshape(k, k, order="F").copy(),
+                            lam[off:off + k].copy()))
+                o += k * k
+            off += c.numel
+        return lam[:self.m], out
+
     @property
     def diagonal_regularizer(self):
         return _lib.lib().hipkkt_kkt_last_regularizer(self._h)

@@ -183,8 +183,8 @@ int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double *d_rhs
  * construction (Delta_s_from_Delta_z_offset!, coneops_compositecone.jl:185-202) and the recovery of
  * (dtau, dx, dz, ds, dkappa) (dots, quad_form mathutils.jl:299-337, mul_Hs!) run on the device, so
  * per solve only the scalars cross PCIe.  Vectors named d_* are
- * device pointers: x-like length n, s/z-like length m.  Covers zero, nonnegative and second-order
- * cones (the combined step of a PSD cone returns an argument error). */
+ * device pointers: x-like length n, s/z-like length m.  Covers zero, nonnegative, second-order and PSD
+ * cones (PSD side <= 48, the limit of hipkkt_kkt_update_from_sz). */
 /* DefaultKKTSystem constructor (kktsystem.jl:21-52): q (n), b (m) host vectors, copied */
 int hipkkt_kkt_system_init(hipkkt_kkt_t h, const double *q, const double *b);
 /* kkt_update! (kktsystem.jl:62-78): cone scaling from (s, z), refactor, constant-RHS solve */
@@ -236,6 +236,10 @@ int hipkkt_kkt_get_maps(hipkkt_kkt_t h, int64_t *mapP, int64_t *mapA, int64_t *m
                         int64_t *map_soc_D, int64_t *dsigns);   /* any may be NULL */
 int hipkkt_kkt_get_perm(hipkkt_kkt_t h, int64_t *perm /* N, 0-based */);
 int hipkkt_kkt_get_Hs(hipkkt_kkt_t h, double *Hsblocks /* |Hs|, positive */);
+/* the NT scaling held on the device after hipkkt_kkt_update_from_sz*: the scaled point lambda (length m; a PSD cone
+ * of side k keeps its k singular values, descending, in the first k of its slots), and for the PSD cones R and Rinv
+ * (coneops_psdtrianglecone.jl:127-132), k x k column-major each, concatenated in cone order.  Any may be NULL. */
+int hipkkt_kkt_get_scaling(hipkkt_kkt_t h, double *lambda, double *psd_R, double *psd_Rinv);
 double hipkkt_kkt_last_regularizer(hipkkt_kkt_t h);
 int64_t hipkkt_kkt_last_ir_iterations(hipkkt_kkt_t h);
 

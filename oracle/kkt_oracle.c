@@ -549,6 +549,15 @@ static void jacobi_svd(double *A, double *U, double *s, double *V, I n)
         s[j] = nrm;
         for (q = 0; q < n; q++) U[q + j * n] = nrm > 0 ? A[q + j * n] / nrm : 0.0;
     }
+    /* singular values in descending order, as LAPACK returns them (stable insertion sort of the triplets) */
+    for (j = 1; j < n; j++)
+        for (i = j; i > 0 && s[i] > s[i - 1]; i--) {
+            double tv = s[i]; s[i] = s[i - 1]; s[i - 1] = tv;
+            for (q = 0; q < n; q++) {
+                tv = U[q + i * n]; U[q + i * n] = U[q + (i - 1) * n]; U[q + (i - 1) * n] = tv;
+                tv = V[q + i * n]; V[q + i * n] = V[q + (i - 1) * n]; V[q + (i - 1) * n] = tv;
+            }
+        }
 }
 /* triu(A (x)_s A) for symmetric A, t x t col-major out (coneops_psdtrianglecone.jl:502-540) */
 static void skron(double *out, const double *A, I n)
@@ -789,6 +798,17 @@ void orc_cones_lambda(const orc_kkt *k, double *lam)
         for (i = 0; i < K->numel; i++) l[i] = 0.0;
         if (K->kind == ORC_NN || K->kind == ORC_SOC) for (i = 0; i < K->numel; i++) l[i] = K->lam[i];
         else if (K->kind == ORC_PSD) for (i = 0; i < K->dim; i++) l[i] = K->plam[i];
+    }
+}
+
+void orc_cones_psd_scaling(const orc_kkt *k, double *R, double *Rinv)
+{
+    I c, i, o = 0;
+    for (c = 0; c < k->ncones; c++) {
+        const cone_t *K = &k->cones[c];
+        if (K->kind != ORC_PSD) continue;
+        for (i = 0; i < K->dim * K->dim; i++) { R[o + i] = K->R[i]; Rinv[o + i] = K->Rinv[i]; }
+        o += K->dim * K->dim;
     }
 }
 

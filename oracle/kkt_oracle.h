@@ -95,6 +95,8 @@ void orc_cones_mul_Hs(const orc_kkt *k, double *y, const double *x);
 void orc_cones_soc_sparse(const orc_kkt *k, double *u, double *v, double *eta2, double *d);
 /* lambda (scaled variable) for all cones, length m (PSD cones: zero-padded diag form) */
 void orc_cones_lambda(const orc_kkt *k, double *lam);
+/* PSD cones' R and Rinv (coneops_psdtrianglecone.jl:127-132), k x k col-major each, concatenated in cone order */
+void orc_cones_psd_scaling(const orc_kkt *k, double *R, double *Rinv);
 
 /* kktsolver_update! (kktsolver_directldl.jl:197-294): scatter -Hs and the sparse-cone
  * columns from the current cone scaling, regularise, refactor.  returns 1 on success. */

@@ -3,7 +3,8 @@ only).  Each entry: (P, q, A, b, cones, expected) with cone
 import numpy as np
 import scipy.sparse as sp
 
-from cuclarabel_amd.cones import (ZeroConeT, NonnegativeConeT, SecondOrderConeT, cones_new_collapsed)
+from cuclarabel_amd.cones import (ZeroConeT, NonnegativeConeT, SecondOrderConeT, PSDTriangleConeT,
+                                  cones_new_collapsed)
 
 
 def basic_qp():
@@ -81,13 +82,105 @@ def unconstrained(feasible=True):
     return P, c, sp.csc_matrix((0, 3)), np.zeros(0), [], exp
 
 
+def basic_qp_univariate():
+    # basic_qp.jl:42-57
+    P = sp.identity(1, format="csc")
+    return P, np.zeros(1), sp.identity(1, format="csc"), np.ones(1), [NonnegativeConeT(1)], \
+        dict(status="SOLVED", x=np.zeros(1), obj=0.0)
+
+
+def basic_qp_priminf():
+    # basic_qp.jl:73-86: b[1] = b[4] = -1 (1-based)
+    P, c, A, b, cones, _ = basic_qp()
+    b = b.copy(); b[0] = -1.0; b[3] = -1.0
+    return P, c, A, b, cones, dict(status="PRIMAL_INFEASIBLE")
+
+
+def basic_qp_dualinf_nonqsd():
+    # basic_qp.jl:99-113: one constraint row only -- the KKT matrix is not quasi-definite
+    P, c, A, b, _, _ = basic_qp_dualinf()
+    return P, c, sp.csc_matrix(A.toarray()[:1, :]), b[:1], [NonnegativeConeT(1)], dict(status="DUAL_INFEASIBLE")
+
+
+def basic_lp_priminf():
+    # basic_lp.jl:40-53
+    P, c, A, b, cones, _ = basic_lp()
+    b = b.copy(); b[0] = -1.0; b[3] = -1.0
+    return P, c, A, b, cones, dict(status="PRIMAL_INFEASIBLE")
+
+
+def basic_lp_dualinf(ill_conditioned=False):
+    # basic_lp.jl:55-68 and :70-84
+    P, c, A, b, cones, _ = basic_lp()
+    A = A.toarray()
+    if ill_conditioned:
+        A[0, 0] = np.finfo(float).eps
+        A[3, 0] = 0.0
+    else:
+        A[3, 0] = 1.0        # swap lower bound on first variable to redundant upper bound
+    return P, np.array([1.0, 0.0, 0.0]), sp.csc_matrix(A), b, cones, dict(status="DUAL_INFEASIBLE")
+
+
+def basic_socp_infeasible():
+    # basic_socp.jl:71-83: b[7] = -10
+    P, c, A, b, cones, _ = basic_socp()
+    b = b.copy(); b[6] = -10.0
+    return P, c, A, b, cones, dict(status="PRIMAL_INFEASIBLE")
+
+
+def basic_socp_feasible_sparse():
+    # basic_socp.jl:58-69: same data with the cone list [NN(3), NN(6)]; status only
+    P, c, A, b, _, _ = basic_socp()
+    return P, c, A, b, cones_new_collapsed([NonnegativeConeT(3), NonnegativeConeT(6)]), dict(status="SOLVED")
+
+
+_SDP_REFSOL = np.array([-3.0729833267361095, 0.3696004167288786, -0.022226685581313674, 0.31441213129613066,
+                        -0.026739700851545107, -0.016084530571308823])
+
+
+def basic_sdp(extra_empty_cone=False):
+    # test/OptTests/basic_sdp.jl:6-20 ; expected :37-48 (and the "empty SDP cone" variant :50-70);
+    # the same data is the SDP leg of test/OptTests/linear_solvers.jl:51-69
+    P = sp.identity(6, format="csc")
+    A = sp.identity(6, format="csc")
+    b = np.array([-3.0, 1.0, 4.0, 1.0, 2.0, 5.0])      # triu of some indefinite matrix
+    cones = [PSDTriangleConeT(3)] + ([PSDTriangleConeT(0)] if extra_empty_cone else [])
+    return P, np.zeros(6), A, b, cones_new_collapsed(cones), dict(status="SOLVED", x=_SDP_REFSOL, obj=4.840076866013861)
+
+
+def basic_sdp_priminf():
+    # basic_sdp.jl:72-87: adds a negative-definiteness constraint on x
+    P, c, A, b, cones, _ = basic_sdp()
+    A2 = sp.vstack([A, -A], format="csc")
+    return P, c, A2, np.concatenate([b, np.zeros(6)]), cones + cones, dict(status="PRIMAL_INFEASIBLE")
+
+
+def basic_sdp_1x1():
+    # basic_sdp.jl:89-106: PSDTriangleConeT(1) is collapsed to a nonnegative cone (cone_api.jl:96-153)
+    P = sp.identity(1, format="csc")
+    return P, np.zeros(1), sp.identity(1, format="csc"), np.ones(1), cones_new_collapsed([PSDTriangleConeT(1)]), \
+        dict(status="SOLVED", x=np.zeros(1), obj=0.0)
+
+
 ALL = {
     "unconstrained": lambda: unconstrained(True),
     "unconstrained_dualinf": lambda: unconstrained(False),
     "basic_qp": basic_qp,
+    "basic_qp_univariate": basic_qp_univariate,
+    "basic_qp_priminf": basic_qp_priminf,
     "basic_qp_dualinf": basic_qp_dualinf,
+    "basic_qp_dualinf_nonqsd": basic_qp_dualinf_nonqsd,
     "basic_lp": basic_lp,
+    "basic_lp_priminf": basic_lp_priminf,
+    "basic_lp_dualinf": basic_lp_dualinf,
+    "basic_lp_dualinf_illcond": lambda: basic_lp_dualinf(True),
     "basic_socp": basic_socp,
+    "basic_socp_infeasible": basic_socp_infeasible,
+    "basic_socp_feasible_sparse": basic_socp_feasible_sparse,
+    "basic_sdp": basic_sdp,
+    "basic_sdp_empty_cone": lambda: basic_sdp(True),
+    "basic_sdp_priminf": basic_sdp_priminf,
+    "basic_sdp_1x1": basic_sdp_1x1,
     "eq_constrained_1": lambda: eq_constrained(1),
     "eq_constrained_2": lambda: eq_constrained(2),
     "eq_constrained_redundant": lambda: eq_constrained(3),

@@ -54,6 +54,7 @@ def _load():
     lib.orc_cones_mul_Hs.argtypes = [C.c_void_p, _f64p, _f64p]
     lib.orc_cones_soc_sparse.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p]
     lib.orc_cones_lambda.argtypes = [C.c_void_p, _f64p]
+    lib.orc_cones_psd_scaling.argtypes = [C.c_void_p, _f64p, _f64p]
     lib.orc_kkt_update.restype = C.c_int
     lib.orc_kkt_update.argtypes = [C.c_void_p]
     lib.orc_kkt_update_values.restype = C.c_int
@@ -199,6 +200,23 @@ class OracleKKT:
         out = np.zeros(max(self.m, 1))
         lib().orc_cones_lambda(self._h, out)
         return out[:self.m]
+
+    def psd_scaling(self):
+        """[(R, Rinv, lam)] per PSD cone, matrices k x k"""
+        ks = [c.dim for c in self.cones if c.kind == 3]
+        tot = sum(k * k for k in ks)
+        R, Ri = np.zeros(max(tot, 1)), np.zeros(max(tot, 1))
+        lib().orc_cones_psd_scaling(self._h, R, Ri)
+        lam = self.cone_lambda()
+        out, o, off = [], 0, 0
+        for c in self.cones:
+            if c.kind == 3:
+                k = c.dim
+                out.append((R[o:o + k * k].reshape(k, k, order="F").copy(), Ri[o:o + k * k].reshape(k, k, order="F").copy(),
+                            lam[off:off + k].copy()))
+                o += k * k
+            off += c.numel
+        return out
 
     # --- the kktsolver_* interface
     def kktsolver_update(self):
