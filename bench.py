@@ -266,6 +266,11 @@ def main():
     ap.add_argument("--ordering", default="nd", choices=["nd", "amd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-units", type=int, default=10)
+    ap.add_argument("--sequential-solves", action="store_true",
+                    help="three single-column solves per step instead of (constant, affine) as one 2-column solve + combined")
+    ap.add_argument("--sync-status", action="store_true",
+                    help="every update / solve call returns its own status (one read-back each) instead of one deferred "
+                         "status query per step")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks rendezvous over gloo and exercise the launch / barrier / gather plumbing "
                          "with an empty step (CPU test of the --gpus N path); the JSON line carries dry_run: true")
@@ -328,22 +333,42 @@ def main():
         st = _lib.default_settings(device=local_rank, ordering=_lib.ORDER_ND if args.ordering == "nd" else _lib.ORDER_AMD)
         ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
         ks.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ks.set_deferred_status(not args.sync_status)
         return ks
 
     def resident(pb, rng):
-        return dict(s=torch.from_numpy(pb.s0).to(dev), z=torch.from_numpy(pb.z0).to(dev),
-                    rhs=[(torch.from_numpy(rng.standard_normal(pb.n)).to(dev), torch.from_numpy(rng.standard_normal(pb.m)).to(dev))
-                         for _ in range(3)],
+        rhs_host = [(rng.standard_normal(pb.n), rng.standard_normal(pb.m)) for _ in range(3)]
+        dd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return dict(s=dd(pb.s0), z=dd(pb.z0), rhs=[(dd(a), dd(b)) for a, b in rhs_host],
+                    # the first two right-hand sides as one column-major pair (row j of the (2, n) tensor = column j)
+                    rx2=dd(np.stack([rhs_host[0][0], rhs_host[1][0]])), rz2=dd(np.stack([rhs_host[0][1], rhs_host[1][1]])),
+                    lx2=torch.zeros(2, pb.n, dtype=torch.float64, device=dev), lz2=torch.zeros(2, pb.m, dtype=torch.float64, device=dev),
                     lx=torch.zeros(pb.n, dtype=torch.float64, device=dev), lz=torch.zeros(pb.m, dtype=torch.float64, device=dev))
 
-    def unit(ks, st):
-        """one IPM iteration's KKT work: 1 update + refactor, 3 solves with refinement"""
+    def unit(ks, st, batched=None):
+        """one IPM iteration's KKT work: 1 update + refactor, 3 solves with refinement.  The constant and the affine
+        right-hand side do not depend on each other (/root/reference/src/kktsystem.jl:87-88 vs :170-171), so they go
+        through the triangular sweeps TOGETHER as a 2-column solve; the combined right-hand side, which depends on the
+        affine step, follows alone.  (--sequential-solves: three single-column solves.)  Deferred status (the default):
+        the calls only enqueue -- the refinement loop's decisions are taken on the device -- and ONE status query per
+        step says whether every call succeeded exactly as the synchronous calls would have; anything else invalidates
+        the run.  --sync-status: every call returns its own status (one host round trip each)."""
+        batched = (not args.sequential_solves) if batched is None else batched
         if not ks.kktsolver_update_from_sz_dev(st["s"].data_ptr(), st["z"].data_ptr()):
             raise RuntimeError("factorisation failed")
-        for rx, rz in st["rhs"]:
+        single = st["rhs"][2:] if batched else st["rhs"]
+        if batched:
+            ok, _ = ks.kktsolver_solve_multi_dev(2, st["rx2"].data_ptr(), st["rz2"].data_ptr(), st["lx2"].data_ptr(), st["lz2"].data_ptr())
+            if not ok:
+                raise RuntimeError("solve failed")
+        for rx, rz in single:
             ks.kktsolver_setrhs_dev(rx.data_ptr(), rz.data_ptr())
             if not ks.kktsolver_solve_dev(st["lx"].data_ptr(), st["lz"].data_ptr()):
                 raise RuntimeError("solve failed")
+        if not args.sync_status:
+            rc = ks.deferred_status()
+            if rc != 0:
+                raise RuntimeError("deferred status %d: a factorisation / solve of this step failed or stopped refining early" % rc)
 
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic"}
@@ -459,14 +484,31 @@ def main():
 
     for _ in range(args.warmup):
         unit(ks, st)
-    ks.profile_enable(True)
-    ks.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         unit(ks, st)
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0, device=dev)
+    # the per-phase breakdown comes from a second, instrumented pass over the same steps (hipEvents around every phase
+    # on the kernels' stream: ~16 event records per step, each a marker packet the stream waits on -- instrumentation
+    # that does not belong in the timed region)
+    # ... and with single-column solves only: every phase launch is then one single-column sweep / residual, which is
+    # what the roofline objects are quoted for.  The same pass un-instrumented gives the step both ways.
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        unit(ks, st, batched=False)
+    barrier()
+    elapsed_seq = time.perf_counter() - t0
+    ks.profile_enable(True)
+    ks.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        unit(ks, st, batched=False)
+    barrier()
+    elapsed_profiled = time.perf_counter() - t0
     prof = ks.profile()
     ks.profile_enable(False)
 
@@ -539,11 +581,17 @@ def main():
                        "factor_flops": info["factor_flops"], "ordering": args.ordering,
                        "ir_rounds_per_step": prof["ir_iterations"] / max(args.steps, 1),
                        "setup_s": setup_s, "parallelism": "independent problems per GPU",
+                       "status": "per call" if args.sync_status else "deferred: one status query per step",
                        "csrc_sha16": traffic_summary()[2]},
             "roofline": roofline,
             "roofline_trisolve": rt,      # the north-star's named roofline target
             "phases": phases,
-            "ms_per_step_outside_phases": elapsed / args.steps * 1e3 - phase_sum,
+            "ms_per_step_sequential_solves": elapsed_seq / args.steps * 1e3,
+            "solves": ("3 single-column solves per step" if args.sequential_solves else
+                       "k = 2: constant + affine right-hand sides share one 2-column solve, combined alone (3 solves per step); "
+                       "ms_per_step_sequential_solves is the same step with three single-column solves (k = 1)"),
+            "ms_per_step_instrumented": elapsed_profiled / args.steps * 1e3,
+            "ms_per_step_outside_phases": elapsed_profiled / args.steps * 1e3 - phase_sum,
         })
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pb, args.cpu_units)

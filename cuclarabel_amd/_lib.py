@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libhipkkt.so")
 
-OK, NUMERIC_FAILURE = 0, 1
+OK, NUMERIC_FAILURE, REFINEMENT_INCOMPLETE = 0, 1, 2
 ORDER_AMD, ORDER_ND, ORDER_NATURAL, ORDER_USER = 0, 1, 2, 3
 
 
@@ -89,6 +89,8 @@ SYMBOLS = {
     "hipkkt_kkt_solve": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_setrhs_dev": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_solve_dev": (C.c_int, [_P, _P, _P]),
+    "hipkkt_kkt_set_deferred_status": (C.c_int, [_P, C.c_int]),
+    "hipkkt_kkt_deferred_status": (C.c_int, [_P]),
     "hipkkt_kkt_solve_multi": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "hipkkt_kkt_solve_multi_dev": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "hipkkt_kkt_system_init": (C.c_int, [_P, _P, _P]),

@@ -76,6 +76,7 @@ struct Launch {
 };
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
+static constexpr int kMaxNR = 4;          // right-hand sides the single-column solve path takes in one sweep (1, 2 or 4)
 static int kSideWinvBlocks = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 192;
 
 // The persistent top-of-tree solve kernel needs all its workgroups resident.  Two such kernels running
@@ -155,11 +156,16 @@ public:
 
     // d_b, d_x in the caller's (original) ordering; may alias.  allow_top: the caller will synchronise and ask
     // top_gave_up() afterwards (and repeat the solve if so); otherwise the launch-per-level path is used.
-    void solve(const double* d_b, double* d_x, bool allow_top = false)
+    // nr = 1, 2 or 4 right-hand sides in ONE sweep (column c at d_b + c ldb / d_x + c ldx): see supports_nr().
+    void solve(const double* d_b, double* d_x, bool allow_top = false, int nr = 1, int64_t ldb = 0, int64_t ldx = 0)
     {
         static const bool no_graph = std::getenv("HIPKKT_GRAPH") == nullptr;
-        if (no_graph || n_solve_calls++ == 0) {
-            enqueue_solve(d_b, d_x, stream, allow_top && claim_top());
+        if (nr > 1) {
+            if (!supports_nr(nr)) throw ArgError("solve: this structure takes one right-hand side per sweep");
+            reserve_nr(nr);
+        }
+        if (no_graph || nr > 1 || n_solve_calls++ == 0) {
+            enqueue_solve(d_b, d_x, stream, allow_top && claim_top(), nr, ldb, ldx);
             return;
         }
         auto key = std::make_pair((const void*)d_b, (const void*)d_x);
@@ -167,7 +173,7 @@ public:
         if (it == solve_graphs.end()) {
             ensure_capture_streams();
             HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-            enqueue_solve(d_b, d_x, cap_stream, false);
+            enqueue_solve(d_b, d_x, cap_stream, false, 1, 0, 0);
             hipGraph_t g;
             HIP_CHECK(hipStreamEndCapture(cap_stream, &g));
             hipGraphExec_t ex;
@@ -176,6 +182,17 @@ public:
             it = solve_graphs.emplace(key, ex).first;
         }
         HIP_CHECK(hipGraphLaunch(it->second, stream));
+    }
+    // The single-column kernels' NR-column instances keep NR times the vectors in LDS: possible when every level's
+    // share still fits a CU, and when the top of the tree does not need the (front, slice) kernel (single column only).
+    bool supports_nr(int nr) const
+    {
+        if (nr == 1) return true;
+        if (nr != 2 && nr != 4) return false;
+        if (top_ntask > 0) return false;
+        for (const Launch& L : launches)
+            if (!L.small && L.lds_solve * (size_t)nr > kLdsCap) return false;
+        return true;
     }
 
     // nrhs right-hand sides at once: column j of d_B at stride ldb, of d_X at stride ldx (may alias d_B).
@@ -360,7 +377,24 @@ private:
         }
     }
 
-    void enqueue_solve(const double* d_b, double* d_x, hipStream_t st, bool use_top)
+    void reserve_nr(int nr)
+    {
+        if ((size_t)nr <= nr_cap) return;
+        wait_w(stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        xp.alloc((size_t)S.N * nr);
+        uvec.alloc(std::max<size_t>(S.rows.size(), 1) * nr);
+        nr_cap = (size_t)nr;
+    }
+    int top_grid_for(int nr)
+    {
+        if (nr == 1) return top_grid;
+        int& g = top_grid_nr[nr == 2 ? 0 : 1];
+        if (g < 0) g = std::min(top_grid, top_solve_capacity_nr(top_lds * (size_t)nr, nr));
+        return g;
+    }
+
+    void enqueue_solve(const double* d_b, double* d_x, hipStream_t st, bool use_top, int nr, int64_t ldb, int64_t ldx)
     {
         SolveArgs a;
         a.T = tree();
@@ -371,14 +405,15 @@ private:
         a.out = d_x;
         a.xp = xp.p;
         a.uvec = uvec.p;
-        a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
+        a.ld_b = ldb; a.ld_out = ldx; a.ld_xp = S.N; a.ld_uvec = (int64_t)std::max<size_t>(S.rows.size(), 1);
         a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         const size_t nl = launches.size();
         // the persistent kernel covers the last ntl launches.  Right after a factorisation the W of the narrow top is
         // still being formed on the side stream: that sweep keeps the per-level launches for the levels below the
         // narrow top, so that the formation hides behind them
-        size_t ntl = (no_top || !use_top || top_disabled) ? 0 : top_launches;
+        const int tgrid = (no_top || !use_top || top_disabled) ? 0 : top_grid_for(nr);
+        size_t ntl = tgrid > 0 ? top_launches : 0;
         int ncount = top_count;
         if (ntl > 0 && w_pending && late_launches > 0 && late_launches < ntl) { ntl = late_launches; ncount = late_count; }
         const size_t first_w = nl - std::min(nl, late_launches);    // fronts from here on get their W late (w_pending)
@@ -394,12 +429,12 @@ private:
             if (pair_at(q)) {
                 const Launch& Ls = launches[q + 1];
                 if (q + 1 == first_w) wait_w(st);
-                launch_fwd_level(a, L.begin, L.count, Ls.count - Ls.ntiny, Ls.ntiny, L.solve_bs, L.lds_solve, st);
+                launch_fwd_level(a, L.begin, L.count, Ls.count - Ls.ntiny, Ls.ntiny, L.solve_bs, L.lds_solve, st, nr);
                 ++q;
             } else if (L.small) {
-                launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, L.level == 0);
+                launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, L.level == 0, nr);
             } else {
-                launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
+                launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st, nr);
             }
         }
         wait_w(st);
@@ -412,19 +447,19 @@ private:
                 launch_top_solve_sliced(a, Lfull.begin, pos0, h_tbase[(size_t)pos0], top_ntask, top_sgrid, top_slds, top_flags.p,
                                         top_nflag, ++top_epoch, st);
             } else {
-                launch_top_solve(a, L0.begin, ncount, std::min(top_grid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st, top_tall);
+                launch_top_solve(a, L0.begin, ncount, std::min(tgrid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st, top_tall, nr);
             }
         }
         for (size_t q = nl - ntl; q-- > 0;) {
             const Launch& L = launches[q];
             if (q > 0 && pair_at(q - 1)) {
                 const Launch& Lb = launches[q - 1];
-                launch_bwd_level(a, Lb.begin, Lb.count, L.count - L.ntiny, L.ntiny, Lb.solve_bs, Lb.lds_solve, st);
+                launch_bwd_level(a, Lb.begin, Lb.count, L.count - L.ntiny, L.ntiny, Lb.solve_bs, Lb.lds_solve, st, nr);
                 --q;
             } else if (L.small) {
-                launch_bwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st);
+                launch_bwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, nr);
             } else {
-                launch_bwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st);
+                launch_bwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st, nr);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -532,6 +567,8 @@ private:
     int top_ntask = 0, top_nflag = 0, top_sgrid = 0;
     size_t top_slds = 0;
     size_t top_launches = 0, late_launches = 0, top_lds = 0;
+    size_t nr_cap = 1;           // right-hand sides xp / uvec are sized for
+    int top_grid_nr[2] = {-1, -1};   // the persistent kernel's grid for 2 / 4 right-hand sides (asked on first use)
     int top_count = 0, late_count = 0, top_grid = 0, top_epoch = 0;
     bool top_tall = true;        // the persistent kernel's 1024-thread build (default) or its 512-thread one
     std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
@@ -1042,7 +1079,7 @@ static void fill_info(const Symbolic& S, hipkkt_info* info)
 
 struct PinnedScalars {
     double* h = nullptr;
-    PinnedScalars() { HIP_CHECK(hipHostMalloc((void**)&h, 16 * sizeof(double))); }
+    PinnedScalars() { HIP_CHECK(hipHostMalloc((void**)&h, 64 * sizeof(double))); }   // [8..11] update status, [16..35] refinement read-back, [40..47] sticky
     ~PinnedScalars() { if (h) (void)hipHostFree(h); }
 };
 
@@ -1158,7 +1195,13 @@ struct hipkkt_kkt_s {
     bool has_psd = false, psd_too_big = false, scaling_valid = false;
     double last_eps = 0;
     int64_t last_ir = 0;
-    bool spec_ir = false;            // the previous solve needed refinement: enqueue the first round ahead
+    // refinement on the device (k_ir_round): state slots (4 doubles per round), a 5-double read-back record, the
+    // sticky deferred-status record (8 doubles)
+    DBuf<double> irbuf;
+    double *ir_state = nullptr, *ir_readback = nullptr, *ir_sticky = nullptr, *ir_norms = nullptr;
+    int ir_stride = 0;
+    int r_spec = 1;                  // refinement rounds enqueued ahead of the first read-back (= what the previous solve took)
+    bool deferred = false;           // hipkkt_kkt_set_deferred_status
     // level C (DefaultKKTSystem on the device, kktsystem.jl:21-215)
     DBuf<double> lam;                                        // scaled point, m
     DBuf<double> sq, snegq, sb, sx1, sz1, sx2, sz2, sworkx, sworkz, sconic, spa, spb;
@@ -1263,6 +1306,22 @@ int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* row
         if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
         Symbolic S;
         analyse((int)N, colptr, rowval, base, opt, S);
+        if (std::getenv("HIPKKT_DUMP_LEVELS")) {          // diagnostic: the shape of every tree level (host only)
+            for (size_t l = 0; l < S.levels.size(); ++l) {
+                int cnt = 0, fmax = 0, ncmax = 0, n8 = 0, n64 = 0;
+                double flops = 0, panel = 0, upd = 0, cols = 0;
+                for (int t = S.levels[l].begin; t < S.levels[l].end; ++t) {
+                    const int sn = S.level_sn[t];
+                    const int nc = S.sn_start[sn + 1] - S.sn_start[sn], nb = (int)(S.rowptr[sn + 1] - S.rowptr[sn]), f = nc + nb;
+                    ++cnt; fmax = std::max(fmax, f); ncmax = std::max(ncmax, nc);
+                    n8 += f <= 8; n64 += f <= 64;
+                    cols += nc; panel += (double)f * nc; upd += (double)nb * nb;
+                    for (int j = 0; j < nc; ++j) { const double c = f - 1 - j; flops += c * c + 3 * c; }
+                }
+                std::fprintf(stderr, "[levels] %2zu: %6d fronts (%6d f<=8, %6d f<=64) fmax %4d ncmax %3d cols %7.0f panel %.2f MB "
+                             "upd %.2f MB flops %.1f M\n", l, cnt, n8, n64, fmax, ncmax, cols, panel * 8e-6, upd * 8e-6, flops * 1e-6);
+            }
+        }
         if (perm_out) for (int64_t i = 0; i < N; ++i) perm_out[i] = S.perm[i];
         if (info_out) { std::memset(info_out, 0, sizeof(*info_out)); fill_info(S, info_out); }
         return HIPKKT_OK;
@@ -1533,25 +1592,37 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
                     h->long_rows.upload(lrows);
                     h->long_chunk_ptr.upload(lptr);
                     h->chunk_q.upload(cq);
-                    h->long_partial.alloc((size_t)h->nchunks);
-                    h->long_partial_cols = 1;
+                    h->long_partial.alloc((size_t)h->nchunks * kMaxNR);
+                    h->long_partial_cols = kMaxNR;
                 }
             }
             double avg = (double)ptr[N] / std::max(N, 1);
             h->lanes_per_row = avg > 24.0 ? 64 : 8;
         }
         const size_t N = (size_t)K.N;
-        h->b.alloc(N); h->x.alloc(N); h->e.alloc(N); h->dx.alloc(N);
-        HIP_CHECK(hipMemset(h->b.p, 0, N * sizeof(double)));
-        HIP_CHECK(hipMemset(h->x.p, 0, N * sizeof(double)));
+        // right-hand side, solution, residual and candidate: up to kMaxNR columns share a sweep (kkt_solve_core)
+        h->b.alloc(N * kMaxNR); h->x.alloc(N * kMaxNR); h->e.alloc(N * kMaxNR); h->dx.alloc(N * kMaxNR);
+        HIP_CHECK(hipMemset(h->b.p, 0, N * kMaxNR * sizeof(double)));
+        HIP_CHECK(hipMemset(h->x.p, 0, N * kMaxNR * sizeof(double)));
         h->cur_x = h->x.p;
         h->cur_dx = h->dx.p;
         h->rx.alloc((size_t)K.n); h->rz.alloc((size_t)K.m);
         h->sbuf.alloc((size_t)K.m); h->zbuf.alloc((size_t)K.m); h->ybuf.alloc((size_t)K.m);
-        h->partial.alloc(2 * (kNormParts + 1) + 8);
+        h->partial.alloc((size_t)std::max(2, kMaxNR) * (kNormParts + 1) + 8);
         h->scal.alloc(16);               // [0] eps, [1] norme, [2] normb, [3] abort, [4] speculative norme, [8..11] update status
         HIP_CHECK(hipMemset(h->scal.p, 0, 16 * sizeof(double)));
         h->pin.reset(new PinnedScalars);
+        {
+            h->ir_stride = 4 * (std::max(h->st.iterative_refinement_max_iter, 0) + 2);
+            const size_t nstate = (size_t)h->ir_stride * kMaxNR;
+            const size_t total = nstate + 5 * kMaxNR + 4 + 8 + 3 * kMaxNR;
+            h->irbuf.alloc(total);
+            HIP_CHECK(hipMemset(h->irbuf.p, 0, total * sizeof(double)));
+            h->ir_state = h->irbuf.p;
+            h->ir_readback = h->irbuf.p + nstate;
+            h->ir_sticky = h->ir_readback + 5 * kMaxNR + 4;
+            h->ir_norms = h->ir_sticky + 8;             // several columns: norme0[kMaxNR], normb[kMaxNR], cand[kMaxNR]
+        }
         // cones
         {
             size_t nc = K.cones.size();
@@ -1625,7 +1696,7 @@ int hipkkt_kkt_info(hipkkt_kkt_t h, hipkkt_info* info)
 
 // scatter of -Hs and the sparse-cone columns, static regulariser, numeric factorisation
 // (kktsolver_directldl.jl:211-294).  Hs/u/v/eta2 already on the device.
-static int kkt_update_device(hipkkt_kkt_t h)
+static int kkt_update_device(hipkkt_kkt_t h, bool deferred = false)
 {
     KKTAssembly& K = h->K;
     h->fval_dirty = true;
@@ -1647,6 +1718,10 @@ static int kkt_update_device(hipkkt_kkt_t h)
     // (one small kernel gathers the four words, one copy into pinned memory brings them over: three separate
     // copies, two of them into pageable memory, cost ~60 us of idle GPU per update)
     launch_collect_status(h->scal.p + 8, h->scal.p, h->fail.p, h->eng->flags_ptr(), h->stream);
+    if (deferred) {                  // no read-back: the status joins the sticky record (hipkkt_kkt_deferred_status)
+        launch_fold_update_status(h->ir_sticky, h->scal.p + 8, h->stream);
+        return HIPKKT_OK;
+    }
     HIP_CHECK(hipMemcpyAsync(h->pin->h + 8, h->scal.p + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->last_eps = h->st.static_regularization_enable ? h->pin->h[8] : 0.0;
@@ -1688,7 +1763,7 @@ int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double* d_s, const doubl
         launch_cone_scaling(h->cone_dev(), h->cone_state(), d_s, d_z, h->K.m, h->stream);
         h->prof.end(pu, h->stream);
         h->scaling_valid = true;
-        return kkt_update_device(h);
+        return kkt_update_device(h, h->deferred);
     });
 }
 
@@ -1774,112 +1849,111 @@ static SpmvDev kkt_spmv(hipkkt_kkt_t h)
     return A;
 }
 
-// e = b - K xi; ||e||_inf -> scal[slot], optionally ||b||_inf -> scal[2]; scal[3] carries the persistent solve
-// kernel's abort word along.  Nothing is read back here.
-static void kkt_enqueue_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, int slot)
+// e = b - K xi for nr columns (ld N); ||e_c||_inf -> norm_out[c], optionally ||b_c||_inf -> normb_out[c]; scal[3] carries
+// the persistent solve kernel's abort word along.  Nothing is read back here.
+static void kkt_enqueue_refine_error(hipkkt_kkt_t h, const double* xi, double* norm_out, double* normb_out, int nr)
 {
     const SpmvDev A = kkt_spmv(h);
     int pr = h->prof.begin(3, h->stream);
-    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, h->scal.p + slot, h->stream, 1, 0,
-                    h->eng->top_abort_word(), h->scal.p + 3, with_normb ? h->scal.p + 2 : nullptr);
+    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, norm_out, h->stream, nr, nr > 1 ? (int64_t)h->K.N : 0,
+                    h->eng->top_abort_word(), h->scal.p + 3, normb_out);
     h->prof.end(pr, h->stream);
 }
-// one read-back of scal[1..4] = {norme, normb, abort, speculative norme}; synchronises
-static void kkt_read_scalars(hipkkt_kkt_t h, bool* top_abort)
-{
-    HIP_CHECK(hipMemcpyAsync(h->pin->h + 1, h->scal.p + 1, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
-    if (top_abort) *top_abort = h->eng->top_abort_word() != nullptr && h->pin->h[3] != 0.0;
-}
-static double kkt_refine_error(hipkkt_kkt_t h, const double* xi, bool with_normb, double* normb, bool* top_abort)
-{
-    kkt_enqueue_refine_error(h, xi, with_normb, 1);
-    kkt_read_scalars(h, top_abort);
-    if (with_normb) *normb = h->pin->h[2];
-    return h->pin->h[1];
-}
-
-static void kkt_trisolve(hipkkt_kkt_t h, const double* rhs, double* out, bool allow_top = true)
+static void kkt_trisolve(hipkkt_kkt_t h, const double* rhs, double* out, bool allow_top = true, int nr = 1)
 {
     int ps = h->prof.begin(2, h->stream);
-    h->eng->solve(rhs, out, allow_top);
+    h->eng->solve(rhs, out, allow_top, nr, h->K.N, h->K.N);
     h->prof.end(ps, h->stream);
 }
 
-// kktsolver_solve! with _iterative_refinement (kktsolver_directldl.jl:346-449); leaves the
-// solution in h->cur_x.  Returns HIPKKT_OK or HIPKKT_NUMERIC_FAILURE.
-static int kkt_solve_core(hipkkt_kkt_t h)
+// kktsolver_solve! with _iterative_refinement (kktsolver_directldl.jl:346-449); leaves the solution in h->x.
+// The accept / stop rule of the loop runs on the device (k_ir_round): the host enqueues the first solve, its
+// residual and r_spec refinement rounds (what the previous solve on this handle took) without waiting, then reads ONE
+// 5-double record back -- or nothing at all in deferred-status mode.  Only when the device reports that the
+// reference's loop would go on does the host add rounds, one read-back each.  A candidate is computed into h->dx and
+// copied over h->x when accepted, so the solution always sits in the same buffer.
+// Returns HIPKKT_OK or HIPKKT_NUMERIC_FAILURE.
+struct IrNorms { double *norme0, *normb, *cand; };
+static IrNorms kkt_ir_norms(hipkkt_kkt_t h, int nr)
+{
+    // one column: the residual kernel's single-column slots in scal; several: the per-column arrays
+    if (nr == 1) return IrNorms{h->scal.p + 1, h->scal.p + 2, h->scal.p + 4};
+    return IrNorms{h->ir_norms, h->ir_norms + kMaxNR, h->ir_norms + 2 * kMaxNR};
+}
+static void kkt_launch_ir(hipkkt_kkt_t h, int r, bool first, bool readback, bool fold, int nr)
 {
     const hipkkt_settings& st = h->st;
-    double* x = h->cur_x;
-    double* dx = h->cur_dx;
+    const IrNorms nm = kkt_ir_norms(h, nr);
+    const double* abortw = h->eng->top_abort_word() ? h->scal.p + 3 : nullptr;
+    launch_ir_round(h->ir_state, h->ir_stride, r, first, nm.norme0, nm.normb, nm.cand, abortw, h->x.p, h->dx.p, h->K.N, nr,
+                    st.iterative_refinement_abstol, st.iterative_refinement_reltol, st.iterative_refinement_stop_ratio,
+                    std::max(st.iterative_refinement_max_iter, 0), readback ? h->ir_readback : nullptr,
+                    (fold && nr == 1) ? h->ir_sticky : nullptr, h->stream);
+    if (fold && nr > 1) launch_ir_fold(h->ir_state, h->ir_stride, r, nr, abortw, h->ir_sticky, h->stream);
+}
+static void kkt_enqueue_round(hipkkt_kkt_t h, int r, bool first, bool readback, bool fold, int nr)
+{
+    kkt_trisolve(h, h->e.p, h->dx.p, true, nr);                                   // dx = K^{-1} e
+    launch_axpby_sum(h->dx.p, h->dx.p, h->x.p, (int64_t)h->K.N * nr, h->stream);  // prospective solution x + dx
+    kkt_enqueue_refine_error(h, h->dx.p, kkt_ir_norms(h, nr).cand, nullptr, nr);  // e <- b - K (x + dx), its norm -> cand
+    kkt_launch_ir(h, r, first, readback, fold, nr);
+}
+// nr = 1, 2 or 4 right-hand sides (columns of h->b, N apart) share every sweep; each column goes through the
+// reference's loop on its own.  ir_out (nullable, nr entries): rounds per column (-1 in deferred mode).
+static int kkt_solve_core(hipkkt_kkt_t h, bool may_defer = false, int nr = 1, int64_t* ir_out = nullptr)
+{
+    const hipkkt_settings& st = h->st;
+    const bool deferred = may_defer && h->deferred;
+    h->cur_x = h->x.p;
+    h->cur_dx = h->dx.p;
     h->last_ir = 0;
+    if (ir_out) for (int c = 0; c < nr; ++c) ir_out[c] = deferred ? -1 : 0;
     if (!st.iterative_refinement_enable) {
-        kkt_trisolve(h, h->b.p, x, false);       // nothing reads the abort word back on this path
+        kkt_trisolve(h, h->b.p, h->x.p, false, nr);   // nothing reads the abort word back on this path
         int bad = 0;
         launch_zero_ints(h->fail.p, 1, h->stream);
-        launch_check_finite(x, h->K.N, h->fail.p, h->stream);
+        launch_check_finite(h->x.p, h->K.N * nr, h->fail.p, h->stream);
+        if (deferred) { launch_fold_flag(h->ir_sticky, h->fail.p, h->stream); return HIPKKT_OK; }
         HIP_CHECK(hipMemcpyAsync(&bad, h->fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         return bad ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;
     }
-    double normb = 0.0;
-    bool gave_up = false;
-    // When the previous solve on this handle needed a refinement round (the rule, with the static regulariser
-    // on), the first round is enqueued before the first residual has been read back: one host round trip per
-    // solve instead of two.  If the first residual already met the tolerance the extra sweep is discarded
-    // (x is untouched by it) and the next solve does not speculate.
-    bool spec = h->spec_ir && st.iterative_refinement_max_iter >= 1;
-    kkt_trisolve(h, h->b.p, x);
-    kkt_enqueue_refine_error(h, x, true, 1);
-    if (spec) {
-        kkt_trisolve(h, h->e.p, dx);
-        launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
-        kkt_enqueue_refine_error(h, dx, false, 4);
-    }
-    kkt_read_scalars(h, &gave_up);
-    double norme = h->pin->h[1];
-    normb = h->pin->h[2];
-    double spec_norme = h->pin->h[4];
-    if (gave_up) {                                               // never expected; see TopOwner
-        h->eng->top_gave_up();
-        spec = false;
-        kkt_trisolve(h, h->b.p, x);
-        norme = kkt_refine_error(h, x, true, &normb, nullptr);
-    }
-    if (!std::isfinite(norme)) return HIPKKT_NUMERIC_FAILURE;
-    for (int i = 0; i < st.iterative_refinement_max_iter; ++i) {
-        if (norme <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb) break;
-        const double lastnorme = norme;
-        if (i == 0 && spec) {
-            norme = spec_norme;                                  // this round is already on the device
-        } else {
-            // dx = K^{-1} e; prospective solution x + dx
-            kkt_trisolve(h, h->e.p, dx);
-            launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
-            norme = kkt_refine_error(h, dx, false, nullptr, &gave_up);
-            if (gave_up) {
-                // e was overwritten with the candidate's residual; rebuild e = b - K x and repeat the round
-                h->eng->top_gave_up();
-                (void)kkt_refine_error(h, x, false, nullptr, nullptr);
-                kkt_trisolve(h, h->e.p, dx);
-                launch_axpby_sum(dx, dx, x, h->K.N, h->stream);
-                norme = kkt_refine_error(h, dx, false, nullptr, nullptr);
-            }
+    const int max_iter = std::max(st.iterative_refinement_max_iter, 0);
+    int R = std::min(max_iter, std::max(h->r_spec, deferred ? 1 : 0));
+    const IrNorms nm = kkt_ir_norms(h, nr);
+    kkt_trisolve(h, h->b.p, h->x.p, true, nr);        // (deferred mode reads the persistent kernel's abort word at the status query)
+    kkt_enqueue_refine_error(h, h->x.p, nm.norme0, nm.normb, nr);     // e = b - K x, ||e||, ||b||
+    if (R == 0) kkt_launch_ir(h, 0, true, !deferred, deferred, nr);
+    for (int r = 1; r <= R; ++r) kkt_enqueue_round(h, r, r == 1, r == R && !deferred, r == R && deferred, nr);
+    if (deferred) { h->last_ir = -1; return HIPKKT_OK; }
+    int64_t total = 0;
+    for (;;) {
+        HIP_CHECK(hipMemcpyAsync(h->pin->h + 16, h->ir_readback, 5 * (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        bool any_active = false, any_bad = false, aborted = false;
+        total = 0;
+        for (int c = 0; c < nr; ++c) {
+            const double* rb = h->pin->h + 16 + 5 * c;
+            any_active = any_active || rb[0] != 0.0;
+            any_bad = any_bad || rb[2] != 0.0;
+            aborted = aborted || rb[4] != 0.0;
+            total += (int64_t)rb[1];
+            if (ir_out) ir_out[c] = (int64_t)rb[1];
         }
-        h->last_ir++;
-        h->prof.acc.ir_iterations++;
-        if (!std::isfinite(norme)) return HIPKKT_NUMERIC_FAILURE;
-        const double ratio = lastnorme / norme;
-        if (ratio < st.iterative_refinement_stop_ratio) {
-            if (ratio > 1.0) std::swap(x, dx);
-            break;
+        if (aborted && h->eng->top_abort_word() != nullptr) {           // never expected; see TopOwner
+            h->eng->top_gave_up();                                      // the per-level path from now on: repeat the solve
+            return kkt_solve_core(h, false, nr, ir_out);
         }
-        std::swap(x, dx);
+        h->last_ir = total;
+        if (any_bad) { h->prof.acc.ir_iterations += total; return HIPKKT_NUMERIC_FAILURE; }
+        if (!any_active || R >= max_iter) break;
+        ++R;                                                            // the reference's loop goes on: one more round
+        kkt_enqueue_round(h, R, false, true, false, nr);
     }
-    h->cur_x = x;
-    h->cur_dx = dx;
-    h->spec_ir = h->last_ir >= 1;
+    h->prof.acc.ir_iterations += total;
+    int64_t most = 0;
+    for (int c = 0; c < nr; ++c) most = std::max<int64_t>(most, (int64_t)h->pin->h[16 + 5 * c + 1]);
+    h->r_spec = (int)std::min<int64_t>(most, max_iter);
     return HIPKKT_OK;
 }
 
@@ -1888,9 +1962,48 @@ int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double* d_lhsx, double* d_lhsz)
     return guarded([&]() {
         if (!h) throw ArgError("null handle");
         HIP_CHECK(hipSetDevice(h->device));
-        int rc = kkt_solve_core(h);
+        int rc = kkt_solve_core(h, true);
         if (rc != HIPKKT_OK) return rc;
         launch_unpack_lhs(d_lhsx, d_lhsz, h->cur_x, h->K.n, h->K.m, h->stream);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_set_deferred_status(hipkkt_kkt_t h, int defer)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        launch_zero_ints((int*)h->ir_sticky, 16, h->stream);
+        h->deferred = defer != 0;
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_deferred_status(hipkkt_kkt_t h)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        launch_zero_ints((int*)h->ir_sticky, 16, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        const double* s = h->pin->h + 40;
+        const int max_iter = std::max(h->st.iterative_refinement_max_iter, 0);
+        h->prof.acc.ir_iterations += (int64_t)s[3];
+        h->prof.acc.dynamic_regularizations += (int64_t)s[4];
+        if (s[5] != 0.0 || !h->st.static_regularization_enable) h->last_eps = h->st.static_regularization_enable ? s[5] : 0.0;
+        if (s[6] > 0.0) h->last_ir = (int64_t)(s[3] / s[6] + 0.5);      // mean rounds per solve since the last query
+        if (s[0] != 0.0) return HIPKKT_NUMERIC_FAILURE;
+        if (s[2] != 0.0 && h->eng->top_abort_word() != nullptr) {       // never expected; see TopOwner
+            h->eng->top_gave_up();
+            return HIPKKT_REFINEMENT_INCOMPLETE;
+        }
+        if (s[1] != 0.0) {                                              // some solve would have gone on refining
+            h->r_spec = std::min(max_iter, h->r_spec + 1);
+            return HIPKKT_REFINEMENT_INCOMPLETE;
+        }
         return HIPKKT_OK;
     });
 }
@@ -2089,6 +2202,42 @@ static void kkt_multi_unpack(hipkkt_kkt_t h, int k, double* lhsx, double* lhsz, 
         HIP_CHECK(hipMemcpy2DAsync(lhsz, m * sizeof(double), h->mX.p + n, N * sizeof(double), m * sizeof(double), (size_t)k, kind, h->stream));
 }
 
+// A handful of right-hand sides (2 .. kSmallBatch): the single-column kernels' 2- and 4-column instances, every
+// sweep shared by up to four columns -- the tree's dependency chain is paid once per sweep, not once per column (the
+// 16-column MFMA path below only pays off from ~a dozen columns on).  Device pointers, column-major, contiguous.
+static constexpr int kSmallBatch = 8;
+static int kkt_solve_small_batch(hipkkt_kkt_t h, int nrhs, const double* d_rhsx, const double* d_rhsz, double* d_lhsx,
+                                 double* d_lhsz, int64_t* ir_iterations, bool may_defer)
+{
+    const int n = h->K.n, m = h->K.m;
+    const size_t N = (size_t)h->K.N;
+    const int chunk = h->eng->supports_nr(4) ? 4 : 2;
+    kkt_multi_reserve(h, kMaxNR);
+    std::swap(h->b.p, h->mB.p);                   // a borrowed right-hand-side buffer: the one set by setrhs! stays as it is
+    int rc = HIPKKT_OK;
+    int64_t total = 0;
+    try {
+        for (int j0 = 0; j0 < nrhs && rc == HIPKKT_OK; j0 += chunk) {
+            const int k = std::min(chunk, nrhs - j0);
+            const int nr = k == 1 ? 1 : (k == 2 ? 2 : 4);
+            launch_pack_rhs(h->b.p, d_rhsx + (size_t)j0 * n, d_rhsz + (size_t)j0 * m, n, m, h->K.p, h->stream, k);
+            if (k < nr) HIP_CHECK(hipMemsetAsync(h->b.p + (size_t)k * N, 0, (size_t)(nr - k) * N * sizeof(double), h->stream));
+            int64_t ir[kMaxNR] = {0, 0, 0, 0};
+            rc = kkt_solve_core(h, may_defer, nr, ir);
+            if (rc != HIPKKT_OK) break;
+            for (int c = 0; c < k; ++c) {
+                launch_unpack_lhs(d_lhsx ? d_lhsx + (size_t)(j0 + c) * n : nullptr, d_lhsz ? d_lhsz + (size_t)(j0 + c) * m : nullptr,
+                                  h->x.p + (size_t)c * N, n, m, h->stream);
+                if (ir_iterations) ir_iterations[j0 + c] = ir[c];
+                total += std::max<int64_t>(ir[c], 0);
+            }
+        }
+    } catch (...) { std::swap(h->b.p, h->mB.p); throw; }
+    std::swap(h->b.p, h->mB.p);
+    h->last_ir = total;
+    return rc;
+}
+
 int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double* d_rhsx, const double* d_rhsz, double* d_lhsx,
                                double* d_lhsz, int64_t* ir_iterations)
 {
@@ -2111,6 +2260,8 @@ int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double* d_rhs
             launch_unpack_lhs(d_lhsx, d_lhsz, h->cur_x, h->K.n, h->K.m, h->stream);
             return HIPKKT_OK;
         }
+        if (nrhs <= kSmallBatch && h->eng->supports_nr(2))
+            return kkt_solve_small_batch(h, (int)nrhs, d_rhsx, d_rhsz, d_lhsx, d_lhsz, ir_iterations, true);
         kkt_multi_reserve(h, (size_t)nrhs);
         if (h->nlong == 0) {
             const int KP = ((int)nrhs + 15) & ~15;
@@ -2143,6 +2294,17 @@ int hipkkt_kkt_solve_multi(hipkkt_kkt_t h, int64_t nrhs, const double* rhsx, con
         double* sz = h->mC.p + n * k;
         if (n) HIP_CHECK(hipMemcpyAsync(sx, rhsx, n * k * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (m) HIP_CHECK(hipMemcpyAsync(sz, rhsz, m * k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (nrhs >= 2 && nrhs <= kSmallBatch && h->eng->supports_nr(2)) {
+            // staged in the candidate buffer of the many-column path (unused by this one); solutions come back through it too
+            double* ox = h->mE.p;
+            double* oz = h->mE.p + n * k;
+            int rc = kkt_solve_small_batch(h, (int)nrhs, sx, sz, lhsx ? ox : nullptr, lhsz ? oz : nullptr, ir_iterations, false);
+            if (rc != HIPKKT_OK) return rc;
+            if (lhsx && n) HIP_CHECK(hipMemcpyAsync(lhsx, ox, n * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (lhsz && m) HIP_CHECK(hipMemcpyAsync(lhsz, oz, m * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            return HIPKKT_OK;
+        }
         if (h->nlong == 0) {
             const int KP = ((int)nrhs + 15) & ~15;
             launch_pack_rhs_rm(h->mB.p, sx, sz, h->K.n, h->K.m, h->K.p, (int)nrhs, KP, h->stream);

@@ -352,6 +352,117 @@ void launch_collect_status(double* dst, const double* eps, const int* conefail, 
 {
     hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(64), 0, st, dst, eps, conefail, flags);
 }
+// ---- the refinement loop's decisions on the device (kktsolver_directldl.jl:389-449).  State after round r
+// (slot r of `state`, 4 doubles): {active: the reference's loop would go on, rounds done, bad: a residual norm was not
+// finite, norme: residual norm of the accepted solution}.  Round r >= 1 has just produced the candidate dx = x + K^-1 e
+// and its residual norm scal[4]; this kernel applies the reference's accept / stop rule to it and, if the candidate is
+// accepted, makes it the solution (x <- dx; e already holds its residual).  Every thread evaluates the rule from the
+// same read-only words; thread 0 of workgroup 0 publishes the new state.  r == 0: only the initial state.
+__device__ inline void ir_initial(double norme0, double normb, double abstol, double reltol, int max_iter,
+                                  double& active, double& rounds, double& bad, double& norme)
+{
+    norme = norme0;
+    bad = isfinite(norme) ? 0.0 : 1.0;
+    rounds = 0.0;
+    active = (bad == 0.0 && max_iter > 0 && !(norme <= abstol + reltol * normb)) ? 1.0 : 0.0;
+}
+// grid.y = right-hand side column c: its state at state + c * state_stride, norms norme0[c], normb[c], cand[c], vectors
+// x + c * ld, dx + c * ld, read-back record at readback + 5 c.  The sticky record is folded by column 0 only when
+// there is a single column (several columns: k_ir_fold).
+__global__ void k_ir_round(double* __restrict__ state, int state_stride, int r, int first, const double* __restrict__ norme0,
+                           const double* __restrict__ normb, const double* __restrict__ cand_norm,
+                           const double* __restrict__ abort_word, double* __restrict__ x, const double* __restrict__ dx,
+                           int n, int64_t ld, double abstol, double reltol, double stop_ratio, int max_iter,
+                           double* __restrict__ readback, double* __restrict__ sticky)
+{
+    const int c = blockIdx.y;
+    state += (int64_t)c * state_stride;
+    x += c * ld;
+    dx += c * ld;
+    double active, rounds, bad, norme;
+    if (r == 0 || first) ir_initial(norme0[c], normb[c], abstol, reltol, max_iter, active, rounds, bad, norme);
+    else { active = state[4 * (r - 1)]; rounds = state[4 * (r - 1) + 1]; bad = state[4 * (r - 1) + 2]; norme = state[4 * (r - 1) + 3]; }
+    bool accept = false;
+    if (r > 0 && active != 0.0) {
+        const double cand = cand_norm[c];
+        rounds += 1.0;
+        if (!isfinite(cand)) {                      // :429: return is_success = false
+            bad = 1.0; active = 0.0;
+        } else {
+            const double ratio = norme / cand;      // :437-446
+            if (ratio < stop_ratio) { accept = ratio > 1.0; active = 0.0; }
+            else accept = true;
+            if (accept) norme = cand;
+            // the head of the next iteration (:407-417): tolerance met, or max_iter rounds done
+            if (active != 0.0 && (r >= max_iter || norme <= abstol + reltol * normb[c])) active = 0.0;
+        }
+    }
+    if (accept)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = dx[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state[4 * r] = active; state[4 * r + 1] = rounds; state[4 * r + 2] = bad; state[4 * r + 3] = norme;
+        const double aborted = abort_word ? abort_word[0] : 0.0;
+        if (readback) {
+            double* rb = readback + 5 * c;
+            rb[0] = active; rb[1] = rounds; rb[2] = bad; rb[3] = norme; rb[4] = aborted;
+        }
+        if (sticky) {                               // deferred status: the worst over all calls since the last query
+            if (bad != 0.0) sticky[0] = 1.0;
+            if (active != 0.0) sticky[1] = 1.0;
+            if (aborted != 0.0) sticky[2] = 1.0;
+            sticky[3] += rounds;
+            sticky[6] += 1.0;
+        }
+    }
+}
+void launch_ir_round(double* state, int state_stride, int r, bool first, const double* norme0, const double* normb,
+                     const double* cand, const double* abort_word, double* x, const double* dx, int n, int nr, double abstol,
+                     double reltol, double stop_ratio, int max_iter, double* readback, double* sticky, hipStream_t st)
+{
+    const int g = r == 0 ? 1 : grid_for(n, 256);
+    hipLaunchKernelGGL(k_ir_round, dim3(g, nr), dim3(256), 0, st, state, state_stride, r, first ? 1 : 0, norme0, normb, cand,
+                       abort_word, x, dx, n, (int64_t)n, abstol, reltol, stop_ratio, max_iter, readback, sticky);
+}
+// several columns: their final states (slot r of each) joined into the sticky record by one thread
+__global__ void k_ir_fold(const double* __restrict__ state, int state_stride, int r, int nr, const double* __restrict__ abort_word,
+                          double* __restrict__ sticky)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int c = 0; c < nr; ++c) {
+        const double* s = state + (int64_t)c * state_stride + 4 * r;
+        if (s[2] != 0.0) sticky[0] = 1.0;
+        if (s[0] != 0.0) sticky[1] = 1.0;
+        sticky[3] += s[1];
+        sticky[6] += 1.0;
+    }
+    if (abort_word && abort_word[0] != 0.0) sticky[2] = 1.0;
+}
+void launch_ir_fold(const double* state, int state_stride, int r, int nr, const double* abort_word, double* sticky, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ir_fold, dim3(1), dim3(64), 0, st, state, state_stride, r, nr, abort_word, sticky);
+}
+// deferred status of a value update: {eps, cone failure, #dynamic regularisations, non-finite pivot} (k_collect_status's
+// words) folded into the sticky record
+__global__ void k_fold_update_status(double* __restrict__ sticky, const double* __restrict__ st4)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (st4[1] != 0.0 || st4[3] != 0.0) sticky[0] = 1.0;
+        sticky[4] += st4[2];
+        sticky[5] = st4[0];
+    }
+}
+void launch_fold_update_status(double* sticky, const double* st4, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fold_update_status, dim3(1), dim3(64), 0, st, sticky, st4);
+}
+__global__ void k_fold_flag(double* __restrict__ sticky, const int* __restrict__ flag)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && flag[0] != 0) sticky[0] = 1.0;
+}
+void launch_fold_flag(double* sticky, const int* flag, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fold_flag, dim3(1), dim3(64), 0, st, sticky, flag);
+}
 void launch_zero_ints(int* p, int n, hipStream_t st)
 {
     if (n <= 0) return;

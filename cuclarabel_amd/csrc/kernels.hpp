@@ -152,7 +152,8 @@ struct SolveArgs {
     double* out;                 // original order
     double* xp;                  // N, permuted work vector
     double* uvec;                // sum nb
-    // several right-hand sides in one launch: column blockIdx.y lives at these strides (0 for one column)
+    // NR right-hand sides in one launch (the single-column kernels' NR template parameter): column c of b, out, xp,
+    // uvec lives at these strides
     int64_t ld_b, ld_out, ld_xp, ld_uvec;
     // k_top_solve_sliced (sets with very tall fronts): its tasks are (front, slice) pairs -- a front whose W is too
     // large for one CU to stream per hop is cut into R slices (rows of W forward, columns of x backward) that never
@@ -172,8 +173,10 @@ size_t solve_lds_bytes(int fmax, int ncmax);
 constexpr int kTopMaxFronts = 480;
 int top_solve_capacity(size_t lds, bool tall);   // resident workgroups the device guarantees for the persistent kernel
                                                 // (tall: its 1024-thread build for sets with very tall fronts)
+int top_solve_capacity_nr(size_t lds_total, int nr);     // the same for the 1024-thread build's NR-column instance
+// nr right-hand sides (1, 2 or 4); lds = bytes per right-hand side
 void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
-                      hipStream_t st, bool tall);
+                      hipStream_t st, bool tall, int nr = 1);
 int top_solve_sliced_capacity(size_t lds);
 void launch_top_solve_sliced(const SolveArgs& a, int begin, int pos0, int task0, int task1, int grid, size_t lds, int* flags, int nflag,
                              int epoch, hipStream_t st);
@@ -192,15 +195,15 @@ void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds,
 void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, hipStream_t st);
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st);
 size_t panel_lds_bytes(int fmax, int panel_max);
-// nrhs > 1: grid.y = right-hand side column, strides in SolveArgs::ld_*
-void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
-void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs = 1);
-// one launch for a level's one-wave fronts [begin, begin + nwave) and the tiny fronts behind them (single right-hand side)
-void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf = false);
-void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st);
+// nr = 1, 2 or 4 right-hand sides per launch (column strides in SolveArgs::ld_*); lds = bytes per right-hand side
+void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);
+void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);
+// one launch for a level's one-wave fronts [begin, begin + nwave) and the tiny fronts behind them
+void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf = false, int nr = 1);
+void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, int nr = 1);
 // one launch for a whole level: nblock block-class fronts at [begin, ..), then nwave one-wave, then ntiny tiny fronts
-void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st);
-void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st);
+void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr = 1);
+void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr = 1);
 
 // several right-hand sides: work vectors row-major N x KP / sum(nb) x KP (KP = columns rounded up to 16)
 // iperm[caller's index] = permuted index
@@ -275,6 +278,17 @@ void launch_check_finite(const double* v, int n, int* flag, hipStream_t st);
 // kktsolver_getlhs! (kktsolver_directldl.jl:329-343) on the device: lhsx = x[0:n], lhsz = x[n:n+m]; either may be null.
 // One kernel instead of two device-to-device copies (the copy engine's latency is several kernel launches' worth).
 void launch_unpack_lhs(double* lhsx, double* lhsz, const double* x, int n, int m, hipStream_t st);
+// The refinement loop's accept / stop rule (kktsolver_directldl.jl:389-449) evaluated on the device after round r
+// (kernels.hip, k_ir_round), for nr right-hand side columns at once (column c: state + c state_stride, norme0[c],
+// normb[c], cand[c], x + c n, dx + c n, readback + 5 c).  state holds 4 doubles per round {active, rounds, bad, norme};
+// readback (nullable): 5 doubles {state of round r, abort} per column for ONE copy to the host; sticky (nullable, one
+// column only): the deferred-status record {bad, more, abort, rounds, #dyn. regularisations, eps, solves}.
+void launch_ir_round(double* state, int state_stride, int r, bool first, const double* norme0, const double* normb,
+                     const double* cand, const double* abort_word, double* x, const double* dx, int n, int nr, double abstol,
+                     double reltol, double stop_ratio, int max_iter, double* readback, double* sticky, hipStream_t st);
+void launch_ir_fold(const double* state, int state_stride, int r, int nr, const double* abort_word, double* sticky, hipStream_t st);
+void launch_fold_update_status(double* sticky, const double* st4, hipStream_t st);
+void launch_fold_flag(double* sticky, const int* flag, hipStream_t st);
 // p[0..n) = 0 with a kernel: a small hipMemsetAsync stalls the stream for ~40 us on this stack
 void launch_zero_ints(int* p, int n, hipStream_t st);
 // dst[0..3] = {eps[0], conefail[0], flags[0], flags[1]} (null pointers read as 0)

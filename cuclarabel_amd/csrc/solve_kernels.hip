@@ -34,8 +34,14 @@ __device__ inline double wave_reduce_sum(double v)
     return v;
 }
 
+// Every kernel below takes NR right-hand sides at once (NR = 1, 2 or 4; column c of a vector v lives at
+// v + c * ld_v, SolveArgs::ld_*): the entries of L / W, the gather lists and the row indices are fetched ONCE and used
+// for all NR columns.  These sweeps are bound by the latency of the tree's dependency chain, not by arithmetic, so two
+// columns cost little more than one -- which is what lets an interior-point iteration's independent solves (constant
+// and affine right-hand sides, /root/reference/src/kktsystem.jl:87-88 vs :170-171) share a sweep.
 // ------------------------------------------------------------------ small fronts, one wave each
-__device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by, bool leaf = false)
+template <int NR>
+__device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, bool leaf = false)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int item = bx * (int)(blockDim.x >> 6) + wv;
@@ -46,16 +52,22 @@ __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    const double* __restrict__ bcol = A.b + by * A.ld_b;          // right-hand side column by
-    double* __restrict__ xp = A.xp + by * A.ld_xp;
-    double* __restrict__ uvec = A.uvec + by * A.ld_uvec;
 
     // gather: right-hand side entry plus the children's contributions to this row, in child order
-    double y = (lane < nc) ? bcol[T.perm[c0 + lane]] : 0.0;
+    double y[NR];
+    {
+        const int pi = (lane < nc) ? T.perm[c0 + lane] : 0;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) y[c] = (lane < nc) ? A.b[c * A.ld_b + pi] : 0.0;
+    }
     if (!leaf && lane < f) {                  // (a leaf has no gather lists to look at)
         const int64_t lc = (int64_t)c0 + rp + lane;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; ++g) y += uvec[T.gl_src[g]];
+        for (int64_t g = g0; g < g1; ++g) {
+            const int src = T.gl_src[g];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) y[c] += A.uvec[c * A.ld_uvec + src];
+        }
     }
     // column sweep: y_l -= L(l,k) y_k
     for (int k0 = 0; k0 < nc; k0 += 8) {
@@ -69,20 +81,23 @@ __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int
         for (int q = 0; q < 8; ++q) {
             const int k = k0 + q;
             if (k < nc) {
-                const double yk = readlane_f64(y, k);
-                y = fma(-lv[q], yk, y);
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    const double yk = readlane_f64(y[c], k);
+                    y[c] = fma(-lv[q], yk, y[c]);
+                }
             }
         }
     }
-    if (lane < nc) xp[c0 + lane] = y;
-    else if (lane < f) uvec[rp + lane - nc] = y;
-}
-__global__ __launch_bounds__(256) void k_fwd_wave(SolveArgs A, int begin, int count)
-{
-    fwd_wave_body(A, begin, count, blockIdx.x, blockIdx.y);
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+        if (lane < nc) A.xp[c * A.ld_xp + c0 + lane] = y[c];
+        else if (lane < f) A.uvec[c * A.ld_uvec + rp + lane - nc] = y[c];
+    }
 }
 
-__device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int count, int bx, int by)
+template <int NR>
+__device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int count, int bx)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int item = bx * (int)(blockDim.x >> 6) + wv;
@@ -93,13 +108,19 @@ __device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    double* __restrict__ xp = A.xp + by * A.ld_xp;
-    double* __restrict__ out = A.out + by * A.ld_out;
 
     // lane = row: y_r = D^{-1} x_r for the front's own columns, the ancestors' solution below
-    double y = 0.0;
-    if (lane < nc) y = xp[c0 + lane] * A.Dinv[c0 + lane];
-    else if (lane < f) y = xp[T.rows[rp + lane - nc]];
+    double y[NR];
+    {
+        const double di = (lane < nc) ? A.Dinv[c0 + lane] : 0.0;
+        const int ri = (lane >= nc && lane < f) ? T.rows[rp + lane - nc] : 0;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            y[c] = 0.0;
+            if (lane < nc) y[c] = A.xp[c * A.ld_xp + c0 + lane] * di;
+            else if (lane < f) y[c] = A.xp[c * A.ld_xp + ri];
+        }
+    }
     // x_j = y_j - sum_{r > j} L(r,j) x_r, j = nc-1 .. 0: column loads (coalesced over lanes) issued eight
     // at a time up front; one wave reduction per column
     for (int j1 = nc; j1 > 0; j1 -= 8) {
@@ -113,19 +134,22 @@ __device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int
         for (int q = 0; q < 8; ++q) {
             const int j = j1 - 1 - q;
             if (j >= 0) {
-                const double sum = wave_reduce_sum(lv[q] * y);
-                if (lane == j) y -= sum;
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    const double sum = wave_reduce_sum(lv[q] * y[c]);
+                    if (lane == j) y[c] -= sum;
+                }
             }
         }
     }
     if (lane < nc) {
-        xp[c0 + lane] = y;
-        out[T.perm[c0 + lane]] = y;
+        const int pi = T.perm[c0 + lane];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            A.xp[c * A.ld_xp + c0 + lane] = y[c];
+            A.out[c * A.ld_out + pi] = y[c];
+        }
     }
-}
-__global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int count)
-{
-    bwd_wave_body(A, begin, count, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------ tiny fronts, eight to a wave
@@ -133,6 +157,7 @@ __global__ __launch_bounds__(256) void k_bwd_wave(SolveArgs A, int begin, int co
 // 92 000 one-wave fronts have f <= 8).  A whole wave for each wastes 7/8 of the machine's wave slots, and
 // these kernels are bound by how many waves are in flight: eight fronts share a wave, eight lanes each.
 constexpr int kTinyFront = 8;
+template <int NR>
 __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int count, int bx, bool leaf = false)
 {
     const int sub = threadIdx.x & 7;                                 // row inside the front
@@ -144,29 +169,41 @@ __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    double y = (sub < nc) ? A.b[T.perm[c0 + sub]] : 0.0;
+    double y[NR];
+    {
+        const int pi = (sub < nc) ? T.perm[c0 + sub] : 0;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) y[c] = (sub < nc) ? A.b[c * A.ld_b + pi] : 0.0;
+    }
     if (!leaf && sub < f) {
         const int64_t lc = (int64_t)c0 + rp + sub;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; ++g) y += A.uvec[T.gl_src[g]];
+        for (int64_t g = g0; g < g1; ++g) {
+            const int src = T.gl_src[g];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) y[c] += A.uvec[c * A.ld_uvec + src];
+        }
     }
     double lv[kTinyFront];
 #pragma unroll
     for (int k = 0; k < kTinyFront; ++k) lv[k] = (k < nc && sub > k && sub < f) ? F[sub + k * f] : 0.0;
 #pragma unroll
     for (int k = 0; k < kTinyFront; ++k) {
-        const double yk = __shfl(y, k, 8);                           // every lane takes part (no divergence here)
-        if (k < nc) y = fma(-lv[k], yk, y);
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            const double yk = __shfl(y[c], k, 8);                    // every lane takes part (no divergence here)
+            if (k < nc) y[c] = fma(-lv[k], yk, y[c]);
+        }
     }
     if (live) {
-        if (sub < nc) A.xp[c0 + sub] = y;
-        else if (sub < f) A.uvec[rp + sub - nc] = y;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            if (sub < nc) A.xp[c * A.ld_xp + c0 + sub] = y[c];
+            else if (sub < f) A.uvec[c * A.ld_uvec + rp + sub - nc] = y[c];
+        }
     }
 }
-__global__ __launch_bounds__(256) void k_fwd_tiny(SolveArgs A, int begin, int count)
-{
-    fwd_tiny_body(A, begin, count, blockIdx.x);
-}
+template <int NR>
 __device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int count, int bx)
 {
     const int sub = threadIdx.x & 7;
@@ -178,43 +215,56 @@ __device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    double y = 0.0;
-    if (sub < nc) y = A.xp[c0 + sub] * A.Dinv[c0 + sub];
-    else if (sub < f) y = A.xp[T.rows[rp + sub - nc]];
+    double y[NR];
+    {
+        const double di = (sub < nc) ? A.Dinv[c0 + sub] : 0.0;
+        const int ri = (sub >= nc && sub < f) ? T.rows[rp + sub - nc] : 0;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            y[c] = 0.0;
+            if (sub < nc) y[c] = A.xp[c * A.ld_xp + c0 + sub] * di;
+            else if (sub < f) y[c] = A.xp[c * A.ld_xp + ri];
+        }
+    }
     double lv[kTinyFront];
 #pragma unroll
     for (int j = 0; j < kTinyFront; ++j) lv[j] = (j < nc && sub > j && sub < f) ? F[sub + j * f] : 0.0;
 #pragma unroll
     for (int j = kTinyFront - 1; j >= 0; --j) {
-        double sum = lv[j] * y;
-        sum += __shfl_xor(sum, 4, 8);
-        sum += __shfl_xor(sum, 2, 8);
-        sum += __shfl_xor(sum, 1, 8);
-        if (j < nc && sub == j) y -= sum;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            double sum = lv[j] * y[c];
+            sum += __shfl_xor(sum, 4, 8);
+            sum += __shfl_xor(sum, 2, 8);
+            sum += __shfl_xor(sum, 1, 8);
+            if (j < nc && sub == j) y[c] -= sum;
+        }
     }
     if (live && sub < nc) {
-        A.xp[c0 + sub] = y;
-        A.out[T.perm[c0 + sub]] = y;
+        const int pi = T.perm[c0 + sub];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            A.xp[c * A.ld_xp + c0 + sub] = y[c];
+            A.out[c * A.ld_out + pi] = y[c];
+        }
     }
-}
-__global__ __launch_bounds__(256) void k_bwd_tiny(SolveArgs A, int begin, int count)
-{
-    bwd_tiny_body(A, begin, count, blockIdx.x);
 }
 // A level's one-wave and tiny fronts are independent of each other: one launch for both (the first nwb workgroups
 // take the one-wave fronts [begin, begin + nwave), the others the tiny fronts behind them) saves a launch per sweep
 // leaf: the fronts have no children (tree level 0), so no gather lists are read
+template <int NR>
 __global__ __launch_bounds__(256) void k_fwd_small(SolveArgs A, int begin, int nwave, int ntiny, int leaf)
 {
     const int nwb = (nwave + 3) >> 2;
-    if ((int)blockIdx.x < nwb) fwd_wave_body(A, begin, nwave, blockIdx.x, 0, leaf != 0);
-    else fwd_tiny_body(A, begin + nwave, ntiny, blockIdx.x - nwb, leaf != 0);
+    if ((int)blockIdx.x < nwb) fwd_wave_body<NR>(A, begin, nwave, blockIdx.x, leaf != 0);
+    else fwd_tiny_body<NR>(A, begin + nwave, ntiny, blockIdx.x - nwb, leaf != 0);
 }
+template <int NR>
 __global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int nwave, int ntiny)
 {
     const int nwb = (nwave + 3) >> 2;
-    if ((int)blockIdx.x < nwb) bwd_wave_body(A, begin, nwave, blockIdx.x, 0);
-    else bwd_tiny_body(A, begin + nwave, ntiny, blockIdx.x - nwb);
+    if ((int)blockIdx.x < nwb) bwd_wave_body<NR>(A, begin, nwave, blockIdx.x);
+    else bwd_tiny_body<NR>(A, begin + nwave, ntiny, blockIdx.x - nwb);
 }
 
 // ------------------------------------------------------------------ larger fronts, one block each
@@ -227,9 +277,11 @@ __global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int n
 // (L^{-1} restricted to a front is [T 0; -M I], and its transpose gives the backward form.)
 // Work is cut into items of 8 columns x 64 rows, 8 independent loads per lane in flight; partial
 // sums are combined in a fixed order (bit-reproducible).
+// LDS (doubles): forward NR * (1 + nks) * fpad  (y, then the partial sums per column slice),
+//                backward NR * (fpad + nrs * ncpad); column c's share sits behind column c - 1's.
 constexpr int kItemsInFlight = 2;     // matrix items (8 loads per lane each) a wave of the block solve kernels fetches at a time
-template <int BS>
-__device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, int bx, int by)
+template <int BS, int NR>
+__device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, int bx)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -242,31 +294,38 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
     const int f = nc + nb;
     const double* __restrict__ W = A.tinv + fd.w_off;                  // f x nc, ld f
     const int fpad = (f + 3) & ~3;
-    double* y = smem;                        // fpad
-    double* part = smem + fpad;              // nks * fpad
-    const double* __restrict__ bcol = A.b + by * A.ld_b;          // right-hand side column by
-    double* __restrict__ xp = A.xp + by * A.ld_xp;
-    double* __restrict__ uvec = A.uvec + by * A.ld_uvec;
+    const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6;
+    const int cst = (1 + nks) * fpad;        // LDS doubles per column
+    double* y = smem;                        // column c: y at c * cst, its partial sums behind it
+    double* part = smem + fpad;
 
     // gather: right-hand side entry plus the children's contributions to each row, in child order
     for (int i = tid; i < f; i += BS) {
-        double v = (i < nc) ? bcol[T.perm[c0 + i]] : 0.0;
+        double v[NR];
+        {
+            const int pi = (i < nc) ? T.perm[c0 + i] : 0;
+#pragma unroll
+            for (int c = 0; c < NR; ++c) v[c] = (i < nc) ? A.b[c * A.ld_b + pi] : 0.0;
+        }
         const int64_t lc = (int64_t)c0 + rp + i;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
         for (int64_t g = g0; g < g1; g += 4) {
             int src[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
-            double u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? uvec[src[q]] : 0.0;
+            for (int c = 0; c < NR; ++c) {
+                double u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v += u[q];
+                for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[c] += u[q];
+            }
         }
-        y[i] = v;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) y[c * cst + i] = v[c];
     }
     __syncthreads();
-    const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6;
     // kItemsInFlight items at a time: their loads are independent, so a wave keeps 8 x kItemsInFlight of them in flight
     constexpr int U = kItemsInFlight;
     for (int it0 = wv; it0 < nrb * nks; it0 += U * NW) {
@@ -286,25 +345,33 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
             if (it < nrb * nks) {
                 const int ks = it / nrb, rb = it - ks * nrb;
                 const int r = rb * 64 + lane, k0 = 8 * ks;
-                double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (k0 + q < nc) ? y[k0 + q] : 0.0, acc);
-                if (r < f) part[ks * fpad + r] = acc;
+                for (int c = 0; c < NR; ++c) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (k0 + q < nc) ? y[c * cst + k0 + q] : 0.0, acc);
+                    if (r < f) part[c * cst + ks * fpad + r] = acc;
+                }
             }
         }
     }
     __syncthreads();
     for (int i = tid; i < f; i += BS) {
-        double v = 0.0;
-        for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
-        if (i < nc) xp[c0 + i] = v;
-        else uvec[rp + i - nc] = y[i] - v;
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            double v = 0.0;
+            for (int ks = 0; ks < nks; ++ks) v += part[c * cst + ks * fpad + i];
+            if (i < nc) A.xp[c * A.ld_xp + c0 + i] = v;
+            else A.uvec[c * A.ld_uvec + rp + i - nc] = y[c * cst + i] - v;
+        }
     }
 }
 
-// backward items: 64 columns (lanes) x 8 rows of W' (= Wt, nc x f col-major), partial sums per row slice
+// backward items: 64 columns (lanes) x 8 rows of W' (= Wt, nc x f col-major), partial sums per row slice;
+// column c's z / part at c * cst
+template <int NR>
 __device__ inline void bwd_items(const double* __restrict__ Wt, int nc, int f, const double* z, double* part, int ncpad,
-                                 int wv, int NW, int lane)
+                                 int cst, int wv, int NW, int lane)
 {
     const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3;
     constexpr int U = kItemsInFlight;
@@ -325,23 +392,26 @@ __device__ inline void bwd_items(const double* __restrict__ Wt, int nc, int f, c
             if (it < ncb * nrs) {
                 const int rs = it / ncb, cb = it - rs * ncb;
                 const int j = cb * 64 + lane, r0 = 8 * rs;
-                double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-                if (j < nc) part[rs * ncpad + j] = acc;
+                for (int c = 0; c < NR; ++c) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[c * cst + r0 + q] : 0.0, acc);
+                    if (j < nc) part[c * cst + rs * ncpad + j] = acc;
+                }
             }
         }
     }
 }
 
-template <int BS>
+template <int BS, int NR>
 __global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
 {
-    fwd_block_body<BS>(A, begin, blockIdx.x, blockIdx.y);
+    fwd_block_body<BS, NR>(A, begin, blockIdx.x);
 }
 
-template <int BS>
-__device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, int bx, int by)
+template <int BS, int NR>
+__device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, int bx)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -354,48 +424,56 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
     const int f = nc + nb;
     const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;       // W'(j, r) at j + r*nc
     const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
+    const int nrs = (f + 7) >> 3;
+    const int cst = fpad + nrs * ncpad;
     double* z = smem;
     double* part = smem + fpad;
-    double* __restrict__ xp = A.xp + by * A.ld_xp;
-    double* __restrict__ out = A.out + by * A.ld_out;
 
     // z = [D^{-1} y_s ; -x_below]
-    for (int i = tid; i < f; i += BS)
-        z[i] = (i < nc) ? xp[c0 + i] * A.Dinv[c0 + i] : -xp[T.rows[rp + i - nc]];
+    for (int i = tid; i < f; i += BS) {
+        const double di = (i < nc) ? A.Dinv[c0 + i] : 0.0;
+        const int ri = (i < nc) ? 0 : T.rows[rp + i - nc];
+#pragma unroll
+        for (int c = 0; c < NR; ++c)
+            z[c * cst + i] = (i < nc) ? A.xp[c * A.ld_xp + c0 + i] * di : -A.xp[c * A.ld_xp + ri];
+    }
     __syncthreads();
-    bwd_items(Wt, nc, f, z, part, ncpad, wv, NW, lane);
+    bwd_items<NR>(Wt, nc, f, z, part, ncpad, cst, wv, NW, lane);
     __syncthreads();
-    const int nrs = (f + 7) >> 3;
     for (int j = tid; j < nc; j += BS) {
-        double v = 0.0;
-        for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
-        xp[c0 + j] = v;
-        out[T.perm[c0 + j]] = v;
+        const int pi = T.perm[c0 + j];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            double v = 0.0;
+            for (int rs = 0; rs < nrs; ++rs) v += part[c * cst + rs * ncpad + j];
+            A.xp[c * A.ld_xp + c0 + j] = v;
+            A.out[c * A.ld_out + pi] = v;
+        }
     }
 }
-template <int BS>
+template <int BS, int NR>
 __global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
 {
-    bwd_block_body<BS>(A, begin, blockIdx.x, blockIdx.y);
+    bwd_block_body<BS, NR>(A, begin, blockIdx.x);
 }
-// A level's block-class, one-wave and tiny fronts are independent of each other: one launch for all three (single
-// right-hand side) -- workgroups [0, nblock) take a block-class front each, the next ones BS/64 one-wave fronts
+// A level's block-class, one-wave and tiny fronts are independent of each other: one launch for all three
+// -- workgroups [0, nblock) take a block-class front each, the next ones BS/64 one-wave fronts
 // each, the last ones BS/8 tiny fronts each.  Saves a launch (~5 us of pure latency) per sweep and level.
-template <int BS>
+template <int BS, int NR>
 __global__ __launch_bounds__(BS) void k_fwd_level(SolveArgs A, int begin, int nblock, int nwave, int ntiny)
 {
     const int bx = blockIdx.x, nwb = (nwave + BS / 64 - 1) / (BS / 64);
-    if (bx < nblock) fwd_block_body<BS>(A, begin, bx, 0);
-    else if (bx < nblock + nwb) fwd_wave_body(A, begin + nblock, nwave, bx - nblock, 0);
-    else fwd_tiny_body(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
+    if (bx < nblock) fwd_block_body<BS, NR>(A, begin, bx);
+    else if (bx < nblock + nwb) fwd_wave_body<NR>(A, begin + nblock, nwave, bx - nblock);
+    else fwd_tiny_body<NR>(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
 }
-template <int BS>
+template <int BS, int NR>
 __global__ __launch_bounds__(BS) void k_bwd_level(SolveArgs A, int begin, int nblock, int nwave, int ntiny)
 {
     const int bx = blockIdx.x, nwb = (nwave + BS / 64 - 1) / (BS / 64);
-    if (bx < nblock) bwd_block_body<BS>(A, begin, bx, 0);
-    else if (bx < nblock + nwb) bwd_wave_body(A, begin + nblock, nwave, bx - nblock, 0);
-    else bwd_tiny_body(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
+    if (bx < nblock) bwd_block_body<BS, NR>(A, begin, bx);
+    else if (bx < nblock + nwb) bwd_wave_body<NR>(A, begin + nblock, nwave, bx - nblock);
+    else bwd_tiny_body<NR>(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
 }
 
 struct ItemRegs { double m[8]; };
@@ -446,8 +524,9 @@ __device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long lon
 // Two builds: 1024 threads with 4 items per wave parked (4 waves per SIMD, 128 VGPRs; 5 spill) -- the default: sixteen
 // waves keep twice the loads in flight and park 64 items per workgroup (cfg2 0.303 -> 0.291 ms per solve, cfg3 0.263
 // -> 0.246, cfg5 with its 1.2 MB fronts 1.56 -> 1.31); and 512 threads with 7 parked (2 waves per SIMD, ~177 VGPRs),
-// kept selectable (HIPKKT_TOP_TALL=0).
-template <int BS, int kTopPF, int kTopPB>
+// kept selectable (HIPKKT_TOP_TALL=0).  NR right-hand sides: the parked matrix items and indices serve all of them;
+// column c's LDS vectors sit at c * cst.
+template <int BS, int kTopPF, int kTopPB, int NR>
 __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs A, int begin, int* flags, int epoch, int ntop, int nflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -477,10 +556,11 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         const int f = nc + nb;
         const double* __restrict__ W = A.tinv + fd.w_off;
         const int fpad = (f + 3) & ~3;
-        double* y = smem;
-        double* part = smem + fpad;
         // ---- preload
         const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6, nitF = nrb * nks;
+        const int cst = (1 + nks) * fpad;
+        double* y = smem;
+        double* part = smem + fpad;
         ItemRegs rf[kTopPF];
 #pragma unroll
         for (int p = 0; p < kTopPF; ++p) {
@@ -496,14 +576,20 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
 #pragma unroll
         for (int q = 0; q < GP; ++q) gsrc[q] = -1;
         int64_t g0 = 0, g1 = 0;
-        double bmine = 0.0;
+        double bmine[NR];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) bmine[c] = 0.0;
         if (tid < f) {
             const int64_t lc = (int64_t)c0 + rp + tid;
             g0 = T.gl_ptr[lc];
             g1 = T.gl_ptr[lc + 1];
 #pragma unroll
             for (int q = 0; q < GP; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
-            if (tid < nc) bmine = A.b[T.perm[c0 + tid]];
+            if (tid < nc) {
+                const int pi = T.perm[c0 + tid];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) bmine[c] = A.b[c * A.ld_b + pi];
+            }
         }
         if (tid == 0) sh_ok = 1;
         __syncthreads();
@@ -520,26 +606,36 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         if (!sh_ok) return;
         // ---- gather (only the handed-over values are loaded now)
         if (tid < f) {
-            double u[GP];
 #pragma unroll
-            for (int q = 0; q < GP; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
-            double v = bmine;
+            for (int c = 0; c < NR; ++c) {
+                const double* uv = A.uvec + c * A.ld_uvec;
+                double u[GP];
 #pragma unroll
-            for (int q = 0; q < GP; ++q) v += u[q];
-            for (int64_t g = g0 + GP; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
-            y[tid] = v;
+                for (int q = 0; q < GP; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(uv + gsrc[q]) : 0.0;
+                double v = bmine[c];
+#pragma unroll
+                for (int q = 0; q < GP; ++q) v += u[q];
+                for (int64_t g = g0 + GP; g < g1; ++g) v += LD_AGENT_F64(uv + T.gl_src[g]);
+                y[c * cst + tid] = v;
+            }
         }
         for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
-            double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
             const int64_t lc = (int64_t)c0 + rp + i;
-            for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
-            y[i] = v;
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                double v = (i < nc) ? A.b[c * A.ld_b + T.perm[c0 + i]] : 0.0;
+                for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + c * A.ld_uvec + T.gl_src[g]);
+                y[c * cst + i] = v;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < kTopPF; ++p) {
             const int it = wv + p * NW;
-            if (it < nitF) item_apply(rf[p], y, f, nc, part, fpad, it, nrb, lane);
+            if (it < nitF) {
+#pragma unroll
+                for (int c = 0; c < NR; ++c) item_apply(rf[p], y + c * cst, f, nc, part + c * cst, fpad, it, nrb, lane);
+            }
         }
         // (tall fronts: the items beyond the parked ones, three at a time -- 24 loads per lane in flight)
         for (int it0 = wv + kTopPF * NW; it0 < nitF; it0 += 3 * NW) {
@@ -555,14 +651,20 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u)
-                if (it0 + u * NW < nitF) item_apply(rr[u], y, f, nc, part, fpad, it0 + u * NW, nrb, lane);
+                if (it0 + u * NW < nitF) {
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) item_apply(rr[u], y + c * cst, f, nc, part + c * cst, fpad, it0 + u * NW, nrb, lane);
+                }
         }
         __syncthreads();
         for (int i = tid; i < f; i += BS) {
-            double v = 0.0;
-            for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
-            if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
-            else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                double v = 0.0;
+                for (int ks = 0; ks < nks; ++ks) v += part[c * cst + ks * fpad + i];
+                if (i < nc) ST_AGENT_F64(A.xp + c * A.ld_xp + c0 + i, v);
+                else ST_AGENT_F64(A.uvec + c * A.ld_uvec + rp + i - nc, y[c * cst + i] - v);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
         __syncthreads();
@@ -577,10 +679,11 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         const int f = nc + nb;
         const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;
         const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
-        double* z = smem;
-        double* part = smem + fpad;
         // ---- preload
         const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3, nitB = ncb * nrs;
+        const int cst = fpad + nrs * ncpad;
+        double* z = smem;
+        double* part = smem + fpad;
         ItemRegs rbk[kTopPB];
 #pragma unroll
         for (int p = 0; p < kTopPB; ++p) {
@@ -608,10 +711,14 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         __syncthreads();
         if (!sh_ok) return;
-        if (tid < nc) z[tid] = LD_AGENT_F64(A.xp + c0 + tid) * dinv;
-        else if (tid < f) z[tid] = -LD_AGENT_F64(A.xp + ridx);
-        for (int i = tid + BS; i < f; i += BS)
-            z[i] = (i < nc) ? LD_AGENT_F64(A.xp + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            const double* xc = A.xp + c * A.ld_xp;
+            if (tid < nc) z[c * cst + tid] = LD_AGENT_F64(xc + c0 + tid) * dinv;
+            else if (tid < f) z[c * cst + tid] = -LD_AGENT_F64(xc + ridx);
+            for (int i = tid + BS; i < f; i += BS)
+                z[c * cst + i] = (i < nc) ? LD_AGENT_F64(xc + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(xc + T.rows[rp + i - nc]);
+        }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < kTopPB; ++p) {
@@ -619,10 +726,13 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             if (it < nitB) {
                 const int rs = it / ncb, cb = it - rs * ncb;
                 const int j = cb * 64 + lane, r0 = 8 * rs;
-                double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-                if (j < nc) part[rs * ncpad + j] = acc;
+                for (int c = 0; c < NR; ++c) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[c * cst + r0 + q] : 0.0, acc);
+                    if (j < nc) part[c * cst + rs * ncpad + j] = acc;
+                }
             }
         }
         for (int it0 = wv + kTopPB * NW; it0 < nitB; it0 += 3 * NW) {
@@ -642,19 +752,26 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
                 if (it < nitB) {
                     const int rs = it / ncb, cb = it - rs * ncb;
                     const int j = cb * 64 + lane, r0 = 8 * rs;
-                    double acc = 0.0;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-                    if (j < nc) part[rs * ncpad + j] = acc;
+                    for (int c = 0; c < NR; ++c) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[c * cst + r0 + q] : 0.0, acc);
+                        if (j < nc) part[c * cst + rs * ncpad + j] = acc;
+                    }
                 }
             }
         }
         __syncthreads();
         for (int j = tid; j < nc; j += BS) {
-            double v = 0.0;
-            for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
-            ST_AGENT_F64(A.xp + c0 + j, v);
-            A.out[T.perm[c0 + j]] = v;
+            const int pi = T.perm[c0 + j];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                double v = 0.0;
+                for (int rs = 0; rs < nrs; ++rs) v += part[c * cst + rs * ncpad + j];
+                ST_AGENT_F64(A.xp + c * A.ld_xp + c0 + j, v);
+                A.out[c * A.ld_out + pi] = v;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1300,29 +1417,42 @@ __global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restric
 
 constexpr int kSolveBS = 512;
 
+// NR dispatch: the kernels exist for 1, 2 and 4 right-hand sides
+#define HIPKKT_NR_SWITCH(nr, ...)                                                                 \
+    do {                                                                                         \
+        if ((nr) == 1) { constexpr int NR = 1; __VA_ARGS__; }                                    \
+        else if ((nr) == 2) { constexpr int NR = 2; __VA_ARGS__; }                               \
+        else { constexpr int NR = 4; __VA_ARGS__; }                                              \
+    } while (0)
+
 static void init_solve_lds()
 {
     static PerDeviceOnce once;
     once.run([]() {
         hipError_t e = hipSuccess;
         auto set = [&](auto k, int bytes) { if (e == hipSuccess) e = set_max_lds(k, bytes); };
-        set(k_fwd_block<128>, 160 * 1024);
-        set(k_bwd_block<128>, 160 * 1024);
-        set(k_fwd_block<kSolveBS>, 160 * 1024);
-        set(k_bwd_block<kSolveBS>, 160 * 1024);
-        set(k_fwd_level<128>, 160 * 1024);
-        set(k_bwd_level<128>, 160 * 1024);
-        set(k_fwd_level<kSolveBS>, 160 * 1024);
-        set(k_bwd_level<kSolveBS>, 160 * 1024);
+#define HIPKKT_SET_NR(NRV)                                     \
+        set(k_fwd_block<128, NRV>, 160 * 1024);                \
+        set(k_bwd_block<128, NRV>, 160 * 1024);                \
+        set(k_fwd_block<kSolveBS, NRV>, 160 * 1024);           \
+        set(k_bwd_block<kSolveBS, NRV>, 160 * 1024);           \
+        set(k_fwd_level<128, NRV>, 160 * 1024);                \
+        set(k_bwd_level<128, NRV>, 160 * 1024);                \
+        set(k_fwd_level<kSolveBS, NRV>, 160 * 1024);           \
+        set(k_bwd_level<kSolveBS, NRV>, 160 * 1024);           \
+        set(k_top_solve<1024, 4, 4, NRV>, 150 * 1024);         /* (a static LDS word as well: leave room for it) */
+        HIPKKT_SET_NR(1)
+        HIPKKT_SET_NR(2)
+        HIPKKT_SET_NR(4)
+#undef HIPKKT_SET_NR
         set(k_winv, 160 * 1024);
-        // these kernels also have a static LDS word: leave room for it
-        set(k_top_solve<512, 7, 7>, 150 * 1024);
-        set(k_top_solve<1024, 4, 4>, 150 * 1024);
+        set(k_top_solve<512, 7, 7, 1>, 150 * 1024);
         set(k_top_solve_sliced<1024>, 150 * 1024);
         return e;
     });
 }
 
+// per right-hand side; the kernels lay NR columns' shares out one after the other
 size_t solve_lds_bytes(int fmax, int ncmax)
 {
     const size_t fpad = (size_t)((fmax + 3) & ~3), ncpad = (size_t)((ncmax + 3) & ~3);
@@ -1331,68 +1461,58 @@ size_t solve_lds_bytes(int fmax, int ncmax)
     return (fwd > bwd ? fwd : bwd) * sizeof(double);
 }
 
-void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
+void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr)
 {
-    if (count <= 0 || nrhs <= 0) return;
-    if (bs == 8) {
-        hipLaunchKernelGGL(k_fwd_tiny, dim3((count + 31) / 32), dim3(256), 0, st, a, begin, count);
-    } else if (bs == 64) {
-        hipLaunchKernelGGL(k_fwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
-    } else {
-        init_solve_lds();
-        // bs = 128: a wide level of small fronts -- more fronts in flight per CU matter more than waves per front
-        if (bs == 128) hipLaunchKernelGGL(k_fwd_block<128>, dim3(count, nrhs), dim3(128), lds, st, a, begin);
-        else hipLaunchKernelGGL(k_fwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
-    }
+    if (count <= 0) return;
+    if (bs == 8) { launch_fwd_small(a, begin, 0, count, st, false, nr); return; }
+    if (bs == 64) { launch_fwd_small(a, begin, count, 0, st, false, nr); return; }
+    init_solve_lds();
+    // bs = 128: a wide level of small fronts -- more fronts in flight per CU matter more than waves per front
+    if (bs == 128) HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_block<128, NR>), dim3(count), dim3(128), lds * NR, st, a, begin));
+    else HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_block<kSolveBS, NR>), dim3(count), dim3(kSolveBS), lds * NR, st, a, begin));
 }
-void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st)
+void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr)
 {
     init_solve_lds();
     if (bs == 128) {
         const int grid = nblock + (nwave + 1) / 2 + (ntiny + 15) / 16;
-        hipLaunchKernelGGL(k_fwd_level<128>, dim3(grid), dim3(128), lds, st, a, begin, nblock, nwave, ntiny);
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_level<128, NR>), dim3(grid), dim3(128), lds * NR, st, a, begin, nblock, nwave, ntiny));
     } else {
         const int grid = nblock + (nwave + kSolveBS / 64 - 1) / (kSolveBS / 64) + (ntiny + kSolveBS / 8 - 1) / (kSolveBS / 8);
-        hipLaunchKernelGGL(k_fwd_level<kSolveBS>, dim3(grid), dim3(kSolveBS), lds, st, a, begin, nblock, nwave, ntiny);
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_level<kSolveBS, NR>), dim3(grid), dim3(kSolveBS), lds * NR, st, a, begin, nblock, nwave, ntiny));
     }
 }
-void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st)
+void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr)
 {
     init_solve_lds();
     if (bs == 128) {
         const int grid = nblock + (nwave + 1) / 2 + (ntiny + 15) / 16;
-        hipLaunchKernelGGL(k_bwd_level<128>, dim3(grid), dim3(128), lds, st, a, begin, nblock, nwave, ntiny);
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_level<128, NR>), dim3(grid), dim3(128), lds * NR, st, a, begin, nblock, nwave, ntiny));
     } else {
         const int grid = nblock + (nwave + kSolveBS / 64 - 1) / (kSolveBS / 64) + (ntiny + kSolveBS / 8 - 1) / (kSolveBS / 8);
-        hipLaunchKernelGGL(k_bwd_level<kSolveBS>, dim3(grid), dim3(kSolveBS), lds, st, a, begin, nblock, nwave, ntiny);
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_level<kSolveBS, NR>), dim3(grid), dim3(kSolveBS), lds * NR, st, a, begin, nblock, nwave, ntiny));
     }
 }
-void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf)
+void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf, int nr)
 {
     if (nwave + ntiny <= 0) return;
-    hipLaunchKernelGGL(k_fwd_small, dim3((nwave + 3) / 4 + (ntiny + 31) / 32), dim3(256), 0, st, a, begin, nwave, ntiny, leaf ? 1 : 0);
+    const int grid = (nwave + 3) / 4 + (ntiny + 31) / 32;
+    HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_small<NR>), dim3(grid), dim3(256), 0, st, a, begin, nwave, ntiny, leaf ? 1 : 0));
 }
-void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st)
+void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, int nr)
 {
-    if (nwave <= 0 || ntiny <= 0) {
-        launch_bwd(a, begin + nwave, ntiny, 8, 0, st, 1);
-        launch_bwd(a, begin, nwave, 64, 0, st, 1);
-        return;
-    }
-    hipLaunchKernelGGL(k_bwd_small, dim3((nwave + 3) / 4 + (ntiny + 31) / 32), dim3(256), 0, st, a, begin, nwave, ntiny);
+    if (nwave + ntiny <= 0) return;
+    const int grid = (nwave + 3) / 4 + (ntiny + 31) / 32;
+    HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_small<NR>), dim3(grid), dim3(256), 0, st, a, begin, nwave, ntiny));
 }
-void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nrhs)
+void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr)
 {
-    if (count <= 0 || nrhs <= 0) return;
-    if (bs == 8) {
-        hipLaunchKernelGGL(k_bwd_tiny, dim3((count + 31) / 32), dim3(256), 0, st, a, begin, count);
-    } else if (bs == 64) {
-        hipLaunchKernelGGL(k_bwd_wave, dim3((count + 3) / 4, nrhs), dim3(256), 0, st, a, begin, count);
-    } else {
-        init_solve_lds();
-        if (bs == 128) hipLaunchKernelGGL(k_bwd_block<128>, dim3(count, nrhs), dim3(128), lds, st, a, begin);
-        else hipLaunchKernelGGL(k_bwd_block<kSolveBS>, dim3(count, nrhs), dim3(kSolveBS), lds, st, a, begin);
-    }
+    if (count <= 0) return;
+    if (bs == 8) { launch_bwd_small(a, begin, 0, count, st, nr); return; }
+    if (bs == 64) { launch_bwd_small(a, begin, count, 0, st, nr); return; }
+    init_solve_lds();
+    if (bs == 128) HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_block<128, NR>), dim3(count), dim3(128), lds * NR, st, a, begin));
+    else HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_block<kSolveBS, NR>), dim3(count), dim3(kSolveBS), lds * NR, st, a, begin));
 }
 // ------------------------------------------------------------------ several right-hand sides
 // The single-column kernels above are latency-bound; with many columns the cost is fetching the
@@ -1819,15 +1939,17 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     else hipLaunchKernelGGL(k_bwd_block_m<512>, dim3(count, KP / kMultiCB), dim3(512), lds, st, a, begin, KP);
 }
 
+// resident workgroups the device guarantees for the persistent kernel with `lds` bytes of dynamic LDS (the 1024-thread
+// build's NR = 1 instance stands for all NR: same launch bounds, the caller passes NR times the LDS)
 int top_solve_capacity(size_t lds, bool tall)
 {
     init_solve_lds();
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    const void* fn = tall ? reinterpret_cast<const void*>(k_top_solve<1024, 4, 4>) : reinterpret_cast<const void*>(k_top_solve<512, 7, 7>);
-    const hipError_t e = tall ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<1024, 4, 4>, 1024, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<512, 7, 7>, 512, lds);
+    const void* fn = tall ? reinterpret_cast<const void*>(k_top_solve<1024, 4, 4, 1>) : reinterpret_cast<const void*>(k_top_solve<512, 7, 7, 1>);
+    const hipError_t e = tall ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<1024, 4, 4, 1>, 1024, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<512, 7, 7, 1>, 512, lds);
     if (e != hipSuccess) return 0;
     // Either build has ONE workgroup per CU resident: the 1024-thread one fills a CU's wave slots at 128 VGPRs, the
     // 512-thread one is built for 2 waves per SIMD (~177 VGPRs).  (Measured: a 128-VGPR 512-thread build with two
@@ -1843,15 +1965,31 @@ int top_solve_capacity(size_t lds, bool tall)
     per_cu = per_cu > 3 ? 3 : per_cu;
     return (int)(per_cu * prop.multiProcessorCount * 0.94);
 }
+// the NR-column instances may need more registers than the one the capacity was asked for: ask each of them once
+int top_solve_capacity_nr(size_t lds_total, int nr)
+{
+    init_solve_lds();
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    hipError_t e;
+    if (nr == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<1024, 4, 4, 1>, 1024, lds_total);
+    else if (nr == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<1024, 4, 4, 2>, 1024, lds_total);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve<1024, 4, 4, 4>, 1024, lds_total);
+    if (e != hipSuccess) return 0;
+    per_cu = per_cu > 3 ? 3 : per_cu;
+    return (int)(per_cu * prop.multiProcessorCount * 0.94);
+}
 void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
-                      hipStream_t st, bool tall)
+                      hipStream_t st, bool tall, int nr)
 {
     if (count <= 0 || grid <= 0 || nflag < count) return;
     init_solve_lds();
-    if (tall)
-        hipLaunchKernelGGL((k_top_solve<1024, 4, 4>), dim3(std::min(grid, count)), dim3(1024), lds, st, a, begin, flags, epoch, count, nflag);
+    if (tall || nr > 1)
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_top_solve<1024, 4, 4, NR>), dim3(std::min(grid, count)), dim3(1024), lds * NR, st, a,
+                                                 begin, flags, epoch, count, nflag));
     else
-        hipLaunchKernelGGL((k_top_solve<512, 7, 7>), dim3(std::min(grid, count)), dim3(512), lds, st, a, begin, flags, epoch, count, nflag);
+        hipLaunchKernelGGL((k_top_solve<512, 7, 7, 1>), dim3(std::min(grid, count)), dim3(512), lds, st, a, begin, flags, epoch, count, nflag);
 }
 int top_solve_sliced_capacity(size_t lds)
 {

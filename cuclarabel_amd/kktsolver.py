@@ -114,6 +114,17 @@ class HipKKTSolver:
                                                      C.c_void_p(d_lhsz) if d_lhsz else None),
                      "hipkkt_kkt_solve_dev")
 
+    def set_deferred_status(self, on=True):
+        """The *_dev entry points only enqueue; `deferred_status()` reports once for everything since the last query."""
+        check(_lib.lib().hipkkt_kkt_set_deferred_status(self._h, int(on)), "hipkkt_kkt_set_deferred_status")
+
+    def deferred_status(self):
+        """0 = every call since the last query succeeded, 1 = numeric failure, 2 = some solve's refinement was cut short."""
+        rc = _lib.lib().hipkkt_kkt_deferred_status(self._h)
+        if rc < 0:
+            check(rc, "hipkkt_kkt_deferred_status")
+        return rc
+
     def kktsolver_solve_multi(self, rhsx, rhsz, want_x=True, want_z=True):
         """setrhs! + solve! for several right-hand sides against the current factorisation.
         rhsx: (n, k), rhsz: (m, k).  Returns (is_success, lhsx (n, k) | None, lhsz (m, k) | None,

@@ -39,6 +39,7 @@ extern "C" {
 
 #define HIPKKT_OK 0
 #define HIPKKT_NUMERIC_FAILURE 1
+#define HIPKKT_REFINEMENT_INCOMPLETE 2   /* hipkkt_kkt_deferred_status only */
 #define HIPKKT_ERR_ARG (-1)
 #define HIPKKT_ERR_HIP (-2)
 #define HIPKKT_ERR_INTERNAL (-3)
@@ -166,6 +167,18 @@ int hipkkt_kkt_setrhs(hipkkt_kkt_t h, const double *rhsx, const double *rhsz);
 int hipkkt_kkt_solve(hipkkt_kkt_t h, double *lhsx, double *lhsz);
 int hipkkt_kkt_setrhs_dev(hipkkt_kkt_t h, const double *d_rhsx, const double *d_rhsz);
 int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double *d_lhsx, double *d_lhsz);
+/* Deferred status (no counterpart in the reference, whose calls are synchronous): with defer = 1 the device-pointer
+ * entry points hipkkt_kkt_update_from_sz_dev and hipkkt_kkt_solve_dev only ENQUEUE their work and return 0 at once;
+ * what they would have returned is accumulated on the device.  The refinement loop's accept / stop decisions
+ * (kktsolver_directldl.jl:389-449) are taken on the device either way; in this mode a solve runs as many refinement
+ * rounds ahead as the previous solves on the handle needed (at least one).  hipkkt_kkt_deferred_status synchronises,
+ * returns the worst status since the previous query and clears it: 0, HIPKKT_NUMERIC_FAILURE (some pivot, cone point
+ * or residual was not finite), or HIPKKT_REFINEMENT_INCOMPLETE (some solve stopped while the reference's loop would
+ * have gone on: its result is the last accepted iterate; later solves run one more round ahead -- repeat the step,
+ * or call hipkkt_kkt_solve_dev with defer = 0, for the reference's exact loop).  A caller issues a whole iteration's
+ * update + solves and asks once. */
+int hipkkt_kkt_set_deferred_status(hipkkt_kkt_t h, int defer);
+int hipkkt_kkt_deferred_status(hipkkt_kkt_t h);
 /* kktsolver_setrhs! + kktsolver_solve! for nrhs right-hand sides at once (SURVEY.md 8b
  * "hipkkt_kkt_solve_multi"): rhsx n x nrhs, rhsz m x nrhs, column-major, contiguous; lhsx / lhsz
  * likewise, either may be NULL.  Every column goes through the reference's refinement rule on its

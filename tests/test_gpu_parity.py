@@ -801,3 +801,118 @@ def test_psd_scaling_on_ill_conditioned_pairs_matches_oracle():
         scale = max(np.abs(xo).max(), np.abs(zo).max())
         assert max(np.abs(x - xo).max(), np.abs(zz - zo).max()) / scale < 1e-9
         assert ks.last_ir_iterations == o.last_ir_iters
+
+
+def test_deferred_status_mode_matches_synchronous_calls():
+    """hipkkt_kkt_set_deferred_status: update_from_sz_dev / solve_dev only enqueue, the refinement decisions are taken on
+    the device, one status query reports for all of them.  Results must be bit-identical to the synchronous calls, a
+    numeric failure must surface at the query, and a solve whose refinement was cut short must be flagged (and the
+    next ones run further ahead)."""
+    import torch
+    _lib, HipKKTSolver, _ = _hip()
+    pb = problems.config2(n=3000)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    rhs = [(rng.standard_normal(pb.n), rng.standard_normal(pb.m)) for _ in range(3)]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ds, dz = d(pb.s0), d(pb.z0)
+    drhs = [(d(a), d(b)) for a, b in rhs]
+
+    def run(ks, deferred):
+        ks.set_deferred_status(deferred)
+        outs = []
+        assert ks.kktsolver_update_from_sz_dev(ds.data_ptr(), dz.data_ptr())
+        for rx, rz in drhs:
+            lx = torch.zeros(pb.n, dtype=torch.float64, device=dev)
+            lz = torch.zeros(pb.m, dtype=torch.float64, device=dev)
+            ks.kktsolver_setrhs_dev(rx.data_ptr(), rz.data_ptr())
+            assert ks.kktsolver_solve_dev(lx.data_ptr(), lz.data_ptr())
+            outs.append((lx, lz))
+        rc = ks.deferred_status() if deferred else 0
+        return rc, [np.concatenate([a.cpu().numpy(), b.cpu().numpy()]) for a, b in outs]
+
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    rc0, ref = run(ks, False)
+    rounds_sync = ks.last_ir_iterations
+    for _ in range(2):
+        rc, out = run(ks, True)
+        assert rc == _lib.OK
+        for a, b in zip(out, ref):
+            np.testing.assert_array_equal(a, b)
+    assert ks.last_ir_iterations == rounds_sync                      # mean rounds per solve, same as each sync solve took
+    o = _oracle_for(pb, ks)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    o.kktsolver_setrhs(*rhs[2])
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok and np.abs(ref[2] - np.concatenate([xo, zo])).max() / np.abs(xo).max() < 1e-9
+    # a numeric failure surfaces at the query, not at the call
+    zbad = pb.z0.copy(); zbad[7] = np.nan
+    dzb = d(zbad)
+    ks.set_deferred_status(True)
+    assert ks.kktsolver_update_from_sz_dev(ds.data_ptr(), dzb.data_ptr())
+    assert ks.deferred_status() == _lib.NUMERIC_FAILURE
+    assert ks.deferred_status() == _lib.OK                           # the record is cleared by the query
+    # tolerances nobody meets: the reference's loop goes on until the residual stops shrinking by 5x -- more than
+    # the one round a fresh handle runs ahead -> flagged; later solves run further ahead and agree with the sync loop
+    st = _lib.default_settings(iterative_refinement_reltol=1e-30, iterative_refinement_abstol=1e-30)
+    k2 = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
+    rc0, ref2 = run(k2, False)
+    need = k2.last_ir_iterations
+    k3 = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
+    seen = []
+    for _ in range(need + 2):
+        rc, out = run(k3, True)
+        seen.append(rc)
+        if rc == _lib.OK:
+            break
+    assert seen[-1] == _lib.OK and (need <= 1 or seen[0] == _lib.REFINEMENT_INCOMPLETE), (need, seen)
+    for a, b in zip(out, ref2):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 8])
+def test_small_batches_share_sweeps_and_match_single_solves(k):
+    """2 .. 8 right-hand sides go through the single-column kernels' 2- and 4-column instances (one sweep for up to
+    four columns, the persistent top-of-tree kernel included): every column must end exactly where its own single
+    solve ends -- same refinement decisions -- and agree with the oracle; in deferred-status mode too."""
+    import torch
+    _lib, HipKKTSolver, _ = _hip()
+    pb = problems.config2(n=6000)
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    o = _oracle_for(pb, ks)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    rng = np.random.default_rng(100 + k)
+    RX, RZ = rng.standard_normal((pb.n, k)), rng.standard_normal((pb.m, k))
+    RX[:, 1] *= 1e5; RZ[:, 1] *= 1e5
+    ks.kktsolver_setrhs(np.ones(pb.n), np.ones(pb.m))              # must survive the batch call
+    ok, LX, LZ, ir = ks.kktsolver_solve_multi(RX, RZ)
+    assert ok
+    x1, z1 = np.zeros(pb.n), np.zeros(pb.m)
+    assert ks.kktsolver_solve(x1, z1)
+    o.kktsolver_setrhs(np.ones(pb.n), np.ones(pb.m))
+    _, xo1, zo1 = o.kktsolver_solve()
+    assert max(np.abs(x1 - xo1).max(), np.abs(z1 - zo1).max()) / max(np.abs(xo1).max(), np.abs(zo1).max()) < 1e-9
+    for j in range(k):
+        ks.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        np.testing.assert_array_equal(LX[:, j], x)                  # same kernels' arithmetic per column: bit-identical
+        np.testing.assert_array_equal(LZ[:, j], z)
+        assert int(ir[j]) == ks.last_ir_iterations
+        o.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        oko, xo, zo = o.kktsolver_solve()
+        so = max(np.abs(xo).max(), np.abs(zo).max())
+        assert oko and max(np.abs(x - xo).max(), np.abs(z - zo).max()) / so < 1e-9
+        assert ks.last_ir_iterations == o.last_ir_iters
+    # device pointers, deferred status
+    dev = torch.device("cuda", 0)
+    dd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    drx, drz = dd(RX.T), dd(RZ.T)
+    dlx = torch.zeros(k, pb.n, dtype=torch.float64, device=dev)
+    dlz = torch.zeros(k, pb.m, dtype=torch.float64, device=dev)
+    ks.set_deferred_status(True)
+    ok, _ = ks.kktsolver_solve_multi_dev(k, drx.data_ptr(), drz.data_ptr(), dlx.data_ptr(), dlz.data_ptr())
+    assert ok and ks.deferred_status() == _lib.OK
+    np.testing.assert_array_equal(dlx.cpu().numpy().T, LX)
+    np.testing.assert_array_equal(dlz.cpu().numpy().T, LZ)
