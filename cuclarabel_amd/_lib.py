@@ -99,6 +99,8 @@ SYMBOLS = {
     "hipkkt_kkt_system_solve_initial_point": (C.c_int, [_P, _P, _P, _P]),
     "hipkkt_kkt_system_solve": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                           _P, _P, _P, C.c_double, C.c_double, C.c_int]),
+    "hipkkt_kkt_system_update_and_solve_affine": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
+                                                            _P, _P, _P, C.c_double, C.c_double]),
     "hipkkt_equilibrate": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P,
                                      C.c_int32, C.c_double, C.c_double, _P, _P, _P, C.c_int, C.c_int]),
     "hipkkt_scale_matrix_values": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_int, C.c_int]),

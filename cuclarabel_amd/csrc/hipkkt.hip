@@ -2364,19 +2364,13 @@ static int sys_solve_into(hipkkt_kkt_t h, const double* rx, const double* rz, do
     return HIPKKT_OK;
 }
 
+static void sys_cache_constant_terms(hipkkt_kkt_t h);
 static int sys_constant_rhs(hipkkt_kkt_t h)
 {
     // _kkt_solve_constant_rhs! (kktsystem.jl:80-92): (x2, z2) = K \ (-q, b)
     int rc = sys_solve_into(h, h->snegq.p, h->sb.p, h->sx2.p, h->sz2.p);
     if (rc != HIPKKT_OK) return rc;
-    // the x2-only terms of tau_den (kktsystem.jl:194-196) are the same for both solves of the iteration
-    launch_P_spmv(sys_spmv(h), h->Kval.p, h->sx2.p, h->spa.p, h->K.n, h->stream);
-    DotPairs P{};
-    P.npairs = 3;
-    P.a[0] = h->sq.p; P.b[0] = h->sx2.p; P.len[0] = h->K.n;
-    P.a[1] = h->sb.p; P.b[1] = h->sz2.p; P.len[1] = h->K.m;
-    P.a[2] = h->sx2.p; P.b[2] = h->spa.p; P.len[2] = h->K.n;
-    launch_dots(P, h->sys_partial.p, h->sys_cached.p, h->stream);
+    sys_cache_constant_terms(h);
     return HIPKKT_OK;
 }
 
@@ -2425,6 +2419,46 @@ int hipkkt_kkt_system_solve_initial_point(hipkkt_kkt_t h, double* d_x, double* d
     });
 }
 
+// the part of kkt_solve! behind the solve for (x1, z1) (kktsystem.jl:175-212): dtau, (dx, dz), ds, dkappa
+static void sys_finish_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,
+                            double rhs_tau, double rhs_kappa, const double* d_var_x, double var_tau, double var_kappa)
+{
+    const int n = h->K.n, m = h->K.m;
+    hipStream_t st = h->stream;
+    const double sc_in[4] = {rhs_tau, rhs_kappa, var_tau, var_kappa};
+    HIP_CHECK(hipMemcpyAsync(h->sys_in.p, sc_in, sizeof(sc_in), hipMemcpyHostToDevice, st));
+    launch_P_spmv(sys_spmv(h), h->Kval.p, h->sx1.p, h->spa.p, n, st);                          // P x1
+    launch_sys_axpby(h->sworkx.p, d_var_x, h->sys_in.p + 2, h->sx2.p, nullptr, -1.0, n, st);   // xi - x2
+    launch_P_spmv(sys_spmv(h), h->Kval.p, h->sworkx.p, h->spb.p, n, st);                       // P (xi - x2)
+    DotPairs P{};
+    P.npairs = 4;
+    P.a[0] = h->sq.p; P.b[0] = h->sx1.p; P.len[0] = n;
+    P.a[1] = h->sb.p; P.b[1] = h->sz1.p; P.len[1] = m;
+    P.a[2] = d_var_x; P.b[2] = h->spa.p; P.len[2] = n;
+    P.a[3] = h->sworkx.p; P.b[3] = h->spb.p; P.len[3] = n;
+    launch_dots(P, h->sys_partial.p, h->sys_dots.p, st);
+    launch_sys_scalars(h->sys_dots.p, h->sys_cached.p, h->sys_in.p, h->sys_out.p, st);
+    // (dx, dz) = (x1, z1) + dtau (x2, z2)                                 (:200-203)
+    launch_sys_axpby(d_lhs_x, h->sx1.p, nullptr, h->sx2.p, h->sys_out.p, 0.0, n, st);
+    launch_sys_axpby(d_lhs_z, h->sz1.p, nullptr, h->sz2.p, h->sys_out.p, 0.0, m, st);
+    // ds = -(Hs dz + const)                                               (:206-212)
+    launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st);
+    launch_neg_sum(d_lhs_s, d_lhs_s, h->sconic.p, m, st);
+    HIP_CHECK(hipMemcpyAsync(lhs_tau_kappa, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));            // also keeps sc_in alive for its copy
+}
+// the x2-only terms of tau_den (kktsystem.jl:194-196) are the same for both solves of the iteration
+static void sys_cache_constant_terms(hipkkt_kkt_t h)
+{
+    launch_P_spmv(sys_spmv(h), h->Kval.p, h->sx2.p, h->spa.p, h->K.n, h->stream);
+    DotPairs P{};
+    P.npairs = 3;
+    P.a[0] = h->sq.p; P.b[0] = h->sx2.p; P.len[0] = h->K.n;
+    P.a[1] = h->sb.p; P.b[1] = h->sz2.p; P.len[1] = h->K.m;
+    P.a[2] = h->sx2.p; P.b[2] = h->spa.p; P.len[2] = h->K.n;
+    launch_dots(P, h->sys_partial.p, h->sys_cached.p, h->stream);
+}
+
 int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,
                             const double* d_rhs_x, const double* d_rhs_s, const double* d_rhs_z, double rhs_tau,
                             double rhs_kappa, const double* d_var_x, const double* d_var_s, const double* d_var_z,
@@ -2447,28 +2481,49 @@ int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, do
         // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
         int rc = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
         if (rc != HIPKKT_OK) return rc;
-        // dtau (:176-199)
-        const double sc_in[4] = {rhs_tau, rhs_kappa, var_tau, var_kappa};
-        HIP_CHECK(hipMemcpyAsync(h->sys_in.p, sc_in, sizeof(sc_in), hipMemcpyHostToDevice, st));
-        launch_P_spmv(sys_spmv(h), h->Kval.p, h->sx1.p, h->spa.p, n, st);                          // P x1
-        launch_sys_axpby(h->sworkx.p, d_var_x, h->sys_in.p + 2, h->sx2.p, nullptr, -1.0, n, st);   // xi - x2
-        launch_P_spmv(sys_spmv(h), h->Kval.p, h->sworkx.p, h->spb.p, n, st);                       // P (xi - x2)
-        DotPairs P{};
-        P.npairs = 4;
-        P.a[0] = h->sq.p; P.b[0] = h->sx1.p; P.len[0] = n;
-        P.a[1] = h->sb.p; P.b[1] = h->sz1.p; P.len[1] = m;
-        P.a[2] = d_var_x; P.b[2] = h->spa.p; P.len[2] = n;
-        P.a[3] = h->sworkx.p; P.b[3] = h->spb.p; P.len[3] = n;
-        launch_dots(P, h->sys_partial.p, h->sys_dots.p, st);
-        launch_sys_scalars(h->sys_dots.p, h->sys_cached.p, h->sys_in.p, h->sys_out.p, st);
-        // (dx, dz) = (x1, z1) + dtau (x2, z2)                                 (:200-203)
-        launch_sys_axpby(d_lhs_x, h->sx1.p, nullptr, h->sx2.p, h->sys_out.p, 0.0, n, st);
-        launch_sys_axpby(d_lhs_z, h->sz1.p, nullptr, h->sz2.p, h->sys_out.p, 0.0, m, st);
-        // ds = -(Hs dz + const)                                               (:206-212)
-        launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st);
-        launch_neg_sum(d_lhs_s, d_lhs_s, h->sconic.p, m, st);
-        HIP_CHECK(hipMemcpyAsync(lhs_tau_kappa, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));            // also keeps sc_in alive for its copy
+        sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_system_update_and_solve_affine(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z,
+                                              double* lhs_tau_kappa, const double* d_rhs_x, const double* d_rhs_z,
+                                              double rhs_tau, double rhs_kappa, const double* d_var_x, const double* d_var_s,
+                                              const double* d_var_z, double var_tau, double var_kappa)
+{
+    // kkt_update! (kktsystem.jl:62-78): scaling, refactor ...
+    int rc = hipkkt_kkt_update_from_sz_dev(h, d_var_s, d_var_z);
+    if (rc != HIPKKT_OK) return rc;
+    return guarded([&]() {
+        if (!h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
+        const int n = h->K.n, m = h->K.m;
+        if ((n && (!d_lhs_x || !d_rhs_x || !d_var_x)) || (m && (!d_lhs_s || !d_lhs_z || !d_rhs_z)) || !lhs_tau_kappa)
+            throw ArgError("hipkkt_kkt_system_update_and_solve_affine: bad argument");
+        if (h->deferred) throw ArgError("hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        if (!h->eng->supports_nr(2)) {
+            // one right-hand side per sweep on this structure: the two calls one after the other
+            int rc2 = sys_constant_rhs(h);
+            if (rc2 != HIPKKT_OK) return rc2;
+            launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, d_var_s, d_var_z, d_rhs_z, m, true, st);
+            rc2 = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
+            if (rc2 != HIPKKT_OK) return rc2;
+            sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
+            return HIPKKT_OK;
+        }
+        // ... then _kkt_solve_constant_rhs! (:80-92) and the affine kkt_solve! (:145-173) as ONE 2-column solve:
+        // column 0 = (-q, b), column 1 = (rhs.x, s - rhs.z) (the affine step's Delta_s constant term is variables.s, :157-158)
+        launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, d_var_s, d_var_z, d_rhs_z, m, true, st);
+        const size_t N = (size_t)h->K.N;
+        launch_pack_rhs(h->b.p, h->snegq.p, h->sb.p, n, m, h->K.p, st);
+        launch_pack_rhs(h->b.p + N, d_rhs_x, h->sworkz.p, n, m, h->K.p, st);
+        int rc2 = kkt_solve_core(h, false, 2, nullptr);
+        if (rc2 != HIPKKT_OK) return rc2;
+        launch_unpack_lhs(h->sx2.p, h->sz2.p, h->x.p, n, m, st);
+        launch_unpack_lhs(h->sx1.p, h->sz1.p, h->x.p + N, n, m, st);
+        sys_cache_constant_terms(h);
+        sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
         return HIPKKT_OK;
     });
 }

@@ -556,7 +556,16 @@ def solve(P, q, A, b, cone_specs, backend, settings=None):
             status = NUMERICAL_ERROR
             break
         it += 1
-        if system is not None:
+        aff_step = None
+        if system is not None and getattr(backend, "batch_affine", False):
+            # kkt_update! and the affine kkt_solve! as ONE call: the constant and the affine right-hand side do not
+            # depend on each other (kktsystem.jl:87-88 vs :170-171; the affine step does not read rhs.s, :157-158),
+            # so their solves share every triangular sweep
+            ok, aff_step = system.update_and_solve_affine(rx, rz, rtau, tau * kappa, x, s, z, tau, kappa)
+            ir_total += backend.last_ir_iterations
+            if ok and any(isinstance(c, _PSD) and c.n for c in cones):
+                adopt_device_scaling(cones, backend.ks.scaling()[1])
+        elif system is not None:
             ok = system.update(s, z)                   # kkt_update!: scaling, refactor, constant-RHS solve
             # The scaled space of a PSD cone is fixed only up to the signs of the singular vectors of L2'L1.  With the
             # reduced system on the device, ITS scaling is the one the right-hand sides must be expressed in (in the
@@ -603,7 +612,10 @@ def solve(P, q, A, b, cone_specs, backend, settings=None):
         step = None
         if ok:
             aff_s = each(lambda c, v: c.affine_ds(v), s)
-            ok, step = kkt_solve(rx, rz, aff_s, rtau, tau * kappa, True)
+            if aff_step is not None:
+                step = aff_step
+            else:
+                ok, step = kkt_solve(rx, rz, aff_s, rtau, tau * kappa, True)
         if ok:
             dx, dz, ds, dtau, dkappa = step
             alpha = step_length(dz, ds, dtau, dkappa, False)
@@ -690,7 +702,8 @@ class HipSystemBackend(HipBackend):
     """As HipBackend, but the reduced-system layer (kktsystem.jl) runs on the device too (level C of the
     C ABI): the driver hands over iterates and right-hand sides and gets the step back."""
 
-    def __init__(self, P, A, cone_specs, settings=None):
+    def __init__(self, P, A, cone_specs, settings=None, batch_affine=False):
         super().__init__(P, A, cone_specs, settings=settings)
         from .kktsolver import HipKKTSystem
         self.system = HipKKTSystem(self.ks)
+        self.batch_affine = batch_affine           # kkt_update! + affine kkt_solve! as one 2-column solve

@@ -299,6 +299,26 @@ class HipKKTSystem:
         ds, dz = self._dev(s), self._dev(z)
         return self.update_dev(ds.data_ptr(), dz.data_ptr())
 
+    def update_and_solve_affine(self, rhs_x, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa):
+        """kkt_update! + kkt_solve!(:affine) in one call: the constant and the affine right-hand side share one
+        2-column solve (hipkkt_kkt_system_update_and_solve_affine).  Returns (is_success, step | None)."""
+        import torch
+        dev = self._devstr
+        n, m = self.ks.n, self.ks.m
+        rhs = [self._dev(rhs_x), self._dev(rhs_z)]
+        var = [self._dev(x), self._dev(s), self._dev(z)]
+        lhs = [torch.zeros(max(k, 1), dtype=torch.float64, device=dev) for k in (n, m, m)]
+        tk = np.zeros(2)
+        ok = check(_lib.lib().hipkkt_kkt_system_update_and_solve_affine(
+            self.ks._h, C.c_void_p(lhs[0].data_ptr()), C.c_void_p(lhs[1].data_ptr()), C.c_void_p(lhs[2].data_ptr()), ptr(tk),
+            C.c_void_p(rhs[0].data_ptr()), C.c_void_p(rhs[1].data_ptr()), float(rhs_tau), float(rhs_kappa),
+            C.c_void_p(var[0].data_ptr()), C.c_void_p(var[1].data_ptr()), C.c_void_p(var[2].data_ptr()), float(tau), float(kappa)),
+            "hipkkt_kkt_system_update_and_solve_affine")
+        if not ok:
+            return False, None
+        dx, ds, dz = lhs[0][:n].cpu().numpy(), lhs[1][:m].cpu().numpy(), lhs[2][:m].cpu().numpy()
+        return True, (dx, dz, ds, float(tk[0]), float(tk[1]))
+
     def solve_initial_point(self):
         import torch
         dev = self._devstr

@@ -215,6 +215,17 @@ int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double *d_lhs_x, double *d_lhs_s, do
                             const double *d_var_x, const double *d_var_s, const double *d_var_z,
                             double var_tau, double var_kappa, int steptype);
 
+/* kkt_update! followed by the affine kkt_solve! in ONE call (kktsystem.jl:62-92 and :145-215 with steptype :affine).
+ * The constant right-hand side (-q, b) of kkt_update! and the affine right-hand side (rhs.x, s - rhs.z) do not depend on
+ * each other, so their two solves share every triangular sweep (one 2-column solve with per-column refinement).  Same
+ * results as hipkkt_kkt_system_update(h, d_var_s, d_var_z) followed by hipkkt_kkt_system_solve(..., steptype 0); the
+ * affine step does not read rhs.s (:157-158). */
+int hipkkt_kkt_system_update_and_solve_affine(hipkkt_kkt_t h, double *d_lhs_x, double *d_lhs_s, double *d_lhs_z,
+                                              double *lhs_tau_kappa, const double *d_rhs_x, const double *d_rhs_z,
+                                              double rhs_tau, double rhs_kappa,
+                                              const double *d_var_x, const double *d_var_s, const double *d_var_z,
+                                              double var_tau, double var_kappa);
+
 /* ------------------------------------------- problem-data scaling (before the KKT solver is built)
  * data_equilibrate! (/root/reference/src/problemdata.jl:133-221): Ruiz equilibration of
  * [P A'; A 0], q, b on the device.  P: n x n upper-triangular CSC,

@@ -102,6 +102,47 @@ def test_reference_known_answers_with_device_resident_kkt_system(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ALL))
+def test_reference_known_answers_with_batched_constant_and_affine_solves(name):
+    """Level C with kkt_update! and the affine kkt_solve! as one call: the constant and the affine right-hand side
+    go through the triangular sweeps together (one 2-column solve per iteration).  Same
+    known answers, same iteration count, same iterates as the call-by-call sequence."""
+    P, q, A, b, cones, exp = ALL[name]()
+    res = ipm.solve(P, q, A, b, cones, ipm.HipSystemBackend(P, A, cones, batch_affine=True))
+    _check(res, exp)
+    ref = ipm.solve(P, q, A, b, cones, ipm.HipSystemBackend(P, A, cones))
+    assert res.iterations == ref.iterations
+    if exp["status"] == "SOLVED":
+        np.testing.assert_allclose(res.x, ref.x, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_batched_update_and_affine_solve_equals_the_two_calls():
+    """hipkkt_kkt_system_update_and_solve_affine against hipkkt_kkt_system_update + hipkkt_kkt_system_solve(:affine) on
+    a problem with every cone kind: the step must agree to round-off (the 2-column sweep runs the same arithmetic per column)."""
+    from cuclarabel_amd import problems
+    from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+    pb = problems.small_mixed(seed=43, psds=(2, 3, 6), socs=(3, 4, 6, 15))
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal(pb.n)
+    rhs_x, rhs_z = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    out = []
+    for batched in (False, True):
+        ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+        system = HipKKTSystem(ks)
+        system.init(pb.q, pb.b)
+        if batched:
+            ok, step = system.update_and_solve_affine(rhs_x, rhs_z, 0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+        else:
+            assert system.update(pb.s0, pb.z0)
+            ok, step = system.solve(rhs_x, pb.s0, rhs_z, 0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7, True)
+        assert ok
+        out.append(step)
+    for a, bb in zip(out[0], out[1]):
+        np.testing.assert_allclose(a, bb, rtol=1e-12, atol=1e-12 * max(1.0, float(np.max(np.abs(a)))))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("affine", [True, False])
 def test_device_kkt_solve_matches_host_algebra(affine):
     """kkt_solve! (kktsystem.jl:145-215) on the device against the same formulas in numpy with host cone
