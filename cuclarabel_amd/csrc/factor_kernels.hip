@@ -18,6 +18,7 @@
 // Loads are issued in explicit batches before first use: a one-load-then-use loop serialises
 // on HBM/L2 latency (the first version of these kernels ran 10x slower for that reason).
 #include "kernels.hpp"
+#include <utility>
 
 namespace hipkkt {
 
@@ -331,6 +332,22 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
     }
 }
 
+// lane K of each 16-lane row to every lane of that row (DPP row_newbcast, gfx90a+; two 32-bit moves: the 64-bit DPP
+// forms exist on gfx950 but were measured at ~1/16 rate).  K must be a compile-time constant after unrolling.
+#define HIPKKT_BCAST16_CASE(K) case K: lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false); \
+                                       hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false); break;
+__device__ __forceinline__ double bcast16(double v, const int k)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (k) {
+        HIPKKT_BCAST16_CASE(0) HIPKKT_BCAST16_CASE(1) HIPKKT_BCAST16_CASE(2) HIPKKT_BCAST16_CASE(3)
+        HIPKKT_BCAST16_CASE(4) HIPKKT_BCAST16_CASE(5) HIPKKT_BCAST16_CASE(6) HIPKKT_BCAST16_CASE(7)
+        HIPKKT_BCAST16_CASE(8) HIPKKT_BCAST16_CASE(9) HIPKKT_BCAST16_CASE(10) HIPKKT_BCAST16_CASE(11)
+        HIPKKT_BCAST16_CASE(12) HIPKKT_BCAST16_CASE(13) HIPKKT_BCAST16_CASE(14) HIPKKT_BCAST16_CASE(15)
+    }
+    return __hiloint2double(hi, lo);
+}
+
 // SLICED: a panel too tall for one CU's LDS is cut into ROW slices, one workgroup each (TreeDev::sdesc).  Every slice
 // holds the top nc x nc block plus its share of the rows below and factors the top block itself, so the slices
 // never talk to each other: the diagonal blocks are computed redundantly (they sit on every slice's critical path
@@ -343,6 +360,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
+    constexpr int NWK = NW - NW / 4;                               // worker waves of the block loop (not on wave 0's SIMD)
+    const int widx = wv - 1 - (wv >> 2);                           // this wave's index among them (wv % 4 != 0)
     const TreeDev& T = A.T;
     const FrontDesc fd = SLICED ? T.sdesc[begin + blockIdx.x] : T.desc[begin + blockIdx.x];
     const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
@@ -360,7 +379,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     double* sh_d_all = smem;                      // 2 x NB
     double* sh_dinv_all = smem + 2 * NB;          // 2 x NB
     double* Lb_all = smem + 4 * NB;               // 2 x NB x NB: Lb[j*NB + t] = d_t * L(j,t), t < j
-    double* colb = smem + 4 * NB + 2 * NB * NB;   // 4*NB: the diagonal step's broadcast buffer (wave 0 only)
+    double* colb = smem + 4 * NB + 2 * NB * NB;   // 4*NB (spare)
     double* sgn = colb + 4 * NB;                  // kBdCols + NB: expected pivot signs of this front's columns
     int* lds_cnt = reinterpret_cast<int*>(sgn + kBdCols + NB);   // (2 doubles) arrival counter of the in-block barrier
     double* P = sgn + kBdCols + NB + 2;           // f x nc, ld f (+ 256 doubles of slack behind it)
@@ -421,41 +440,57 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     }
     HIPKKT_STAMP(A, 3);
     long long t_i = 0, t_ii = 0, t_iii = 0, t0 = 0;
-    // the 16 x 16 diagonal block kb (see (i) below) as a callable: with look-ahead it runs on wave 0 while the
-    // other waves finish the trailing update of the previous block
+    // The 16 x 16 diagonal block kb as a callable: with look-ahead it runs on wave 0 while the other waves finish the
+    // trailing update of the previous block.  ROW PER LANE: lane i (< 16) keeps row i of the block in 16 registers and,
+    // beside it, row i of T = L_bb^{-1} (unit lower), built by the same row operations.  Pivot by pivot, fully
+    // unrolled: the pivot, the entries a(j, k) of the pivot column and the entries T(k, c) of T's pivot row come out of
+    // their owners' registers as scalar broadcasts (v_readlane) -- no LDS round trip anywhere on the pivot chain, and
+    // the reciprocal of the next pivot can start as soon as its entry is updated.  Same operation order per entry as
+    // the scalar algorithm; QDLDL's sign rule at pivot time.  T lets every wave turn its rows' substitution against
+    // the block into one 16 x 16 x 16 matrix product (trsm_tile below).
     auto diag_block = [&](const int kb, const int w, const int par) {
         double* sh_d = sh_d_all + par * NB;
         double* sh_dinv = sh_dinv_all + par * NB;
-        double* Lb = Lb_all + par * NB * NB;
-        // Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3).  Pivot by pivot, fully unrolled: the lanes
-        // owning column k put it into LDS, every lane reads back its row's entry, the entries of its own four
-        // columns' rows and the pivot (one LDS round trip per pivot, ~35 dependent instructions), while the
-        // reciprocal of the pivot is formed beside it.  Same operation order per entry as the scalar algorithm.
+        double* Tb = Lb_all + par * NB * NB;         // Tb[i * NB + c] = T(i, c), T = L_bb^{-1}
+        // Lane (i = lane & 15, g = lane >> 4) holds a(i, 4g .. 4g+3) and, beside it, T(i, 4g .. 4g+3): T = L_bb^{-1}
+        // (unit lower) is built by the same row operations, T(i, :) -= l_i T(k, :), whose pivot row comes from lane
+        // (k, g) of the SAME 16-lane row by a DPP row broadcast (row_newbcast, gfx90a+) -- no LDS, no scalar registers.
+        // T turns every wave's substitution of its rows against the block into one 16 x 16 x 16 product (trsm_tile).
+        // Pivot by pivot, fully unrolled: every lane puts its entry of its group's pivot-column candidate into LDS
+        // (slot g * 16 + i: no lane mask), every lane reads back its row's entry and the entries of its own four
+        // columns' rows from the pivot column's group -- one LDS round trip per pivot -- while the pivot comes straight
+        // out of its owner's register (scalar broadcast) and its reciprocal is formed beside the trip.  This wave is
+        // alone on the serial chain and bound by its own instruction issue, so the step is written for few
+        // instructions: no operation is guarded by "column already finished" (finished columns of a4 / zero parts of T
+        // are simply never read again), and the lane id is made opaque per step so that the compiler computes the two
+        // lane conditions where they are used instead of keeping 16 x 3 precomputed masks alive in (spilled) SGPRs.
+        // Same operation order per live entry as the scalar algorithm; QDLDL's sign rule at pivot time.
+        int lane_o = lane;
         const int i = lane & 15, g = lane >> 4;
         const double my_sg = (lane < w) ? sgn[kb + lane] : 1.0;      // lane k: expected sign of pivot k
         int nreg = 0;
         bool bad = false;
-        double a4[4], lout[4], vout[4];
+        double a4[4], lout[4], t4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = 4 * g + q;
             a4[q] = (i < w && j <= i) ? P[(kb + i) + pcol(kb + j, f)] : 0.0;
             lout[q] = 0.0;
-            vout[q] = 0.0;
+            t4[q] = (j == i) ? 1.0 : 0.0;
         }
-        double dmine = 1.0, dimine = 1.0;                            // lane k keeps d_k and 1 / d_k
         const double inv_delta = 1.0 / A.dyn_delta;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             if (k < w) {
+                asm volatile("" : "+v"(lane_o));
+                const int io = lane_o & 15, go = lane_o >> 4;
                 const int gk = k >> 2, qk = k & 3;
-                double* cb = colb + (k & 1) * NB;                     // two buffers: no wait between pivots
-                if (g == gk) cb[i] = a4[qk];
+                colb[lane_o] = a4[qk];                                // (one wave: its LDS operations execute in order)
                 WAVE_FENCE();
-                const double ci = cb[i];
+                const double ci = colb[gk * NB + io];
                 double cj[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) cj[t] = cb[4 * g + t];
+                for (int t = 0; t < 4; ++t) cj[t] = colb[gk * NB + 4 * go + t];
                 WAVE_FENCE();
                 // the pivot comes straight out of its owner's register (scalar broadcast), so its reciprocal is
                 // under way while the column is still on its way through LDS
@@ -468,31 +503,32 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 nreg += reg ? 1 : 0;
                 bad = bad || !isfinite(di);
                 const double li = ci * di;
-                if (g == gk) {
-                    if (i > k) { lout[qk] = li; vout[qk] = ci; }
-                    else if (i == k) lout[qk] = d;
-                }
-                if (lane == k) { dmine = d; dimine = di; }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int j = 4 * g + t;
-                    if (j > k) a4[t] = fma(-li, cj[t], a4[t]);      // (entries above the diagonal are never read)
-                }
+                for (int t = 0; t < 4; ++t) a4[t] = fma(-li, cj[t], a4[t]);     // (finished columns: garbage, never read)
+                // rows below the pivot of T: T(i, c) -= l_i T(k, c)  (c > k: T(k, c) = 0, the operation adds nothing)
+                const double lt = (io > k) ? -li : 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) t4[t] = fma(lt, bcast16(t4[t], k), t4[t]);
+                // the owner of (row i, column k) keeps L(i, k) (below the pivot) or d (the pivot itself)
+                if (go == gk) lout[qk] = (io > k) ? li : d;
+                sh_d[k] = d;                                          // (every lane, same value)
+                sh_dinv[k] = di;
             }
         }
-        if (lane < NB) { sh_d[lane] = dmine; sh_dinv[lane] = dimine; }
+        for (int k = w + lane; k < NB; k += 64) { sh_d[k] = 1.0; sh_dinv[k] = 1.0; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = 4 * g + q;
             if (i < w && j <= i) P[(kb + i) + pcol(kb + j, f)] = lout[q];       // scaled L below, d on the diagonal
-            if (i < w && j < i) Lb[i * NB + j] = vout[q];                       // d_j L(i,j): what the rows below need
+            Tb[i * NB + j] = t4[q];
         }
-        if (first && lane < w) A.Dinv[c0 + kb + lane] = dimine;
+        WAVE_FENCE();
+        if (first && lane < w) A.Dinv[c0 + kb + lane] = sh_dinv[lane];
         if (first && lane == 0) {
             if (nreg) atomicAdd(&A.flags[0], nreg);
             if (bad) A.flags[1] = 1;
         }
-            };
+    };
     // ---- 4. blocked right-looking factorisation inside LDS, software-pipelined across the waves:
     //   wave 0        rows of the NEXT diagonal block against block k (16 rows), the one 16 x 16 tile that updates
     //                 that diagonal block, then its factorisation -- the serial chain of the panel, start to end;
@@ -501,37 +537,44 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     //   One workgroup barrier per block.  The B operand of the trailing tiles is d_k L(j,k), scaled on the fly.
     if (tid == 0) *lds_cnt = 0;
     __syncthreads();                     // the panel is assembled (every wave has applied its children's columns)
-    if (wv == 0) diag_block(0, min(NB, nc), 0);
+    // (the loop starts one block early: that prologue pass only factors diagonal block 0 -- ONE copy of the diagonal
+    // step's long straight-line code in the kernel instead of two)
     int epoch = 0;
-    for (int kb = 0; kb < nc; kb += NB) {
-        const int w = min(NB, nc - kb);
-        const int par = (kb / NB) & 1;
+    for (int kb = -NB; kb < nc; kb += NB) {
+        const bool pro = kb < 0;
+        const int w = pro ? 0 : min(NB, nc - kb);
+        const int par = pro ? 1 : ((kb / NB) & 1);
         const double* sh_d = sh_d_all + par * NB;
         const double* sh_dinv = sh_dinv_all + par * NB;
         const double* Lb = Lb_all + par * NB * NB;
         __syncthreads();                 // diagonal block kb is factored, trailing update kb - NB is complete
         if (A.stamps) t0 = wall_clock64();
-        ++epoch;
-        const int g0 = kb + w;
+        if (!pro) ++epoch;
+        const int g0 = pro ? 0 : kb + w;
         const int Tc = nc - g0, Tr = f - g0;
-        // rows below the block: L(i,j) = (A(i,j) - sum_{t<j} L(i,t) * [d_t L(j,t)]) / d_j, a thread per row
-        auto trsm_row = [&](const int i) {
-            double l[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) l[j] = (j < w) ? P[i + pcol(kb + j, f)] : 0.0;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (j < w) {
-                    double acc = l[j];
-#pragma unroll
-                    for (int t = 0; t < j; ++t) acc = fma(-l[t], Lb[j * NB + t], acc);
-                    l[j] = acc * sh_dinv[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) if (j < w) P[i + pcol(kb + j, f)] = l[j];
-        };
         const int ml = lane & 15, mk = lane >> 4;
+        // rows below the block, 16 at a time: L(rows, block) = A(rows, block) T' D^{-1} with T = L_bb^{-1} -- one
+        // 16 x 16 x 16 product on the matrix cores instead of a 120-term dependent substitution chain per row.
+        // A operand A[i = ml][k] = a(row0 + i, kb + k), B operand B[k][j = ml] = T(j, k).
+        auto trsm_tile = [&](const int row0) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * kk + mk;
+                av[kk] = (row0 + ml < f && k < w) ? P[(row0 + ml) + pcol(kb + k, f)] : 0.0;
+                bv[kk] = Lb[ml * NB + k];
+            }
+            d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+            const double dj = sh_dinv[ml];
+            const int ccol = pcol(kb + min(ml, w - 1), f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + mk + 4 * r;
+                if (row < f && ml < w) P[row + ccol] = acc[r] * dj;
+            }
+        };
         // C(16 x 16 tile at rows g0 + 16 tr, columns g0 + 16 tc) -= L(rows, block) * (d L(cols, block))'
         auto tile = [&](const int tr, const int tc) {
             const int i0 = g0 + 16 * tr, j0 = g0 + 16 * tc;
@@ -553,27 +596,38 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 if (row < f && col < nc && row >= col) P[row + ccol] -= acc[r];
             }
         };
-        const int nfirst = min(NB, Tr);                       // rows of the next diagonal block (or the last rows)
+        const int nfirst = pro ? 0 : min(NB, Tr);             // rows of the next diagonal block (or the last rows)
         if (wv == 0) {
-            if (lane < nfirst) trsm_row(g0 + lane);
-            WAVE_FENCE();
-            if (Tc > 0) {
-                tile(0, 0);
+            if (!pro) {
+                long long ta = A.stamps ? wall_clock64() : 0;
+                if (nfirst > 0) trsm_tile(g0);
                 WAVE_FENCE();
+                if (Tc > 0) {
+                    tile(0, 0);
+                    WAVE_FENCE();
+                }
+                if (lane == 0) __hip_atomic_fetch_add(lds_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (A.stamps) t_ii += wall_clock64() - ta;
             }
-            if (lane == 0) __hip_atomic_fetch_add(lds_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (Tc > 0) diag_block(g0, min(NB, nc - g0), par ^ 1);
-        } else {
-            for (int i = g0 + nfirst + (tid - 64); i < f; i += BS - 64) trsm_row(i);
+            if (Tc > 0) {
+                long long ta = A.stamps ? wall_clock64() : 0;
+                diag_block(g0, min(NB, nc - g0), par ^ 1);
+                if (A.stamps) t_i += wall_clock64() - ta;
+            }
+        } else if (!pro && (wv & 3) != 0) {
+            // Waves are dealt round-robin to the CU's four SIMDs, so waves 4, 8, 12 share wave 0's.  Wave 0 carries
+            // the serial chain and is bound by its own instruction issue (~55 instructions per pivot): those waves
+            // sit this part out at the barrier instead of competing for its issue slots (workers: the other 3/4).
+            for (int row0 = g0 + nfirst + 16 * widx; row0 < f; row0 += 16 * NWK) trsm_tile(row0);
             WAVE_FENCE();
             if (lane == 0) __hip_atomic_fetch_add(lds_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (Tc > 0) {
                 // every wave's rows are in place once all NW arrivals of this block are counted
-                while (__hip_atomic_load(lds_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch)
+                while (__hip_atomic_load(lds_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (NWK + 1) * epoch)
                     __builtin_amdgcn_s_sleep(1);
                 WAVE_FENCE();
                 const int ntr = (Tr + 15) >> 4, ntc = (Tc + 15) >> 4;
-                for (int t = wv - 1; t < ntr * ntc; t += NW - 1) {
+                for (int t = widx; t < ntr * ntc; t += NWK) {
                     const int tc = t / ntr, tr = t - tc * ntr;
                     if (tr < tc || (tr == 0 && tc == 0)) continue;      // above the diagonal / wave 0's tile
                     tile(tr, tc);
