@@ -571,8 +571,10 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
 #pragma unroll
             for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
         }
-        constexpr int GP = 12;             // gather sources per row whose indices are fetched before the wait: the
-        int gsrc[GP];                      // separator rows near the top collect a dozen small children each
+        // gather sources per row whose indices are fetched before the wait: the separator rows near the top collect a
+        // dozen small children each (fewer with several right-hand sides: the values of all columns are in flight together)
+        constexpr int GP = NR == 1 ? 12 : (NR == 2 ? 8 : 4);
+        int gsrc[GP];
 #pragma unroll
         for (int q = 0; q < GP; ++q) gsrc[q] = -1;
         int64_t g0 = 0, g1 = 0;
@@ -606,18 +608,28 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         if (!sh_ok) return;
         // ---- gather (only the handed-over values are loaded now)
         if (tid < f) {
+            double u[NR][GP];              // every column's values in flight before the first sum
+#pragma unroll
+            for (int q = 0; q < GP; ++q)
+#pragma unroll
+                for (int c = 0; c < NR; ++c) u[c][q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + c * A.ld_uvec + gsrc[q]) : 0.0;
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
-                const double* uv = A.uvec + c * A.ld_uvec;
-                double u[GP];
-#pragma unroll
-                for (int q = 0; q < GP; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(uv + gsrc[q]) : 0.0;
                 double v = bmine[c];
 #pragma unroll
-                for (int q = 0; q < GP; ++q) v += u[q];
-                for (int64_t g = g0 + GP; g < g1; ++g) v += LD_AGENT_F64(uv + T.gl_src[g]);
-                y[c * cst + tid] = v;
+                for (int q = 0; q < GP; ++q) v += u[c][q];
+                bmine[c] = v;
             }
+            for (int64_t g = g0 + GP; g < g1; ++g) {
+                const int src = T.gl_src[g];
+                double w[NR];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) w[c] = LD_AGENT_F64(A.uvec + c * A.ld_uvec + src);
+#pragma unroll
+                for (int c = 0; c < NR; ++c) bmine[c] += w[c];
+            }
+#pragma unroll
+            for (int c = 0; c < NR; ++c) y[c * cst + tid] = bmine[c];
         }
         for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
             const int64_t lc = (int64_t)c0 + rp + i;
@@ -711,11 +723,20 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         __syncthreads();
         if (!sh_ok) return;
+        {
+            double zv[NR];                 // every column's value in flight before the first use
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                const double* xc = A.xp + c * A.ld_xp;
+                zv[c] = (tid < nc) ? LD_AGENT_F64(xc + c0 + tid) : (tid < f ? LD_AGENT_F64(xc + ridx) : 0.0);
+            }
+#pragma unroll
+            for (int c = 0; c < NR; ++c)
+                if (tid < f) z[c * cst + tid] = (tid < nc) ? zv[c] * dinv : -zv[c];
+        }
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
             const double* xc = A.xp + c * A.ld_xp;
-            if (tid < nc) z[c * cst + tid] = LD_AGENT_F64(xc + c0 + tid) * dinv;
-            else if (tid < f) z[c * cst + tid] = -LD_AGENT_F64(xc + ridx);
             for (int i = tid + BS; i < f; i += BS)
                 z[c * cst + i] = (i < nc) ? LD_AGENT_F64(xc + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(xc + T.rows[rp + i - nc]);
         }
