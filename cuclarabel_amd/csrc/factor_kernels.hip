@@ -34,6 +34,12 @@ __device__ inline double rl_f64(double v, int lane)
 // outstanding global stores/loads, which put ~1 us into every pivot step.)
 #define WAVE_FENCE() asm volatile("" ::: "memory")
 
+// LDS += without the read-wait-add-write chain: ds_add_f64 (gfx90a+) is fire-and-forget, and the LDS executes one
+// wave's operations in issue order, so a wave's adds to one address still land in program order (deterministic sums).
+__device__ __forceinline__ void lds_add(double* p, double v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // first index t in [0, n) with arr[t] >= v  (arr ascending)
 __device__ inline int lower_bound_dev(const int* __restrict__ arr, int n, int v)
 {
@@ -106,8 +112,8 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
                     const int a = b + rem;
                     const int ra = relc[a], rb = relc[b];
                     const double v = Uc[a + (int64_t)b * nbc];
-                    if (rb < nc) P[ra + rb * f] += v;
-                    else Us[(ra - nc) + (rb - nc) * nb] += v;
+                    if (rb < nc) lds_add(P + ra + rb * f, v);
+                    else lds_add(Us + (ra - nc) + (rb - nc) * nb, v);
                 }
                 continue;
             }
@@ -116,8 +122,8 @@ __global__ __launch_bounds__(256) void k_front_wave(FactorArgs A, int begin, int
                 for (int a = b + lane; a < nbc; a += 64) {
                     const int ra = relc[a];
                     const double v = Uc[a + (int64_t)b * nbc];
-                    if (rb < nc) P[ra + rb * f] += v;
-                    else Us[(ra - nc) + (rb - nc) * nb] += v;
+                    if (rb < nc) lds_add(P + ra + rb * f, v);
+                    else lds_add(Us + (ra - nc) + (rb - nc) * nb, v);
                 }
             }
         }
@@ -208,8 +214,8 @@ __global__ __launch_bounds__(256) void k_front_tiny(FactorArgs A, int begin, int
             for (int a = b + sub; a < nbc; a += 8) {
                 const int ra = relc[a];
                 const double v = Uc[a + (int64_t)b * nbc];
-                if (rb < nc) P[ra + rb * f] += v;
-                else Us[(ra - nc) + (rb - nc) * nb] += v;
+                if (rb < nc) lds_add(P + ra + rb * f, v);
+                else lds_add(Us + (ra - nc) + (rb - nc) * nb, v);
             }
         }
     }
@@ -291,15 +297,17 @@ __device__ inline int64_t uniform_i64(int64_t v)
 // SLICED: the workgroup holds the top nc rows and the front rows [r_lo, r_lo + rs) only (local row nc + r - r_lo)
 template <bool SLICED>
 __device__ inline void apply_items_panel(const TreeDev& T, const double* __restrict__ upd, double* P, int f,
-                                         int64_t i0_, int64_t i1_, int lane, int nc, int r_lo, int rs)
+                                         int64_t i0_, int64_t i1_, int lane, int nc, int r_lo, int rs, const ExtItem& first,
+                                         long long* dbg = nullptr)
 {
     // the range is the same for every lane
     const int64_t i0 = uniform_i64(i0_), i1 = uniform_i64(i1_);
     constexpr int IF = 16;        // pieces in flight
     for (int64_t ii = i0; ii < i1; ii += 64) {
         // the next 64 descriptors in ONE vector load round (lane l fetches item ii + l); their fields are handed out
-        // with v_readlane as the pieces are issued -- no scalar-load latency per batch
-        const ExtItem mine = T.items[min(ii + lane, i1 - 1)];
+        // with v_readlane as the pieces are issued -- no scalar-load latency per batch.  The first round was issued by
+        // the caller before the panel was zeroed (static data: its latency hides behind the kernel's first phases)
+        const ExtItem mine = (ii == i0) ? first : T.items[min(ii + lane, i1 - 1)];
         const int lo = (int)(mine.uoff & 0xffffffff), hi = (int)(mine.uoff >> 32);
         // (sliced: a piece wholly below the top block and outside this slice's rows brings nothing)
         const int mycnt = (SLICED && mine.rfirst >= nc && (mine.rlast < r_lo || mine.rfirst >= r_lo + rs)) ? 0 : mine.cnt;
@@ -324,9 +332,10 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
                     tg[q] = r >= 0 ? r + pcol(tcol, f) : -1;
                 }
             }
+            if (dbg && q0 == 0 && ii == i0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) dbg[0] = wall_clock64(); }
 #pragma unroll
             for (int q = 0; q < IF; ++q) {
-                if (tg[q] >= 0) P[tg[q]] += v[q];          // (a piece has at most 64 rows; pieces in item order)
+                if (tg[q] >= 0) lds_add(P + tg[q], v[q]);          // (a piece has at most 64 rows; pieces in item order)
             }
         }
     }
@@ -386,6 +395,19 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 
     HIPKKT_STAMP(A, 0);
     const long long clk0 = A.stamps ? clock64() : 0;
+    // this wave's slice of the children's extend-add items (host-cut, 16 slices) and its first 64 descriptors: issued
+    // now, used in phase 3
+    int64_t it0 = 0, it1 = 0;
+    ExtItem it_first{};
+    {
+        const int64_t* __restrict__ wc = T.wave_cut + (int64_t)s * 17;
+        constexpr int SPW = 16 / NW > 0 ? 16 / NW : 1;      // slices per wave
+        if (wv * SPW < 16) {
+            it0 = wc[wv * SPW];
+            it1 = wc[min(16, (wv + 1) * SPW)];
+            if (it1 > it0) it_first = T.items[min(it0 + lane, it1 - 1)];
+        }
+    }
     // ---- 1. zero the panel (and fetch the pivot signs: the serial diagonal step must not wait for global memory)
     for (int k = tid; k < nc; k += BS) sgn[k] = (double)T.psign[c0 + k];
     const int psize = f * nc - ((nc * (nc - 1)) >> 1);
@@ -429,15 +451,14 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     }
     __syncthreads();
     HIPKKT_STAMP(A, 2);
-    // ---- 3. children: each wave applies a slice of whole columns' items (host-cut, 16 slices)
-    {
-        const int64_t* __restrict__ wc = T.wave_cut + (int64_t)s * 17;
-        constexpr int SPW = 16 / NW > 0 ? 16 / NW : 1;      // slices per wave
-        if (wv * SPW < 16) {
-            const int64_t i0 = wc[wv * SPW], i1 = wc[min(16, (wv + 1) * SPW)];
-            if (i1 > i0) apply_items_panel<SLICED>(T, A.upd, P, f, i0, i1, lane, nc, r_lo, rs);
-        }
+    // ---- 3. children: each wave applies its slice of whole columns' items
+    if (A.stamps && blockIdx.x == 0 && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        A.stamps[A.stamp_row * 16 + 6] = wall_clock64();
     }
+    if (it1 > it0) apply_items_panel<SLICED>(T, A.upd, P, f, it0, it1, lane, nc, r_lo, rs, it_first,
+                                             (A.stamps && blockIdx.x == 0 && wv == 0) ? A.stamps + A.stamp_row * 16 + 15 : nullptr);
+    if (A.stamps && blockIdx.x == 0 && tid == 0) A.stamps[A.stamp_row * 16 + 7] = wall_clock64();
     HIPKKT_STAMP(A, 3);
     long long t_i = 0, t_ii = 0, t_iii = 0, t0 = 0;
     // The 16 x 16 diagonal block kb as a callable: with look-ahead it runs on wave 0 while the other waves finish the
@@ -790,7 +811,7 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
             }
             double* ct = &Ct[0][0];
 #pragma unroll
-            for (int z = 0; z < 8; ++z) if (tg[z] >= 0) ct[tg[z]] += v[z];
+            for (int z = 0; z < 8; ++z) if (tg[z] >= 0) lds_add(ct + tg[z], v[z]);
         }
     }
     __syncthreads();

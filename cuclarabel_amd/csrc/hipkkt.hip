@@ -367,6 +367,7 @@ private:
                 for (size_t r = 0; r < launches.size(); ++r) {
                     const long long* q = &h[r * 16];
                     if (launches[r].small) continue;
+                    std::fprintf(stderr, "[stamps2] launch %zu: wave 0's items %.1f us (first batch's loads %.1f us), then all waves %.1f us\n", r, (q[7] - q[6]) * 0.01, (q[15] - q[6]) * 0.01, (q[3] - q[7]) * 0.01);
                     std::fprintf(stderr, "[stamps] launch %zu fronts %d f=%lld nc=%lld kids=%lld | zero %.1f K %.1f kids %.1f factor %.1f "
                                  "(diag %.1f trsm %.1f trail %.1f) store %.1f us  clk %.0f MHz\n", r, launches[r].count, q[11], q[12], q[13],
                                  (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01,
@@ -762,10 +763,17 @@ private:
             std::vector<int64_t> toff(S.nsuper + 1, 0);
             std::vector<char> in_list(S.nsuper, 0);
             for (int s : tinv_list) in_list[s] = 1;
-            for (int s = 0; s < S.nsuper; ++s) {
-                int64_t nc = S.sn_start[s + 1] - S.sn_start[s];
-                int64_t fs = nc + (S.rowptr[s + 1] - S.rowptr[s]);
-                toff[s + 1] = toff[s] + (in_list[s] ? 2 * fs * nc : 0);
+            // (level by level like the panel and update stores: symbolic.cpp, step 10)
+            {
+                int64_t wo = 0;
+                for (int t = 0; t < S.nsuper; ++t) {
+                    const int s = S.level_sn[t];
+                    int64_t nc = S.sn_start[s + 1] - S.sn_start[s];
+                    int64_t fs = nc + (S.rowptr[s + 1] - S.rowptr[s]);
+                    toff[s] = wo;
+                    wo += in_list[s] ? 2 * fs * nc : 0;
+                }
+                toff[S.nsuper] = wo;
             }
             d_tinv_off.upload(toff);
             static_assert(sizeof(FrontDesc) == 64, "FrontDesc layout");
@@ -980,6 +988,20 @@ private:
                 wcut[(size_t)s * 17 + 16] = I1;
             }
             d_wave_cut.upload(wcut);
+            if (const char* vb = std::getenv("HIPKKT_VERBOSE")) {
+                if (std::atoi(vb) >= 2) {            // the extend-add work of the last fronts of the schedule
+                    for (size_t q = sched.size() > 12 ? sched.size() - 12 : 0; q < sched.size(); ++q) {
+                        const int sn = sched[q];
+                        const int64_t* w = wcut.data() + (size_t)sn * 17;
+                        int64_t mx = 0, rows = 0;
+                        for (int k = 0; k < 16; ++k) mx = std::max(mx, w[k + 1] - w[k]);
+                        for (int64_t it = w[0]; it < w[16]; ++it) rows += items[(size_t)it].cnt;
+                        std::fprintf(stderr, "[hipkkt] front %d f %d nc %d kids %d: %lld panel items (%lld entries), largest wave slice %lld\n",
+                                     sn, front_size(sn), S.sn_start[sn + 1] - S.sn_start[sn], S.child_ptr[sn + 1] - S.child_ptr[sn],
+                                     (long long)(w[16] - w[0]), (long long)rows, (long long)mx);
+                    }
+                }
+            }
             // Schur sub-items: every child update column that lands in a U column, cut at the parent's
             // 64-row tile boundaries, grouped by (tile, tile column), children in fixed order
             static_assert(sizeof(SubItem) == 16, "SubItem layout");

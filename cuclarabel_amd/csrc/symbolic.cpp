@@ -2,6 +2,7 @@
 // supernodes (+ relaxed amalgamation) -> row structures, assembly maps, level schedule.
 // See symbolic.hpp for what this replaces in the reference.
 #include "symbolic.hpp"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -462,6 +463,25 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
     {
         std::vector<int> nxt(cnt.begin(), cnt.end() - 1);
         for (int s = 0; s < S.nsuper; ++s) S.level_sn[nxt[S.sn_level[s]]++] = s;
+    }
+    // ---- 10. the stores are laid out LEVEL BY LEVEL (a level's fronts side by side, leaves first), not in supernode
+    // order: a front's children sit (mostly) one level below it, so the update blocks a panel gathers from, and the
+    // panels / solve matrices one launch touches, share a few large pages instead of one page each -- a front near
+    // the root has a dozen children whose blocks were megabytes apart in postorder, and its assembly spent 10-20 us
+    // on what are ~30 scattered first touches (address translation, not bytes).  Offsets stay per supernode;
+    // entry [nsuper] holds the total.  (HIPKKT_POSTORDER_LAYOUT=1 keeps the postorder layout, for comparison.)
+    if (!std::getenv("HIPKKT_POSTORDER_LAYOUT")) {
+        int64_t fo = 0, uo = 0;
+        for (int t = 0; t < S.nsuper; ++t) {
+            const int s = S.level_sn[t];
+            const int64_t nc = S.sn_start[s + 1] - S.sn_start[s], nb = S.rowptr[s + 1] - S.rowptr[s], f = nc + nb;
+            S.front_off[s] = fo;
+            S.upd_off[s] = uo;
+            fo += f * nc;
+            uo += nb * nb;
+        }
+        S.front_off[S.nsuper] = fo;
+        S.upd_off[S.nsuper] = uo;
     }
 }
 
