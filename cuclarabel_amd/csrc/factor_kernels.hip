@@ -40,6 +40,25 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// ---- overlap mode (FactorArgs::ov): hand-over between concurrently running kernels, the Guideline-16 recipe of the
+// HIP guide in its write-through form -- payload stored sc1 (relaxed agent-scope atomic stores), every storing wave
+// drains vmcnt, the workgroup meets, ONE lane bumps / stores the counter; consumers poll the counter with relaxed
+// agent-scope loads and read the payload with agent-scope (L1 / L2-bypassing) loads only.  Every spin is bounded by
+// wall clock; on expiry flags[2] is set, everyone leaves, and the host repeats the factorisation level by level.
+#define OV_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define OV_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+__device__ inline bool ov_wait_ge(const int* counter, int target, int* abort_word, long long t0)
+{
+    for (;;) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (wall_clock64() - t0 > 5000000) {          // 50 ms at 100 MHz: far beyond any real factorisation step
+            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 // first index t in [0, n) with arr[t] >= v  (arr ascending)
 __device__ inline int lower_bound_dev(const int* __restrict__ arr, int n, int v)
 {
@@ -295,7 +314,7 @@ __device__ inline int64_t uniform_i64(int64_t v)
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 // SLICED: the workgroup holds the top nc rows and the front rows [r_lo, r_lo + rs) only (local row nc + r - r_lo)
-template <bool SLICED>
+template <bool SLICED, bool COH>
 __device__ inline void apply_items_panel(const TreeDev& T, const double* __restrict__ upd, double* P, int f,
                                          int64_t i0_, int64_t i1_, int lane, int nc, int r_lo, int rs, const ExtItem& first,
                                          long long* dbg = nullptr)
@@ -323,7 +342,8 @@ __device__ inline void apply_items_panel(const TreeDev& T, const double* __restr
                 const int cnt = (q0 + q < nhere) ? __builtin_amdgcn_readlane(mycnt, j) : 0;
                 const int tcol = __builtin_amdgcn_readlane(mine.tcol, j);
                 const bool ok = lane < cnt;
-                v[q] = ok ? upd[uoff + lane] : 0.0;
+                v[q] = ok ? (COH ? OV_LD(upd + uoff + lane) : upd[uoff + lane]) : 0.0;     // (overlap mode: written by a
+                                                                                           // kernel that may still be running)
                 if (!SLICED) {
                     tg[q] = ok ? T.rel[relstart + lane] + pcol(tcol, f) : -1;
                 } else {
@@ -362,9 +382,10 @@ __device__ __forceinline__ double bcast16(double v, const int k)
 // never talk to each other: the diagonal blocks are computed redundantly (they sit on every slice's critical path
 // anyway), the substitution and the trailing update only ever combine a row with the top block.  Inside the kernel
 // a slice is simply a front with f = nc + (rows of the slice); only assembly and the final store map rows.
-template <int BS, bool SLICED>
+template <int BS, bool SLICED, bool OV>
 __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 {
+    static_assert(!(SLICED && OV), "overlap mode takes whole panels only");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -451,12 +472,30 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     }
     __syncthreads();
     HIPKKT_STAMP(A, 2);
+    if (OV) {
+        // the children's Schur tiles run beside this kernel: wait until every tile of every child has been stored
+        volatile int& sh_ov_ok = reinterpret_cast<volatile int*>(lds_cnt)[2];
+        if (tid == 0) sh_ov_ok = 1;
+        __syncthreads();
+        if (wv == 0) {
+            const long long tw = wall_clock64();
+            bool ok = true;
+            for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
+                const int c = T.child_idx[e];
+                const int need = A.ov_ntiles[c];
+                if (need > 0) ok = ov_wait_ge(A.ov_done + c, need, A.flags + 2, tw) && ok;
+            }
+            if (!ok) sh_ov_ok = 0;
+        }
+        __syncthreads();
+        if (!sh_ov_ok) return;
+    }
     // ---- 3. children: each wave applies its slice of whole columns' items
     if (A.stamps && blockIdx.x == 0 && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         A.stamps[A.stamp_row * 16 + 6] = wall_clock64();
     }
-    if (it1 > it0) apply_items_panel<SLICED>(T, A.upd, P, f, it0, it1, lane, nc, r_lo, rs, it_first,
+    if (it1 > it0) apply_items_panel<SLICED, OV>(T, A.upd, P, f, it0, it1, lane, nc, r_lo, rs, it_first,
                                              (A.stamps && blockIdx.x == 0 && wv == 0) ? A.stamps + A.stamp_row * 16 + 15 : nullptr);
     if (A.stamps && blockIdx.x == 0 && tid == 0) A.stamps[A.stamp_row * 16 + 7] = wall_clock64();
     HIPKKT_STAMP(A, 3);
@@ -556,7 +595,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     //   waves 1..     the other rows against block k (thread per row), an LDS arrival counter as their barrier
     //                 (wave 0 signals but does not wait), then the rest of the trailing update on the matrix cores.
     //   One workgroup barrier per block.  The B operand of the trailing tiles is d_k L(j,k), scaled on the fly.
-    if (tid == 0) *lds_cnt = 0;
+    if (tid == 0) { lds_cnt[0] = 0; lds_cnt[1] = 0; }
     __syncthreads();                     // the panel is assembled (every wave has applied its children's columns)
     // (the loop starts one block early: that prologue pass only factors diagonal block 0 -- ONE copy of the diagonal
     // step's long straight-line code in the kernel instead of two)
@@ -642,6 +681,23 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             for (int row0 = g0 + nfirst + 16 * widx; row0 < f; row0 += 16 * NWK) trsm_tile(row0);
             WAVE_FENCE();
             if (lane == 0) __hip_atomic_fetch_add(lds_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (OV) {
+                // Block kb's columns are final once every wave's rows are in place: the workers publish them now
+                // (written through), off wave 0's chain, and the last one to finish advances the front's progress
+                // counter -- the front's Schur tiles, running beside this kernel, take the block from there.
+                while (__hip_atomic_load(lds_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (NWK + 1) * epoch)
+                    __builtin_amdgcn_s_sleep(1);
+                WAVE_FENCE();
+                for (int idx = widx * 64 + lane; idx < w * f; idx += NWK * 64) {
+                    const int jj = idx / f, r = idx - jj * f, j = kb + jj;
+                    if (r >= j) OV_ST(F + r + (int64_t)j * ff, P[r + pcol(j, f)]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const int arrived = __hip_atomic_fetch_add(lds_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                    if (arrived == NWK * epoch) __hip_atomic_store(A.ov_prog + s, kb + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             if (Tc > 0) {
                 // every wave's rows are in place once all NW arrivals of this block are counted
                 while (__hip_atomic_load(lds_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (NWK + 1) * epoch)
@@ -659,8 +715,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     }
     __syncthreads();
     HIPKKT_STAMP(A, 4);
-    // ---- 5. write L and D (lower part of the panel)
-    for (int idx = tid; idx < f * nc; idx += BS) {
+    // ---- 5. write L and D (lower part of the panel; overlap mode has published every block already)
+    if (!OV) for (int idx = tid; idx < f * nc; idx += BS) {
         const int j = idx / f, r = idx - j * f;
         if (!SLICED) {
             if (r >= j) F[idx] = P[r + pcol(j, f)];
@@ -696,14 +752,21 @@ constexpr int LDA = TS + 16;    // k-rows 80 doubles apart: consecutive k land 3
 // 32 x 32 quadrant of the tile (2 x 2 MFMA tiles, 4 k-steps per staged chunk).  Operand layout
 // (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // D: col = lane&15, row = (lane>>4) + 4*reg.
+// OV (overlap mode): the tile runs BESIDE its front's panel kernel.  The children's pass-through (which does not depend
+// on this front's panel at all) is summed into the tile buffer first; then the product takes the panel's 16-column
+// blocks one by one as the panel kernel publishes them (FactorArgs::ov_prog), so that when the panel's last block
+// arrives only one rank-16 update and the store remain; the tile is stored written-through and counted in ov_done.
+template <bool OV>
 __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin)
 {
     // the operand chunks are dead once the product is done: the tile buffer shares their LDS (33 KB per
     // workgroup instead of 53 KB -> one more workgroup per CU)
-    __shared__ __attribute__((aligned(16))) double smem_s[TS * (TS + 1)];
-    double (*As)[LDA] = reinterpret_cast<double (*)[LDA]>(smem_s);                 // As[k][r] = L21(r0 + r, k0 + k)
-    double (*Bs)[LDA] = reinterpret_cast<double (*)[LDA]>(smem_s + KC * LDA);      // Bs[k][c] = L21(q0 + c, k0 + k) * d_k
+    // (overlap mode keeps the tile buffer beside the operand chunks: it is filled before the product)
+    __shared__ __attribute__((aligned(16))) double smem_s[TS * (TS + 1) + (OV ? 2 * KC * LDA + 2 : 0)];
+    double (*As)[LDA] = reinterpret_cast<double (*)[LDA]>(smem_s + (OV ? TS * (TS + 1) : 0));   // As[k][r] = L21(r0 + r, k0 + k)
+    double (*Bs)[LDA] = reinterpret_cast<double (*)[LDA]>(smem_s + (OV ? TS * (TS + 1) : 0) + KC * LDA);   // Bs[k][c] = L21(q0 + c, k0 + k) * d_k
     double (*Ct)[TS + 1] = reinterpret_cast<double (*)[TS + 1]>(smem_s);           // the tile, [col][row]
+    volatile int* sh_ok = reinterpret_cast<volatile int*>(smem_s + TS * (TS + 1) + 2 * KC * LDA);   // (OV only)
     static_assert(2 * KC * LDA <= TS * (TS + 1), "operand chunks must fit under the tile buffer");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -739,17 +802,57 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
         it[z] = T.sitems[max(min(i0 + z, i1 - 1), (int64_t)0)];
         if (i0 + z >= i1) it[z].cnt = 0;
     }
+    // children pass-through: this wave's slice of the tile's sub-items (whole columns, child order),
+    // eight in flight: one round of descriptor loads, one round of (rel, value) loads, then LDS adds
+    auto pass_through = [&]() {
+        const int rlo = nc + r0;
+        for (int64_t ii = i0; ii < i1; ii += 8) {
+            double v[8];
+            int tg[8];
+            if (ii > i0) {
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    it[z] = T.sitems[min(ii + z, i1 - 1)];
+                    if (ii + z >= i1) it[z].cnt = 0;
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const bool ok = lane < (int)it[z].cnt;
+                v[z] = ok ? A.upd[it[z].uoff + lane] : 0.0;
+                tg[z] = ok ? (int)it[z].qcol * (TS + 1) + (T.rel[it[z].relstart + lane] - rlo) : -1;
+            }
+            double* ct = &Ct[0][0];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) if (tg[z] >= 0) lds_add(ct + tg[z], v[z]);
+        }
+    };
+    if (OV) {
+        for (int idx = tid; idx < TS * (TS + 1); idx += 256) (&Ct[0][0])[idx] = 0.0;
+        if (tid == 0) *sh_ok = 1;
+        __syncthreads();
+        pass_through();
+    }
+    const long long tw = OV ? wall_clock64() : 0;
 
     for (int k0 = 0; k0 < nc; k0 += KC) {
         const int kw = min(KC, nc - k0);
+        if (OV) {
+            // the panel kernel of this front publishes its 16-column blocks as they are finished
+            if (tid == 0 && !ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw)) *sh_ok = 0;
+            __syncthreads();
+            if (!*sh_ok) return;
+        }
         {
             const int k = tid >> 4, rr = (tid & 15) * 4;
             double av[4], bv[4];
-            const double dk = (k < kw) ? F[(k0 + k) + (int64_t)(k0 + k) * f] : 0.0;
+            // (overlap mode: the panel entries were written through by a kernel that is still running)
+            auto ldF = [&](int64_t o) { return OV ? OV_LD(F + o) : F[o]; };
+            const double dk = (k < kw) ? ldF((k0 + k) + (int64_t)(k0 + k) * f) : 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                av[q] = (k < kw && rr + q < nr) ? F[(nc + r0 + rr + q) + (int64_t)(k0 + k) * f] : 0.0;
-                bv[q] = (ti != tj && k < kw && rr + q < nq) ? F[(nc + q0 + rr + q) + (int64_t)(k0 + k) * f] : 0.0;
+                av[q] = (k < kw && rr + q < nr) ? ldF((nc + r0 + rr + q) + (int64_t)(k0 + k) * f) : 0.0;
+                bv[q] = (ti != tj && k < kw && rr + q < nq) ? ldF((nc + q0 + rr + q) + (int64_t)(k0 + k) * f) : 0.0;
             }
             if (ti == tj) {                                  // diagonal tile: both strips are the same rows
 #pragma unroll
@@ -787,38 +890,23 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Ct[32 * wc + 16 * j + ml][32 * wr + 16 * i + mk + 4 * r] = -acc[i][j][r];
+                if (OV) Ct[32 * wc + 16 * j + ml][32 * wr + 16 * i + mk + 4 * r] -= acc[i][j][r];      // (each entry has one owner)
+                else Ct[32 * wc + 16 * j + ml][32 * wr + 16 * i + mk + 4 * r] = -acc[i][j][r];
     __syncthreads();
-    // children pass-through: this wave's slice of the tile's sub-items (whole columns, child order),
-    // eight in flight: one round of descriptor loads, one round of (rel, value) loads, then LDS adds
-    {
-        const int rlo = nc + r0;
-        for (int64_t ii = i0; ii < i1; ii += 8) {
-            double v[8];
-            int tg[8];
-            if (ii > i0) {
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    it[z] = T.sitems[min(ii + z, i1 - 1)];
-                    if (ii + z >= i1) it[z].cnt = 0;
-                }
-            }
-#pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                const bool ok = lane < (int)it[z].cnt;
-                v[z] = ok ? A.upd[it[z].uoff + lane] : 0.0;
-                tg[z] = ok ? (int)it[z].qcol * (TS + 1) + (T.rel[it[z].relstart + lane] - rlo) : -1;
-            }
-            double* ct = &Ct[0][0];
-#pragma unroll
-            for (int z = 0; z < 8; ++z) if (tg[z] >= 0) lds_add(ct + tg[z], v[z]);
-        }
-    }
+    if (!OV) pass_through();
     __syncthreads();
     // store the lower part of the tile
     for (int idx = tid; idx < TS * TS; idx += 256) {
         const int b = idx >> 6, a = idx & 63;
-        if (a < nr && b < nq && (r0 + a) >= (q0 + b)) U[(r0 + a) + (int64_t)(q0 + b) * nb] = Ct[b][a];
+        if (a < nr && b < nq && (r0 + a) >= (q0 + b)) {
+            if (OV) OV_ST(U + (r0 + a) + (int64_t)(q0 + b) * nb, Ct[b][a]);
+            else U[(r0 + a) + (int64_t)(q0 + b) * nb] = Ct[b][a];
+        }
+    }
+    if (OV) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(A.ov_done + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -834,10 +922,13 @@ static void init_factor_lds()
     once.run([]() {
         hipError_t e = hipSuccess;
         auto set = [&](auto k) { if (e == hipSuccess) e = set_max_lds(k, 160 * 1024); };
-        set(k_panel<256, false>);
-        set(k_panel<512, false>);
-        set(k_panel<1024, false>);
-        set(k_panel<1024, true>);
+        set(k_panel<256, false, false>);
+        set(k_panel<512, false, false>);
+        set(k_panel<1024, false, false>);
+        set(k_panel<256, false, true>);
+        set(k_panel<512, false, true>);
+        set(k_panel<1024, false, true>);
+        set(k_panel<1024, true, false>);
         set(k_front_wave);
         return e;
     });
@@ -859,20 +950,27 @@ void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds,
 {
     if (count <= 0) return;
     init_factor_lds();
-    if (bs == 1024) hipLaunchKernelGGL((k_panel<1024, false>), dim3(count), dim3(1024), lds, st, a, begin);
-    else if (bs == 512) hipLaunchKernelGGL((k_panel<512, false>), dim3(count), dim3(512), lds, st, a, begin);
-    else hipLaunchKernelGGL((k_panel<256, false>), dim3(count), dim3(256), lds, st, a, begin);
+    if (a.ov) {
+        if (bs == 1024) hipLaunchKernelGGL((k_panel<1024, false, true>), dim3(count), dim3(1024), lds, st, a, begin);
+        else if (bs == 512) hipLaunchKernelGGL((k_panel<512, false, true>), dim3(count), dim3(512), lds, st, a, begin);
+        else hipLaunchKernelGGL((k_panel<256, false, true>), dim3(count), dim3(256), lds, st, a, begin);
+        return;
+    }
+    if (bs == 1024) hipLaunchKernelGGL((k_panel<1024, false, false>), dim3(count), dim3(1024), lds, st, a, begin);
+    else if (bs == 512) hipLaunchKernelGGL((k_panel<512, false, false>), dim3(count), dim3(512), lds, st, a, begin);
+    else hipLaunchKernelGGL((k_panel<256, false, false>), dim3(count), dim3(256), lds, st, a, begin);
 }
 void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, hipStream_t st)
 {
     if (count <= 0) return;
     init_factor_lds();
-    hipLaunchKernelGGL((k_panel<1024, true>), dim3(count), dim3(1024), lds, st, a, begin);
+    hipLaunchKernelGGL((k_panel<1024, true, false>), dim3(count), dim3(1024), lds, st, a, begin);
 }
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st)
 {
     if (ntiles <= 0) return;
-    hipLaunchKernelGGL(k_schur, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin);
+    if (a.ov) hipLaunchKernelGGL(k_schur<true>, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin);
+    else hipLaunchKernelGGL(k_schur<false>, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin);
 }
 
 }  // namespace hipkkt

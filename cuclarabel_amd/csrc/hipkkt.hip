@@ -120,9 +120,10 @@ public:
             int nblock = 0, nsl_fronts = 0;
             for (const Launch& L : launches) if (!L.small) { nblock += L.count; nsl_fronts += L.nsliced; }
             std::fprintf(stderr, "[hipkkt] N %d, %d supernodes in %zu levels (%zu launches), %d block-class fronts, %d of them in "
-                         "%zu row slices; persistent solve set: last %zu launches, %d fronts on %d workgroups, %d (front, slice) tasks\n",
+                         "%zu row slices; persistent solve set: last %zu launches, %d fronts on %d workgroups, %d (front, slice) tasks; "
+                         "factorisation overlap: last %zu launches\n",
                          S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
-                         top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask);
+                         top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, launches.size() - ov_first);
         }
     }
 
@@ -264,6 +265,9 @@ public:
         if (cap_side) (void)hipStreamDestroy(cap_side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ov_stream) (void)hipStreamDestroy(ov_stream);
+        if (ev_ov_fork) (void)hipEventDestroy(ev_ov_fork);
+        if (ev_ov_join) (void)hipEventDestroy(ev_ov_join);
     }
 
 private:
@@ -285,7 +289,46 @@ private:
     void enqueue_factor(const double* d_Kval, const double* d_eps, hipStream_t st, hipStream_t side, bool want_stamps)
     {
         wait_w(st);                  // (a refactorisation without a solve in between: the side stream still reads the fronts)
-        launch_zero_ints(flags.p, 2, st);
+        launch_zero_ints(flags.p, 3, st);
+        // overlap mode (eager launches only): the top launches' Schur tiles on their own stream, ordered by counters
+        // Opt-in (HIPKKT_FACTOR_OVERLAP=1).  Measured on cfg2: the tiles hide completely behind the panels (a top level
+        // costs its panel kernel, 63 us, instead of panel + tiles, 79 us; factorisation 2.05 -> 1.97 ms), but the step does
+        // not get shorter yet: the solve matrices W of the top fronts are formed behind the tree either way, and the first
+        // sweep after the factorisation waits for them by as much as the factorisation ended earlier (3.667 vs 3.661 ms
+        // per step).  It pays once W formation moves off that path.
+        static const bool want_ov = std::getenv("HIPKKT_FACTOR_OVERLAP") != nullptr && std::atoi(std::getenv("HIPKKT_FACTOR_OVERLAP")) != 0;
+        const bool use_ov = want_ov && !side && !want_stamps && !ov_disabled && ov_first < launches.size();
+        if (use_ov) {
+            if (!ov_stream) {
+                // A panel workgroup needs a whole CU's LDS: tiles that reached the device first, spread one per CU and
+                // waiting for their panel, would leave no CU for it.  The submission order below makes the panels ready
+                // before their tiles; the bounded waits are the safety net.
+                hipDeviceProp_t prop;
+                HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+                const int words = (prop.multiProcessorCount + 31) / 32;
+                std::vector<uint32_t> mask((size_t)std::max(words, 1), 0x55555555u);
+                // (HIPKKT_OV_CU_MASK=1 confines the tile stream to every other CU.  Measured: on this stack a CU-masked
+                // stream slows EVERY stream of the process down as if all of them were masked -- residual 0.032 -> 0.054 ms,
+                // sweep 0.29 -> 0.37 ms -- so the default is a plain stream and the submission order described below.)
+                static const bool cu_mask = std::getenv("HIPKKT_OV_CU_MASK") != nullptr;
+                const hipError_t ce = !cu_mask ? hipStreamCreateWithFlags(&ov_stream, hipStreamNonBlocking)
+                                               : hipExtStreamCreateWithCUMask(&ov_stream, (uint32_t)mask.size(), mask.data());
+                if (ce != hipSuccess) {
+                    (void)hipGetLastError();
+                    ov_stream = nullptr;
+                    ov_disabled = true;
+                    std::fprintf(stderr, "[hipkkt] no stream for the Schur tiles: factorisation overlap off\n");
+                } else {
+                    HIP_CHECK(hipEventCreateWithFlags(&ev_ov_fork, hipEventDisableTiming));
+                    HIP_CHECK(hipEventCreateWithFlags(&ev_ov_join, hipEventDisableTiming));
+                }
+            }
+        }
+        const bool ov_on = use_ov && !ov_disabled;
+        if (ov_on) {
+            launch_zero_ints(d_ov_prog.p, S.nsuper, st);
+            launch_zero_ints(d_ov_done.p, S.nsuper, st);
+        }
         FactorArgs a;
         a.T = tree();
         a.Kval = d_Kval;
@@ -296,6 +339,7 @@ private:
         a.flags = flags.p;
         a.dyn_eps = dyn_eps;
         a.dyn_delta = dyn_delta;
+        a.ov_prog = d_ov_prog.p; a.ov_done = d_ov_done.p; a.ov_ntiles = d_ov_ntiles.p; a.ov = 0;
         a.stamps = nullptr;
         a.stamp_row = 0;
         if (want_stamps) {
@@ -323,6 +367,28 @@ private:
                 launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, launches[q].tinv_begin, tinv_ncmax, cap_side, kSideWinvBlocks);
                 HIP_CHECK(hipEventRecord(ev_join, cap_side));
                 eager_fork = true;
+            }
+            if (ov_on && q >= ov_first) {
+                // Panels on the main stream, the level's Schur tiles on the overlap stream,
+                // submitted in this order -- panel L, tiles L, panel L+1, ... -- which is correct even if the two streams
+                // share a hardware queue.  Tiles of level L become ready only when the tiles of level L-1 have finished,
+                // i.e. after panel L-1 ended and panel L got ready: the panels reach the CUs first.  (A tile workgroup
+                // that waits for its panel holds LDS a panel workgroup needs; the first overlapped level therefore
+                // starts its tiles only after its panels have finished.)
+                a.ov = 1;
+                a.nbk = L.nbk;
+                launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, st);
+                if (q == ov_first) {
+                    HIP_CHECK(hipEventRecord(ev_ov_fork, st));
+                    HIP_CHECK(hipStreamWaitEvent(ov_stream, ev_ov_fork, 0));
+                }
+                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, ov_stream);
+                a.ov = 0;
+                if (q + 1 == nl) {
+                    HIP_CHECK(hipEventRecord(ev_ov_join, ov_stream));
+                    HIP_CHECK(hipStreamWaitEvent(st, ev_ov_join, 0));
+                }
+                continue;
             }
             if (L.small) {
                 launch_front_wave(a, L.begin, L.count - L.ntiny, L.slice, st);
@@ -525,12 +591,21 @@ public:
         return v != 0;
     }
 
-    // synchronises: {#dynamic regularisations, non-finite flag}
-    void read_flags(int out[2])
+    // synchronises: {#dynamic regularisations, non-finite flag, an overlap-mode wait gave up}
+    void read_flags(int out[3])
     {
-        HIP_CHECK(hipMemcpyAsync(out, flags.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(out, flags.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }
+    // The caller found flags[2] set: a bounded wait of the overlap mode expired (never expected; another process on
+    // the GPU, or two streams that could not run side by side).  From now on the factorisation runs level by level;
+    // the caller repeats it.
+    void ov_gave_up()
+    {
+        ov_disabled = true;
+        std::fprintf(stderr, "[hipkkt] factorisation overlap gave up waiting; falling back to one level after the other\n");
+    }
+    bool ov_active() const { return !ov_disabled && ov_first < launches.size(); }
 
     int* flags_ptr() { return flags.p; }
 
@@ -568,6 +643,12 @@ private:
     int top_ntask = 0, top_nflag = 0, top_sgrid = 0;
     size_t top_slds = 0;
     size_t top_launches = 0, late_launches = 0, top_lds = 0;
+    // overlap mode of the factorisation (factor_kernels.hip): the launches from ov_first on (the narrow top of the tree)
+    size_t ov_first = 0;         // == launches.size(): none
+    bool ov_disabled = false;
+    DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles;
+    hipStream_t ov_stream = nullptr;
+    hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
     size_t nr_cap = 1;           // right-hand sides xp / uvec are sized for
     int top_grid_nr[2] = {-1, -1};   // the persistent kernel's grid for 2 / 4 right-hand sides (asked on first use)
     int top_count = 0, late_count = 0, top_grid = 0, top_epoch = 0;
@@ -759,6 +840,33 @@ private:
         }
         d_sched.upload(sched);
         d_tiles.upload(tiles);
+        {
+            // overlap mode: the longest suffix of block-class launches, none sliced, none with more than kOvMaxFronts fronts
+            // (a panel workgroup holds a whole CU while it waits for its children's tiles: the tiles need CUs of their own)
+            static const int ov_max = std::getenv("HIPKKT_OV_MAX_FRONTS") ? std::atoi(std::getenv("HIPKKT_OV_MAX_FRONTS")) : 120;
+            size_t first = launches.size();
+            while (first > 0) {
+                const Launch& L = launches[first - 1];
+                if (L.small || L.nsliced > 0 || L.count > ov_max) break;
+                --first;
+            }
+            ov_first = (launches.size() - first >= 3) ? first : launches.size();
+            std::vector<int> nt((size_t)S.nsuper, 0);
+            for (size_t q = ov_first; q < launches.size(); ++q) {
+                const Launch& L = launches[q];
+                for (int t = L.begin; t < L.begin + L.count; ++t) {
+                    const int sn = sched[(size_t)t];
+                    const int nb = front_size(sn) - (S.sn_start[sn + 1] - S.sn_start[sn]);
+                    const int k = (nb + 63) / 64;
+                    nt[(size_t)sn] = k * (k + 1) / 2;
+                }
+            }
+            d_ov_ntiles.upload(nt);
+            d_ov_prog.alloc((size_t)S.nsuper);
+            d_ov_done.alloc((size_t)S.nsuper);
+            HIP_CHECK(hipMemset(d_ov_prog.p, 0, (size_t)std::max(S.nsuper, 1) * sizeof(int)));
+            HIP_CHECK(hipMemset(d_ov_done.p, 0, (size_t)std::max(S.nsuper, 1) * sizeof(int)));
+        }
         {
             std::vector<int64_t> toff(S.nsuper + 1, 0);
             std::vector<char> in_list(S.nsuper, 0);
@@ -1077,10 +1185,10 @@ private:
         Dinv.alloc((size_t)S.N);
         xp.alloc((size_t)S.N);
         uvec.alloc(S.rows.size());
-        flags.alloc(2);
+        flags.alloc(4);
         HIP_CHECK(hipMemset(fronts.p, 0, std::max<size_t>(fronts.n, 1) * sizeof(double)));
         HIP_CHECK(hipMemset(Dinv.p, 0, std::max<size_t>(Dinv.n, 1) * sizeof(double)));
-        HIP_CHECK(hipMemset(flags.p, 0, 2 * sizeof(int)));
+        HIP_CHECK(hipMemset(flags.p, 0, 4 * sizeof(int)));
     }
 };
 
@@ -1434,8 +1542,13 @@ int hipkkt_ldl_refactor(hipkkt_ldl_t h)
         if (!h) throw ArgError("null handle");
         HIP_CHECK(hipSetDevice(h->device));
         h->eng->factor(h->Kval.p, nullptr);
-        int fl[2];
+        int fl[3];
         h->eng->read_flags(fl);
+        if (fl[2]) {                                            // never expected; see LDLEngine::ov_gave_up
+            h->eng->ov_gave_up();
+            h->eng->factor(h->Kval.p, nullptr);
+            h->eng->read_flags(fl);
+        }
         return fl[1] ? HIPKKT_NUMERIC_FAILURE : HIPKKT_OK;      // directldl_qdldl.jl:79
     });
 }
@@ -1744,8 +1857,15 @@ static int kkt_update_device(hipkkt_kkt_t h, bool deferred = false)
         launch_fold_update_status(h->ir_sticky, h->scal.p + 8, h->stream);
         return HIPKKT_OK;
     }
-    HIP_CHECK(hipMemcpyAsync(h->pin->h + 8, h->scal.p + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 8, h->scal.p + 8, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->pin->h[12] != 0.0) {                      // never expected; see LDLEngine::ov_gave_up: repeat level by level
+        h->eng->ov_gave_up();
+        h->eng->factor(h->Kval.p, eps_ptr);
+        launch_collect_status(h->scal.p + 8, h->scal.p, h->fail.p, h->eng->flags_ptr(), h->stream);
+        HIP_CHECK(hipMemcpyAsync(h->pin->h + 8, h->scal.p + 8, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
     h->last_eps = h->st.static_regularization_enable ? h->pin->h[8] : 0.0;
     h->prof.acc.dynamic_regularizations += (int64_t)h->pin->h[10];
     if (h->pin->h[9] != 0.0) return HIPKKT_NUMERIC_FAILURE;
@@ -2018,6 +2138,10 @@ int hipkkt_kkt_deferred_status(hipkkt_kkt_t h)
         if (s[5] != 0.0 || !h->st.static_regularization_enable) h->last_eps = h->st.static_regularization_enable ? s[5] : 0.0;
         if (s[6] > 0.0) h->last_ir = (int64_t)(s[3] / s[6] + 0.5);      // mean rounds per solve since the last query
         if (s[0] != 0.0) return HIPKKT_NUMERIC_FAILURE;
+        if (s[7] != 0.0) {                                              // never expected; see LDLEngine::ov_gave_up
+            h->eng->ov_gave_up();
+            return HIPKKT_REFINEMENT_INCOMPLETE;                        // (the step's results are void: repeat it)
+        }
         if (s[2] != 0.0 && h->eng->top_abort_word() != nullptr) {       // never expected; see TopOwner
             h->eng->top_gave_up();
             return HIPKKT_REFINEMENT_INCOMPLETE;

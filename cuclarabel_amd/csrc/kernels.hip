@@ -346,6 +346,7 @@ __global__ void k_collect_status(double* __restrict__ dst, const double* __restr
         dst[1] = conefail ? (double)conefail[0] : 0.0;
         dst[2] = (double)flags[0];
         dst[3] = (double)flags[1];
+        dst[4] = (double)flags[2];       // an overlap-mode wait of the factorisation gave up
     }
 }
 void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st)
@@ -447,6 +448,7 @@ __global__ void k_fold_update_status(double* __restrict__ sticky, const double* 
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (st4[1] != 0.0 || st4[3] != 0.0) sticky[0] = 1.0;
+        if (st4[4] != 0.0) sticky[7] = 1.0;
         sticky[4] += st4[2];
         sticky[5] = st4[0];
     }

@@ -134,7 +134,16 @@ struct FactorArgs {
     double* fronts;
     double* upd;
     double* Dinv;                // N, permuted order
-    int* flags;                  // [0] #dynamic regularisations, [1] non-finite pivot seen
+    int* flags;                  // [0] #dynamic regularisations, [1] non-finite pivot seen, [2] an overlap-mode wait gave up
+    // Overlap mode (the narrow top of the tree, factor_kernels.hip "overlap"): a level's Schur tiles run on a second
+    // stream BESIDE its panels and the next level's panels, ordered by counters in memory instead of kernel boundaries.
+    //   ov_prog[s]    panel columns of supernode s whose L / D entries are published (written through) this factorisation
+    //   ov_done[s]    Schur tiles of s completed this factorisation
+    //   ov_ntiles[s]  tiles a parent's panel must wait for (0: s is not factorised in overlap mode)
+    int* ov_prog;
+    int* ov_done;
+    const int* ov_ntiles;
+    int ov;                      // this launch runs in overlap mode
     double dyn_eps, dyn_delta;
     int nbk;                     // block-column width (<= 16), chosen so the LDS buffer fits
     long long* stamps;           // diagnostic only (HIPKKT_STAMPS=1): phase time stamps of block 0, else null
@@ -291,7 +300,7 @@ void launch_fold_update_status(double* sticky, const double* st4, hipStream_t st
 void launch_fold_flag(double* sticky, const int* flag, hipStream_t st);
 // p[0..n) = 0 with a kernel: a small hipMemsetAsync stalls the stream for ~40 us on this stack
 void launch_zero_ints(int* p, int n, hipStream_t st);
-// dst[0..3] = {eps[0], conefail[0], flags[0], flags[1]} (null pointers read as 0)
+// dst[0..4] = {eps[0], conefail[0], flags[0], flags[1], flags[2]} (null pointers read as 0)
 void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st);
 
 // ---- cone scalings on the device (update_scaling! + get_Hs!, src/cones/coneops_*.jl)

@@ -14,7 +14,10 @@ src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+have_bench = os.path.exists(os.path.join(src, "bench.json")) and os.path.getsize(os.path.join(src, "bench.json")) > 0
+if have_bench:
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+command = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else ""
 
 
 def short(name):
@@ -34,8 +37,32 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as out:
     for k, v in sorted(traffic.items(), key=lambda kv: -(kv[1]["fetch_kb"] + kv[1]["write_kb"])):
         c = max(v["calls"], 1)
         out.write(f"{k},{v['calls']},{v['fetch_kb']:.1f},{v['write_kb']:.1f},{v['fetch_kb']/c:.2f},{v['write_kb']/c:.2f}\n")
+# MFMA pipe: SQ_VALU_MFMA_BUSY_CYCLES is summed over all 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs, so the pipe's
+# utilisation inside a kernel is busy / (gui_active / 8 * 1024) = (busy / gui_active) / 128
+mf = glob.glob(os.path.join(src, "pmc_mfma", "*", "*_counter_collection.csv"))
+if mf:
+    busy = collections.defaultdict(lambda: dict(calls=0, busy=0.0, gui=0.0))
+    for r in csv.DictReader(open(mf[0])):
+        k = short(r["Kernel_Name"])
+        if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+            busy[k]["busy"] += float(r["Counter_Value"])
+            busy[k]["calls"] += 1
+        elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            busy[k]["gui"] += float(r["Counter_Value"])
+    with open(os.path.join(dst, f"{tag}_mfma_busy.csv"), "w") as out:
+        out.write("# %s -- separate pass: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE\n" % command)
+        out.write("# mfma_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)\n")
+        out.write("kernel,calls,SQ_VALU_MFMA_BUSY_CYCLES_total,GRBM_GUI_ACTIVE_total,mfma_pipe_utilisation\n")
+        for k, v in sorted(busy.items(), key=lambda kv: -kv[1]["busy"]):
+            if v["busy"] > 0:
+                out.write(f"{k},{v['calls']},{v['busy']:.0f},{v['gui']:.0f},{v['busy'] / max(v['gui'], 1.0) / 128.0:.4f}\n")
+if not have_bench:
+    json.dump(dict(tag=tag, command=command, note="kernel stats, HBM traffic and MFMA counters only (no bench line for this command)"),
+              open(os.path.join(dst, f"{tag}_traffic_summary.json"), "w"), indent=1)
+    sys.exit(0)
 bench = json.loads(open(os.path.join(src, "bench.json")).read())
-steps = bench["steps"] + bench["warmup"]
+# bench.py runs the steps three times (timed, un-instrumented sequential, instrumented sequential) after the warm-up
+steps = 3 * bench["steps"] + bench["warmup"]
 TRI = ("k_fwd", "k_bwd", "k_top_solve")
 FAC = ("k_panel", "k_schur", "k_front", "k_subtree", "k_tinv", "k_winv")
 
@@ -56,12 +83,12 @@ for k, nread, nwrite in (("k_sum2", 2, 1), ("k_absmax", 1, 0), ("k_pack_rhs", 1,
                         expected_write_KB=nwrite * N * 8 / 1024.0, WRITE_SIZE_KB=traffic[k]["write_kb"] / c)
 ratios = [v["expected_read_KB"] / v["FETCH_SIZE_KB"] for v in calib.values() if v["FETCH_SIZE_KB"] > 0]
 fetch_scale = round(sum(ratios) / len(ratios)) if ratios else 2          # measured: 2 (as for 16 B/lane reads)
-ntri = bench["phases"]["trisolve"]["launches"] / bench["steps"] * steps
+ntri = bench["phases"]["trisolve"]["launches"] / bench["steps"] * steps        # (profiled with --sequential-solves)
 tri_raw = (total(TRI, "fetch_kb") + total(TRI, "write_kb")) / ntri / 1024.0
 fac_raw = (total(FAC, "fetch_kb") + total(FAC, "write_kb")) / steps / 1024.0
 tri = (fetch_scale * total(TRI, "fetch_kb") + total(TRI, "write_kb")) / ntri / 1024.0
 fac = (fetch_scale * total(FAC, "fetch_kb") + total(FAC, "write_kb")) / steps / 1024.0
-summary = dict(tag=tag, steps_profiled=steps, csrc_sha16=bench["config"].get("csrc_sha16"),
+summary = dict(tag=tag, command=command, steps_profiled=steps, csrc_sha16=bench["config"].get("csrc_sha16"),
                trisolve_hbm_MB_per_solve=tri, factor_hbm_MB_per_factorisation=fac,
                trisolve_hbm_MB_per_solve_uncorrected=tri_raw, factor_hbm_MB_per_factorisation_uncorrected=fac_raw,
                fetch_size_scale=fetch_scale, calibration=calib,
