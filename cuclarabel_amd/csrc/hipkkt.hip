@@ -77,7 +77,8 @@ struct Launch {
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
 static constexpr int kMaxNR = 4;          // right-hand sides the single-column solve path takes in one sweep (1, 2 or 4)
-static int kSideWinvBlocks = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 192;
+static const size_t kWinvTailLaunches = std::getenv("HIPKKT_WINV_TAIL") ? (size_t)std::atoi(std::getenv("HIPKKT_WINV_TAIL")) : 4;
+static int kSideWinvBlocks = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 96;
 
 // The persistent top-of-tree solve kernel needs all its workgroups resident.  Two such kernels running
 // at the same time on one device (two handles on different streams) could each hold part of the CUs while
@@ -349,6 +350,10 @@ private:
         }
         int li = 0;
         bool forked = false;
+        // EXPERIMENT (timing only, valid when K does not change between factorisations): skip W formation after n factorisations
+        static const int skip_w_after = std::getenv("HIPKKT_EXPERIMENT_SKIP_WINV") ? std::atoi(std::getenv("HIPKKT_EXPERIMENT_SKIP_WINV")) : -1;
+        const bool skip_w = skip_w_after >= 0 && n_skipw_calls++ >= skip_w_after;
+#define launch_tinv(...) do { if (!skip_w) launch_tinv(__VA_ARGS__); } while (0)
         // eager mode: once the tree narrows to its top levels most CUs idle, so the solve matrices
         // W = [T; M] of everything below are formed on a side stream meanwhile (HIPKKT_NO_OVERLAP=1 disables)
         static const bool no_overlap = std::getenv("HIPKKT_NO_OVERLAP") != nullptr;
@@ -356,6 +361,7 @@ private:
         const size_t first_top = (!side && !no_overlap && !want_stamps && late_launches > 0 && late_launches < nl)
                                      ? nl - late_launches : nl;
         bool eager_fork = false;
+        int w_done = 0;
         for (size_t q = 0; q < nl; ++q) {
             const Launch& L = launches[q];
             a.stamp_row = li++;
@@ -367,6 +373,16 @@ private:
                 launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, launches[q].tinv_begin, tinv_ncmax, cap_side, kSideWinvBlocks);
                 HIP_CHECK(hipEventRecord(ev_join, cap_side));
                 eager_fork = true;
+                w_done = launches[q].tinv_begin;
+            }
+            // ... and again a few levels before the root for the top fronts finished so far: behind the tree only the
+            // last levels' handful of fronts is left, which the next sweep's bottom levels hide
+            if (eager_fork && q > first_top && q + kWinvTailLaunches == nl && launches[q].tinv_begin > w_done) {
+                HIP_CHECK(hipEventRecord(ev_fork, st));
+                HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
+                launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + w_done, launches[q].tinv_begin - w_done, tinv_ncmax, cap_side,
+                            kSideWinvBlocks);
+                w_done = launches[q].tinv_begin;
             }
             if (ov_on && q >= ov_first) {
                 // Panels on the main stream, the level's Schur tiles on the overlap stream,
@@ -413,7 +429,7 @@ private:
             // the solve matrices of the top fronts are formed on the side stream as well, behind the tree: the next
             // sweep only needs them when it reaches the top of the tree (enqueue_solve waits for ev_join there), so
             // their formation hides behind the sweep's bottom levels instead of ending the factorisation
-            const int done = launches[first_top].tinv_begin;
+            const int done = w_done;
             HIP_CHECK(hipEventRecord(ev_fork, st));
             HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
             launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, cap_side);
@@ -423,6 +439,7 @@ private:
             // one launch over every supernode, after the tree (all of them independent)
             launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st);
         }
+#undef launch_tinv
         HIP_CHECK(hipGetLastError());
         if (want_stamps) {
             std::vector<long long> h(launches.size() * 16);
@@ -618,6 +635,7 @@ private:
     DBuf<int> d_iperm;
     size_t multi_cap = 0;
     DBuf<int64_t> d_tinv_off;
+    int n_skipw_calls = 0;
     DBuf<int> d_tinv_list;
     std::vector<int> tinv_list;
     int tinv_ncmax = 1;

@@ -1283,16 +1283,25 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
 
 // ------------------------------------------------------------------ W = [L11^{-1} ; L21 L11^{-1}]
 // Runs once after the factorisation, all supernodes in parallel (off the critical path of the tree).
-// L11 (unit lower, nc x nc) is staged in LDS and inverted in place, blocked bottom-up:
-//   1. every 16 x 16 diagonal block is inverted by 16 threads (thread = column, forward substitution);
-//   2. for block sizes 16, 32, 64, ...: adjacent diagonal blocks A (top) and B (bottom) are joined,
-//      T21 = -T_B * (L21 * T_A), two small products whose entries are independent -- two barriers
-//      per doubling instead of two per row.
-// Then M = L21 * T, one thread per row, 8 columns at a time against T in LDS.
+// L11 (unit lower, nc x nc) is staged in LDS; T = L11^{-1} is built in 16 x 16 blocks:
+//   1. every diagonal block is inverted by 16 threads (thread = column, forward substitution), in place;
+//   2. the blocks below the diagonal by the block recurrence
+//          T(k,b) = -T_k * sum_{j=b..k-1} L(k,j) T(j,b),     k = b+1, b+2, ...
+//      one WAVE per block column b (the columns are independent of each other), every product on
+//      v_mfma_f64_16x16x4_f64 with operands from LDS; T(k,b) goes to the transposed slot (b,k) in the unused upper
+//      triangle, so that the L(k,j) the other block columns still need stay where they are.  The accumulator layout
+//      of the first product (row = lane>>4 + 4q) is exactly the B operand layout of the second (k = 4t + lane>>4):
+//      no exchange between the two.
+// Then M = L21 * T, a wave per strip of 16 rows against T in LDS (A operands of a strip fetched ahead of the products).
+constexpr int kWinvThreads = 512;
 __device__ inline void winv_one(const TreeDev& T, const double* __restrict__ fronts, double* __restrict__ wst, int s,
                                 double* smem)
 {
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    constexpr int NT = kWinvThreads, NWV = NT / 64;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wvi = tid >> 6;
+    const int ml = lane & 15, mk = lane >> 4;
     const int c0 = T.sn_start[s];
     const int nc = T.sn_start[s + 1] - c0;
     const int nb = (int)(T.rowptr[s + 1] - T.rowptr[s]);
@@ -1300,18 +1309,18 @@ __device__ inline void winv_one(const TreeDev& T, const double* __restrict__ fro
     const double* __restrict__ F = fronts + T.front_off[s];
     double* __restrict__ W = wst + T.tinv_off[s];
     const int ld = nc | 1;
-    double* Ls = smem;                 // entry (i,k), i > k, at i*ld + k ; becomes T in place
-    // scratch W(i,c), i > c, lives in the unused upper triangle at the transposed slot c*ld + i
+    const int nblk = (nc + 15) >> 4;
+    double* Ls = smem;                 // entry (i,k), i > k, at i*ld + k
+    // scratch / off-diagonal T(i,c), i > c, lives in the unused upper triangle at the transposed slot c*ld + i
 #define WK(i, c) Ls[(c) * ld + (i)]
-    for (int idx = tid; idx < nc * nc; idx += 256) {
+    for (int idx = tid; idx < nc * nc; idx += NT) {
         const int k = idx / nc, i = idx - k * nc;
         if (i > k) Ls[i * ld + k] = F[i + (int64_t)k * f];
     }
     __syncthreads();
     // ---- 1. diagonal 16 x 16 blocks: thread (block b, column j) solves L_bb t = e_j in registers
     {
-        const int nblk = (nc + 15) >> 4;
-        for (int item = tid; item < nblk * 16; item += 256) {
+        for (int item = tid; item < nblk * 16; item += NT) {
             const int b = item >> 4, j = item & 15;
             const int o = 16 * b, w = min(16, nc - o);
             if (j >= w) continue;
@@ -1333,76 +1342,93 @@ __device__ inline void winv_one(const TreeDev& T, const double* __restrict__ fro
                 if (i > j && i < w) WK(o + i, o + j) = t[i];
         }
         __syncthreads();
-        for (int item = tid; item < nblk * 256; item += 256) {
+        for (int item = tid; item < nblk * 256; item += NT) {
             const int b = item >> 8, i = (item >> 4) & 15, j = item & 15;
             const int o = 16 * b;
             if (i > j && o + i < nc) Ls[(o + i) * ld + o + j] = WK(o + i, o + j);
         }
         __syncthreads();
     }
-    // ---- 2. join adjacent blocks of size bs: rows [o+bs, o+2bs) x cols [o, o+bs)
-    for (int bs = 16; bs < nc; bs <<= 1) {
-        const int npair = (nc + 2 * bs - 1) / (2 * bs);
-        // W = L21 * T_A   (T_A unit lower: W(r,c) = L21(r,c) + sum_{k>c} L21(r,k) T_A(k,c))
-        for (int item = tid; item < npair * bs * bs; item += 256) {
-            const int p = item / (bs * bs), rem = item - p * bs * bs;
-            const int r = rem / bs, c = rem - r * bs;
-            const int o = 2 * bs * p;
-            const int gi = o + bs + r, gc = o + c;
-            if (gi >= nc) continue;
-            double acc = Ls[gi * ld + gc];
-            for (int k = c + 1; k < bs; ++k) acc = fma(Ls[gi * ld + o + k], Ls[(o + k) * ld + gc], acc);
-            WK(gi, gc) = acc;
+    // ---- 2. block column b of T, top to bottom (wave = block column)
+    for (int b = wvi; b + 1 < nblk; b += NWV) {
+        const int ob = 16 * b;
+        for (int k = b + 1; k < nblk; ++k) {
+            const int ok = 16 * k;
+            const int ri = ok + ml;                    // row of block k this lane feeds as A
+            d4_t S = (d4_t){0.0, 0.0, 0.0, 0.0};
+            for (int j = b; j < k; ++j) {
+                const int oj = 16 * j;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = 4 * t + mk;         // index inside block j
+                    const double a = (ri < nc) ? Ls[ri * ld + oj + kk] : 0.0;         // L(k,j)[ml][kk]  (oj + kk < ok <= ri)
+                    double bv;                                                        // T(j,b)[kk][ml]
+                    if (j == b) bv = (kk > ml) ? Ls[(ob + kk) * ld + ob + ml] : (kk == ml ? 1.0 : 0.0);
+                    else bv = WK(oj + kk, ob + ml);
+                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, S, 0, 0, 0);
+                }
+            }
+            d4_t R = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kk = 4 * t + mk;
+                double a = 0.0;                                                       // T_k[ml][kk], unit lower
+                if (ri < nc && ok + kk < nc) a = (ml > kk) ? Ls[ri * ld + ok + kk] : (ml == kk ? 1.0 : 0.0);
+                R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, S[t], R, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = ok + mk + 4 * q;
+                if (i < nc) WK(i, ob + ml) = -R[q];
+            }
         }
-        __syncthreads();
-        // T21 = -T_B * W   (T_B unit lower: T21(r,c) = -(W(r,c) + sum_{k<r} T_B(r,k) W(k,c)))
-        for (int item = tid; item < npair * bs * bs; item += 256) {
-            const int p = item / (bs * bs), rem = item - p * bs * bs;
-            const int r = rem / bs, c = rem - r * bs;
-            const int o = 2 * bs * p;
-            const int gi = o + bs + r, gc = o + c;
-            if (gi >= nc) continue;
-            double acc = WK(gi, gc);
-            for (int k = 0; k < r; ++k) acc = fma(Ls[gi * ld + o + bs + k], WK(o + bs + k, gc), acc);
-            Ls[gi * ld + gc] = -acc;
-        }
-        __syncthreads();
     }
-#undef WK
+    __syncthreads();
+    // T(i,j), i > j: inside a diagonal block in place, below it in the transposed slot
+#define TGET(i, j) ((((i) ^ (j)) & ~15) == 0 ? Ls[(i) * ld + (j)] : WK(i, j))
     // ---- 3. T part of W (unit diagonal, zeros above), and of its transpose copy Wt (nc x f)
     double* __restrict__ Wt = W + (int64_t)f * nc;
-    for (int idx = tid; idx < nc * nc; idx += 256) {
+    for (int idx = tid; idx < nc * nc; idx += NT) {
         const int j = idx / nc, i = idx - j * nc;
-        W[i + (int64_t)j * f] = (i > j) ? Ls[i * ld + j] : (i == j ? 1.0 : 0.0);
+        W[i + (int64_t)j * f] = (i > j) ? TGET(i, j) : (i == j ? 1.0 : 0.0);
     }
-    for (int idx = tid; idx < nc * nc; idx += 256) {
+    for (int idx = tid; idx < nc * nc; idx += NT) {
         const int i = idx / nc, j = idx - i * nc;
-        Wt[j + (int64_t)i * nc] = (i > j) ? Ls[i * ld + j] : (i == j ? 1.0 : 0.0);
+        Wt[j + (int64_t)i * nc] = (i > j) ? TGET(i, j) : (i == j ? 1.0 : 0.0);
     }
     // ---- 4. M = L21 * T on the matrix cores (v_mfma_f64_16x16x4_f64): a wave owns a strip of 16 rows
-    //         and all column tiles; A = L21 straight from global (16 contiguous rows per k), B = T from LDS
-    //         with its unit diagonal / zero upper part generated on the fly; column tiles right of k are skipped.
+    //         and all column tiles; A = L21 straight from global (16 contiguous rows per k, a batch of k's in flight),
+    //         B = T from LDS with its unit diagonal / zero upper part generated on the fly; column tiles right of k are skipped.
     {
-        typedef double d4_t __attribute__((ext_vector_type(4)));
-        const int lane = tid & 63, wvi = tid >> 6;
-        const int ml = lane & 15, mk = lane >> 4;
-        const int nct = (nc + 15) >> 4;                 // column tiles (<= 9 for nc <= 144)
-        for (int strip = wvi; strip * 16 < nb; strip += 4) {
+        const int nct = nblk;                           // column tiles (<= 9 for nc <= 144)
+        constexpr int KB = 12;                          // k-steps (of 4) fetched together
+        for (int strip = wvi; strip * 16 < nb; strip += NWV) {
             const int r = strip * 16 + ml;
             const double* __restrict__ Lr = F + nc + r;
             d4_t acc[9];
 #pragma unroll
             for (int jt = 0; jt < 9; ++jt) acc[jt] = (d4_t){0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < nc; k0 += 4) {
-                const int k = k0 + mk;
-                const double a = (r < nb && k < nc) ? Lr[(int64_t)k * f] : 0.0;
+            for (int kb0 = 0; kb0 < nc; kb0 += 4 * KB) {
+                double av[KB];
 #pragma unroll
-                for (int jt = 0; jt < 9; ++jt) {
-                    if (jt < nct && 16 * jt <= k0 + 3) {
-                        const int j = 16 * jt + ml;
-                        double bv = 0.0;
-                        if (k < nc && j < nc) bv = (k > j) ? Ls[k * ld + j] : (k == j ? 1.0 : 0.0);
-                        acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[jt], 0, 0, 0);
+                for (int u = 0; u < KB; ++u) {
+                    const int k = kb0 + 4 * u + mk;
+                    av[u] = (r < nb && k < nc) ? Lr[(int64_t)k * f] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int k0 = kb0 + 4 * u;
+                    if (k0 < nc) {
+                        const int k = k0 + mk;
+#pragma unroll
+                        for (int jt = 0; jt < 9; ++jt) {
+                            if (jt < nct && 16 * jt <= k0 + 3) {
+                                const int j = 16 * jt + ml;
+                                double bv = 0.0;
+                                if (k < nc && j < nc) bv = (k > j) ? TGET(k, j) : (k == j ? 1.0 : 0.0);
+                                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv, acc[jt], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -1422,10 +1448,12 @@ __device__ inline void winv_one(const TreeDev& T, const double* __restrict__ fro
             }
         }
     }
+#undef TGET
+#undef WK
 }
 
 // count supernodes, any grid: a small grid keeps this off most CUs when it runs beside the tree's critical path
-__global__ __launch_bounds__(256) void k_winv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ wst,
+__global__ __launch_bounds__(kWinvThreads) void k_winv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ wst,
                                               const int* __restrict__ list, int count)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -2038,7 +2066,7 @@ void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int
     init_solve_lds();
     const size_t lds = (size_t)ncmax * (ncmax | 1) * sizeof(double);
     const int grid = (max_blocks > 0 && max_blocks < count) ? max_blocks : count;
-    hipLaunchKernelGGL(k_winv, dim3(grid), dim3(256), lds, st, T, fronts, tinv, list, count);
+    hipLaunchKernelGGL(k_winv, dim3(grid), dim3(kWinvThreads), lds, st, T, fronts, tinv, list, count);
 }
 
 }  // namespace hipkkt
