@@ -10,7 +10,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libhipkkt.so")
+# (HIPKKT_LIB: another build of the same library, for A/B timing of kernel variants on one box)
+SO_PATH = os.environ.get("HIPKKT_LIB") or os.path.join(_HERE, "libhipkkt.so")
 
 OK, NUMERIC_FAILURE, REFINEMENT_INCOMPLETE = 0, 1, 2
 ORDER_AMD, ORDER_ND, ORDER_NATURAL, ORDER_USER = 0, 1, 2, 3

@@ -792,39 +792,41 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     const int ml = lane & 15, mk = lane >> 4;
-    // the pass-through work list is static data: fetch this wave's range and its first eight descriptors now,
-    // so that after the product only the (rel, value) loads remain on the critical path
+    // the pass-through work list is static data: fetch this wave's range and its first 64 descriptors now -- lane l
+    // takes descriptor l, ONE vector load round -- so that after the product only (rel, value) load rounds remain
     const int64_t* __restrict__ tc = T.tile_cut + 5 * (int64_t)(tile_begin + blockIdx.x);
     const int64_t i0 = tc[wv], i1 = tc[wv + 1];
-    SubItem it[8];
-#pragma unroll
-    for (int z = 0; z < 8; ++z) {
-        it[z] = T.sitems[max(min(i0 + z, i1 - 1), (int64_t)0)];
-        if (i0 + z >= i1) it[z].cnt = 0;
-    }
+    static_assert(sizeof(SubItem) == 16, "SubItem is read as an int4");
+    const int4* __restrict__ sit4 = reinterpret_cast<const int4*>(T.sitems);
+    int4 mine = (i0 < i1) ? sit4[min(i0 + lane, i1 - 1)] : make_int4(0, 0, 0, 0);
     // children pass-through: this wave's slice of the tile's sub-items (whole columns, child order),
-    // eight in flight: one round of descriptor loads, one round of (rel, value) loads, then LDS adds
+    // PT in flight: the descriptors handed out with v_readlane, one round of (rel, value) loads, then LDS adds
     auto pass_through = [&]() {
+        constexpr int PT = 16;
         const int rlo = nc + r0;
-        for (int64_t ii = i0; ii < i1; ii += 8) {
-            double v[8];
-            int tg[8];
-            if (ii > i0) {
+        double* ct = &Ct[0][0];
+        for (int64_t base = i0; base < i1; base += 64) {
+            if (base > i0) mine = sit4[min(base + lane, i1 - 1)];
+            const int n = (int)min((int64_t)64, i1 - base);
+            for (int z0 = 0; z0 < n; z0 += PT) {
+                double v[PT];
+                int tg[PT];
 #pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    it[z] = T.sitems[min(ii + z, i1 - 1)];
-                    if (ii + z >= i1) it[z].cnt = 0;
+                for (int z = 0; z < PT; ++z) {
+                    const int src = min(z0 + z, 63);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(mine.x, src);
+                    const int hi = __builtin_amdgcn_readlane(mine.y, src);
+                    const int relstart = __builtin_amdgcn_readlane(mine.z, src);
+                    const int cq = __builtin_amdgcn_readlane(mine.w, src);          // cnt | qcol << 8
+                    const int64_t uoff = ((int64_t)hi << 32) | lo;
+                    const int cnt = (z0 + z < n) ? (cq & 0xff) : 0, qcol = (cq >> 8) & 0xff;
+                    const bool ok = lane < cnt;
+                    v[z] = ok ? A.upd[uoff + lane] : 0.0;
+                    tg[z] = ok ? qcol * (TS + 1) + (T.rel[relstart + lane] - rlo) : -1;
                 }
-            }
 #pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                const bool ok = lane < (int)it[z].cnt;
-                v[z] = ok ? A.upd[it[z].uoff + lane] : 0.0;
-                tg[z] = ok ? (int)it[z].qcol * (TS + 1) + (T.rel[it[z].relstart + lane] - rlo) : -1;
+                for (int z = 0; z < PT; ++z) if (tg[z] >= 0) lds_add(ct + tg[z], v[z]);
             }
-            double* ct = &Ct[0][0];
-#pragma unroll
-            for (int z = 0; z < 8; ++z) if (tg[z] >= 0) lds_add(ct + tg[z], v[z]);
         }
     };
     if (OV) {
