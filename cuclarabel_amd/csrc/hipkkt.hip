@@ -78,6 +78,7 @@ struct Launch {
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
 static constexpr int kMaxNR = 4;          // right-hand sides the single-column solve path takes in one sweep (1, 2 or 4)
 static const size_t kWinvTailLaunches = std::getenv("HIPKKT_WINV_TAIL") ? (size_t)std::atoi(std::getenv("HIPKKT_WINV_TAIL")) : 4;
+static const size_t kWinvEarlyLaunches = std::getenv("HIPKKT_WINV_EARLY") ? (size_t)std::atoi(std::getenv("HIPKKT_WINV_EARLY")) : 1;
 static int kSideWinvBlocks = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 96;
 
 // The persistent top-of-tree solve kernel needs all its workgroups resident.  Two such kernels running
@@ -124,7 +125,7 @@ public:
                          "%zu row slices; persistent solve set: last %zu launches, %d fronts on %d workgroups, %d (front, slice) tasks; "
                          "factorisation overlap: last %zu launches\n",
                          S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
-                         top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, launches.size() - ov_first);
+                         top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, overlap_wanted() ? launches.size() - ov_first : (size_t)0);
         }
     }
 
@@ -266,6 +267,7 @@ public:
         if (cap_side) (void)hipStreamDestroy(cap_side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_side) (void)hipEventDestroy(ev_side);
         if (ov_stream) (void)hipStreamDestroy(ov_stream);
         if (ev_ov_fork) (void)hipEventDestroy(ev_ov_fork);
         if (ev_ov_join) (void)hipEventDestroy(ev_ov_join);
@@ -274,7 +276,7 @@ public:
 private:
     std::map<std::pair<const void*, const void*>, hipGraphExec_t> factor_graphs, solve_graphs;
     hipStream_t cap_stream = nullptr, cap_side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side = nullptr;
     long n_factor_calls = 0, n_solve_calls = 0;
 
     void ensure_capture_streams()
@@ -284,6 +286,7 @@ private:
         HIP_CHECK(hipStreamCreateWithFlags(&cap_side, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
     }
 
     // side != nullptr: put the T = L11^{-1} kernels on that stream, forked after each level's panels
@@ -292,12 +295,12 @@ private:
         wait_w(st);                  // (a refactorisation without a solve in between: the side stream still reads the fronts)
         launch_zero_ints(flags.p, 3, st);
         // overlap mode (eager launches only): the top launches' Schur tiles on their own stream, ordered by counters
-        // Opt-in (HIPKKT_FACTOR_OVERLAP=1).  Measured on cfg2: the tiles hide completely behind the panels (a top level
-        // costs its panel kernel, 63 us, instead of panel + tiles, 79 us; factorisation 2.05 -> 1.97 ms), but the step does
-        // not get shorter yet: the solve matrices W of the top fronts are formed behind the tree either way, and the first
-        // sweep after the factorisation waits for them by as much as the factorisation ended earlier (3.667 vs 3.661 ms
-        // per step).  It pays once W formation moves off that path.
-        static const bool want_ov = std::getenv("HIPKKT_FACTOR_OVERLAP") != nullptr && std::atoi(std::getenv("HIPKKT_FACTOR_OVERLAP")) != 0;
+        // in memory instead of kernel boundaries.  On by default (HIPKKT_FACTOR_OVERLAP=0 turns it off).  Measured on cfg2:
+        // the tiles hide completely behind the panels (a top level costs its panel kernel instead of panel + tiles:
+        // factorisation 1.85 -> 1.79 ms); it pays since the solve matrices W are formed early enough on the side stream
+        // (3.43 -> 3.365 ms per step; with the round's earlier, slower W formation the first sweep waited for W by as
+        // much as the factorisation ended earlier).
+        const bool want_ov = overlap_wanted();
         const bool use_ov = want_ov && !side && !want_stamps && !ov_disabled && ov_first < launches.size();
         if (use_ov) {
             if (!ov_stream) {
@@ -365,24 +368,22 @@ private:
         for (size_t q = 0; q < nl; ++q) {
             const Launch& L = launches[q];
             a.stamp_row = li++;
-            if (q == first_top && launches[q].tinv_begin > 0) {
+            // fork points of the side stream: a few levels before the narrow top (the bulk of the fronts), at the narrow
+            // top, and a few levels before the root -- behind the tree only the last levels' handful of fronts is left,
+            // which the next sweep's bottom levels hide
+            if (first_top < nl && (q + kWinvEarlyLaunches == first_top || q == first_top ||
+                                   (q > first_top && q + kWinvTailLaunches == nl)) && launches[q].tinv_begin > w_done) {
                 ensure_capture_streams();
                 HIP_CHECK(hipEventRecord(ev_fork, st));
                 HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
                 // a bounded grid: the top panels need whole CUs (their LDS), which a full-width launch would hold
-                launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, launches[q].tinv_begin, tinv_ncmax, cap_side, kSideWinvBlocks);
-                HIP_CHECK(hipEventRecord(ev_join, cap_side));
-                eager_fork = true;
-                w_done = launches[q].tinv_begin;
-            }
-            // ... and again a few levels before the root for the top fronts finished so far: behind the tree only the
-            // last levels' handful of fronts is left, which the next sweep's bottom levels hide
-            if (eager_fork && q > first_top && q + kWinvTailLaunches == nl && launches[q].tinv_begin > w_done) {
-                HIP_CHECK(hipEventRecord(ev_fork, st));
-                HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
                 launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + w_done, launches[q].tinv_begin - w_done, tinv_ncmax, cap_side,
                             kSideWinvBlocks);
+                eager_fork = true;
                 w_done = launches[q].tinv_begin;
+                // the fronts below the narrow top are used by the next sweep's first launches: the factorisation ends
+                // with a wait for this event (normally long past by then)
+                if (q <= first_top) HIP_CHECK(hipEventRecord(ev_side, cap_side));
             }
             if (ov_on && q >= ov_first) {
                 // Panels on the main stream, the level's Schur tiles on the overlap stream,
@@ -430,6 +431,7 @@ private:
             // sweep only needs them when it reaches the top of the tree (enqueue_solve waits for ev_join there), so
             // their formation hides behind the sweep's bottom levels instead of ending the factorisation
             const int done = w_done;
+            HIP_CHECK(hipStreamWaitEvent(st, ev_side, 0));
             HIP_CHECK(hipEventRecord(ev_fork, st));
             HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
             launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, cap_side);
@@ -622,7 +624,12 @@ public:
         ov_disabled = true;
         std::fprintf(stderr, "[hipkkt] factorisation overlap gave up waiting; falling back to one level after the other\n");
     }
-    bool ov_active() const { return !ov_disabled && ov_first < launches.size(); }
+    static bool overlap_wanted()
+    {
+        static const bool v = !(std::getenv("HIPKKT_FACTOR_OVERLAP") && std::atoi(std::getenv("HIPKKT_FACTOR_OVERLAP")) == 0);
+        return v;
+    }
+    bool ov_active() const { return overlap_wanted() && !ov_disabled && ov_first < launches.size(); }
 
     int* flags_ptr() { return flags.p; }
 
@@ -1457,17 +1464,23 @@ int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* row
         if (std::getenv("HIPKKT_DUMP_LEVELS")) {          // diagnostic: the shape of every tree level (host only)
             for (size_t l = 0; l < S.levels.size(); ++l) {
                 int cnt = 0, fmax = 0, ncmax = 0, n8 = 0, n64 = 0;
+                int lds3 = 0, lds2 = 0, lds1 = 0;        // panels (f > 64) that would fit 3 / 2 / 1 to a CU's LDS
                 double flops = 0, panel = 0, upd = 0, cols = 0;
                 for (int t = S.levels[l].begin; t < S.levels[l].end; ++t) {
                     const int sn = S.level_sn[t];
                     const int nc = S.sn_start[sn + 1] - S.sn_start[sn], nb = (int)(S.rowptr[sn + 1] - S.rowptr[sn]), f = nc + nb;
                     ++cnt; fmax = std::max(fmax, f); ncmax = std::max(ncmax, nc);
                     n8 += f <= 8; n64 += f <= 64;
+                    if (f > 64) {
+                        const size_t b = panel_lds_bytes(f, f * nc - nc * (nc - 1) / 2);
+                        (b <= 52 * 1024 ? lds3 : b <= 79 * 1024 ? lds2 : lds1)++;
+                    }
                     cols += nc; panel += (double)f * nc; upd += (double)nb * nb;
                     for (int j = 0; j < nc; ++j) { const double c = f - 1 - j; flops += c * c + 3 * c; }
                 }
                 std::fprintf(stderr, "[levels] %2zu: %6d fronts (%6d f<=8, %6d f<=64) fmax %4d ncmax %3d cols %7.0f panel %.2f MB "
-                             "upd %.2f MB flops %.1f M\n", l, cnt, n8, n64, fmax, ncmax, cols, panel * 8e-6, upd * 8e-6, flops * 1e-6);
+                             "upd %.2f MB flops %.1f M | panels by LDS <=52K %d, <=79K %d, more %d\n", l, cnt, n8, n64, fmax, ncmax, cols, panel * 8e-6,
+                             upd * 8e-6, flops * 1e-6, lds3, lds2, lds1);
             }
         }
         if (perm_out) for (int64_t i = 0; i < N; ++i) perm_out[i] = S.perm[i];

@@ -920,15 +920,17 @@ def test_small_batches_share_sweeps_and_match_single_solves(k):
 
 @pytest.mark.parametrize("maker", ["problems.config2(n=20000)", "problems.config5(n=300, npsd=6, psd_dim=6, nsoc=4, soc_dim=12)",
                                    "problems.config3(nblocks=6, blk=200)"])
-def test_factorisation_overlap_mode(maker):
-    """HIPKKT_FACTOR_OVERLAP=1 (opt-in): the top levels' Schur tiles run on a second stream beside their panels and the
-    next level's panels, ordered by counters in memory (published panel blocks, finished tiles) instead of kernel
-    boundaries.  Solutions must match the oracle, no bounded wait may expire, and the mode must really be on."""
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_factorisation_overlap_mode(maker, overlap):
+    """Overlap mode of the factorisation (the default; HIPKKT_FACTOR_OVERLAP=0 turns it off): the top levels' Schur tiles
+    run on a second stream beside their panels and the next level's panels, ordered by counters in memory (published
+    panel blocks, finished tiles) instead of kernel boundaries.  In both modes the solutions must match the oracle; with
+    the mode on no bounded wait may expire and the mode must really be on."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_FACTOR_OVERLAP="1", HIPKKT_VERBOSE="1")
+    env = dict(os.environ, HIPKKT_FACTOR_OVERLAP=overlap, HIPKKT_VERBOSE="1")
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -936,4 +938,4 @@ def test_factorisation_overlap_mode(maker):
     assert "gave up" not in r.stderr, r.stderr
     import re
     m = re.search(r"factorisation overlap: last (\d+) launches", r.stderr)
-    assert m and int(m.group(1)) >= 3, r.stderr
+    assert m and (int(m.group(1)) >= 3 if overlap == "1" else int(m.group(1)) == 0), r.stderr
