@@ -1057,6 +1057,28 @@ private:
                     }
             }
             if (S.rows.size() >= ((size_t)1 << 31)) throw std::runtime_error("row structure exceeds int32 indexing");
+            if (std::getenv("HIPKKT_VERBOSE") && std::atoi(std::getenv("HIPKKT_VERBOSE")) >= 2 && top_launches > 0) {
+                // gather-list lengths of the rows of the persistent solve set (what k_top_solve's parked indices must cover)
+                long hist[6] = {0, 0, 0, 0, 0, 0};
+                long fronts_over8 = 0, fronts_over12 = 0, nf = 0;
+                int64_t gmax = 0;
+                for (size_t q = launches.size() - top_launches; q < launches.size(); ++q)
+                    for (int t = launches[q].begin; t < launches[q].begin + launches[q].count; ++t) {
+                        const int sn = sched[(size_t)t];
+                        const int f = front_size(sn);
+                        int64_t fm = 0;
+                        for (int i = 0; i < f; ++i) {
+                            const int64_t n = ptr[lbase(sn) + i + 1] - ptr[lbase(sn) + i];
+                            hist[n == 0 ? 0 : n <= 4 ? 1 : n <= 8 ? 2 : n <= 12 ? 3 : n <= 16 ? 4 : 5]++;
+                            fm = std::max(fm, n);
+                        }
+                        gmax = std::max(gmax, fm);
+                        fronts_over8 += fm > 8; fronts_over12 += fm > 12; ++nf;
+                    }
+                std::fprintf(stderr, "[hipkkt] persistent solve set: gather sources per row: 0: %ld, 1-4: %ld, 5-8: %ld, 9-12: %ld, "
+                             "13-16: %ld, more: %ld (max %lld); fronts with a row over 8: %ld, over 12: %ld of %ld\n",
+                             hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], (long long)gmax, fronts_over8, fronts_over12, nf);
+            }
             d_item_ptr.upload(ptr);
             // extend-add items of the PANEL columns (the update-block columns go through the Schur sub-items):
             // one record per child update column and 64-row piece of it, grouped by the (global, permuted) panel

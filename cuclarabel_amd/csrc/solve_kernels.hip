@@ -63,10 +63,20 @@ __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int
     if (!leaf && lane < f) {                  // (a leaf has no gather lists to look at)
         const int64_t lc = (int64_t)c0 + rp + lane;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; ++g) {
-            const int src = T.gl_src[g];
+        // four sources per pair of load rounds (indices, then all columns' values); sums in list order
+        for (int64_t g = g0; g < g1; g += 4) {
+            int src[4];
+            double u[NR][4];
 #pragma unroll
-            for (int c = 0; c < NR; ++c) y[c] += A.uvec[c * A.ld_uvec + src];
+            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < NR; ++c) u[c][q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NR; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (src[q] >= 0) y[c] += u[c][q];
         }
     }
     // column sweep: y_l -= L(l,k) y_k
@@ -178,10 +188,20 @@ __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int
     if (!leaf && sub < f) {
         const int64_t lc = (int64_t)c0 + rp + sub;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; ++g) {
-            const int src = T.gl_src[g];
+        // four sources per pair of load rounds (indices, then all columns' values); sums in list order
+        for (int64_t g = g0; g < g1; g += 4) {
+            int src[4];
+            double u[NR][4];
 #pragma unroll
-            for (int c = 0; c < NR; ++c) y[c] += A.uvec[c * A.ld_uvec + src];
+            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < NR; ++c) u[c][q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NR; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (src[q] >= 0) y[c] += u[c][q];
         }
     }
     double lv[kTinyFront];
@@ -309,17 +329,17 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
         }
         const int64_t lc = (int64_t)c0 + rp + i;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; g += 4) {
-            int src[4];
+        for (int64_t g = g0; g < g1; g += 8) {
+            int src[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+            for (int q = 0; q < 8; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
-                double u[4];
+                double u[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) u[q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
+                for (int q = 0; q < 8; ++q) u[q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[c] += u[q];
+                for (int q = 0; q < 8; ++q) if (src[q] >= 0) v[c] += u[q];
             }
         }
 #pragma unroll
@@ -505,6 +525,24 @@ typedef __attribute__((address_space(1))) int gint;
 #define LD_AGENT_F64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ST_AGENT_F64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
+// The tail of a row's gather list, GPB sources per pair of load rounds (indices, then values) instead of two dependent
+// loads per source; sums in list order.
+template <int GPB>
+__device__ inline double gather_rest(const TreeDev& T, const double* uvec, int64_t g, int64_t g1, double v)
+{
+    for (; g < g1; g += GPB) {
+        int src[GPB];
+        double u[GPB];
+#pragma unroll
+        for (int q = 0; q < GPB; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+#pragma unroll
+        for (int q = 0; q < GPB; ++q) u[q] = src[q] >= 0 ? LD_AGENT_F64(uvec + src[q]) : 0.0;
+#pragma unroll
+        for (int q = 0; q < GPB; ++q) if (src[q] >= 0) v += u[q];
+    }
+    return v;
+}
+
 __device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long long t0, long long limit)
 {
     for (;;) {
@@ -620,13 +658,23 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
                 for (int q = 0; q < GP; ++q) v += u[c][q];
                 bmine[c] = v;
             }
-            for (int64_t g = g0 + GP; g < g1; ++g) {
-                const int src = T.gl_src[g];
-                double w[NR];
+            // rows with more sources than the parked ones (a few separator rows collect up to ~50): the same two load
+            // rounds per GP sources -- indices, then all columns' values -- instead of two dependent loads per source;
+            // the order of the sums is the list's order as before
+            for (int64_t gb = g0 + GP; gb < g1; gb += GP) {
 #pragma unroll
-                for (int c = 0; c < NR; ++c) w[c] = LD_AGENT_F64(A.uvec + c * A.ld_uvec + src);
+                for (int q = 0; q < GP; ++q) gsrc[q] = (gb + q < g1) ? T.gl_src[gb + q] : -1;
 #pragma unroll
-                for (int c = 0; c < NR; ++c) bmine[c] += w[c];
+                for (int q = 0; q < GP; ++q)
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) u[c][q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + c * A.ld_uvec + gsrc[q]) : 0.0;
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    double v = bmine[c];
+#pragma unroll
+                    for (int q = 0; q < GP; ++q) if (gsrc[q] >= 0) v += u[c][q];
+                    bmine[c] = v;
+                }
             }
 #pragma unroll
             for (int c = 0; c < NR; ++c) y[c * cst + tid] = bmine[c];
@@ -893,7 +941,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
                 double v = bmine;
     #pragma unroll
                 for (int q = 0; q < GP; ++q) v += u[q];
-                for (int64_t g = g0 + GP; g < g1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+                v = gather_rest<8>(T, A.uvec, g0 + GP, g1, v);
                 y[tid] = v;
             }
             for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
@@ -1019,7 +1067,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
                 double v = bm[x];
 #pragma unroll
                 for (int q = 0; q < kSlGP; ++q) v += u[q];
-                for (int64_t g = g0[x] + kSlGP; g < g1[x]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+                v = gather_rest<8>(T, A.uvec, g0[x] + kSlGP, g1[x], v);
                 yloc[lr] = v;
                 if (sl == 0 && lr < nc) ytop[lr] = v;
             }
@@ -1039,7 +1087,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             double v = bt;
 #pragma unroll
             for (int q = 0; q < kSlGP; ++q) v += u[q];
-            for (int64_t g = gt0 + kSlGP; g < gt1; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
+            v = gather_rest<8>(T, A.uvec, gt0 + kSlGP, gt1, v);
             ytop[tid] = v;
         }
         __syncthreads();
