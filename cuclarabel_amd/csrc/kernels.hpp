@@ -163,7 +163,9 @@ struct SolveArgs {
     double* uvec;                // sum nb
     // NR right-hand sides in one launch (the single-column kernels' NR template parameter): column c of b, out, xp,
     // uvec lives at these strides
-    int64_t ld_b, ld_out, ld_xp, ld_uvec;
+    int64_t ld_b, ld_out, ld_xp, ld_uvec;   // (b, out: columns ld apart.  The sweeps' internal vectors xp and uvec keep their
+                                            //  NR columns INTERLEAVED -- entry i of column c at i * NR + c -- so that a gather
+                                            //  touches one cache line for all columns; ld_xp / ld_uvec are unused)
     // k_top_solve_sliced (sets with very tall fronts): its tasks are (front, slice) pairs -- a front whose W is too
     // large for one CU to stream per hop is cut into R slices (rows of W forward, columns of x backward) that never
     // exchange anything.  Task t works on the front at set position tk_pos[t], slice tk_sl[t] & 0xff of tk_sl[t] >> 8;

@@ -40,6 +40,29 @@ __device__ inline double wave_reduce_sum(double v)
 // columns cost little more than one -- which is what lets an interior-point iteration's independent solves (constant
 // and affine right-hand sides, /root/reference/src/kktsystem.jl:87-88 vs :170-171) share a sweep.
 // ------------------------------------------------------------------ small fronts, one wave each
+// The sweeps' internal vectors (xp, uvec) keep their NR columns interleaved: entry i of column c at i * NR + c.
+// One 8 * NR-byte access fetches / stores an entry of every column (the stores are 256-byte aligned allocations).
+template <int NR>
+__device__ inline void ldv(const double* __restrict__ base, int64_t i, double (&out)[NR])
+{
+    if constexpr (NR == 1) out[0] = base[i];
+    else if constexpr (NR == 2) {
+        const double2 t = *reinterpret_cast<const double2*>(base + 2 * i);
+        out[0] = t.x; out[1] = t.y;
+    } else {
+        static_assert(NR == 4, "1, 2 or 4 right-hand sides");
+        const double4 t = *reinterpret_cast<const double4*>(base + 4 * i);
+        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+    }
+}
+template <int NR>
+__device__ inline void stv(double* __restrict__ base, int64_t i, const double (&v)[NR])
+{
+    if constexpr (NR == 1) base[i] = v[0];
+    else if constexpr (NR == 2) *reinterpret_cast<double2*>(base + 2 * i) = make_double2(v[0], v[1]);
+    else *reinterpret_cast<double4*>(base + 4 * i) = make_double4(v[0], v[1], v[2], v[3]);
+}
+
 template <int NR>
 __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, bool leaf = false)
 {
@@ -70,9 +93,14 @@ __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                double t[NR];
 #pragma unroll
-                for (int c = 0; c < NR; ++c) u[c][q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
+                for (int c = 0; c < NR; ++c) t[c] = 0.0;
+                if (src[q] >= 0) ldv<NR>(A.uvec, src[q], t);
+#pragma unroll
+                for (int c = 0; c < NR; ++c) u[c][q] = t[c];
+            }
 #pragma unroll
             for (int c = 0; c < NR; ++c)
 #pragma unroll
@@ -99,11 +127,8 @@ __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int
             }
         }
     }
-#pragma unroll
-    for (int c = 0; c < NR; ++c) {
-        if (lane < nc) A.xp[c * A.ld_xp + c0 + lane] = y[c];
-        else if (lane < f) A.uvec[c * A.ld_uvec + rp + lane - nc] = y[c];
-    }
+    if (lane < nc) stv<NR>(A.xp, c0 + lane, y);
+    else if (lane < f) stv<NR>(A.uvec, rp + lane - nc, y);
 }
 
 template <int NR>
@@ -125,10 +150,11 @@ __device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int
         const double di = (lane < nc) ? A.Dinv[c0 + lane] : 0.0;
         const int ri = (lane >= nc && lane < f) ? T.rows[rp + lane - nc] : 0;
 #pragma unroll
-        for (int c = 0; c < NR; ++c) {
-            y[c] = 0.0;
-            if (lane < nc) y[c] = A.xp[c * A.ld_xp + c0 + lane] * di;
-            else if (lane < f) y[c] = A.xp[c * A.ld_xp + ri];
+        for (int c = 0; c < NR; ++c) y[c] = 0.0;
+        if (lane < f) ldv<NR>(A.xp, lane < nc ? c0 + lane : ri, y);
+        if (lane < nc) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) y[c] *= di;
         }
     }
     // x_j = y_j - sum_{r > j} L(r,j) x_r, j = nc-1 .. 0: column loads (coalesced over lanes) issued eight
@@ -154,11 +180,9 @@ __device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int
     }
     if (lane < nc) {
         const int pi = T.perm[c0 + lane];
+        stv<NR>(A.xp, c0 + lane, y);
 #pragma unroll
-        for (int c = 0; c < NR; ++c) {
-            A.xp[c * A.ld_xp + c0 + lane] = y[c];
-            A.out[c * A.ld_out + pi] = y[c];
-        }
+        for (int c = 0; c < NR; ++c) A.out[c * A.ld_out + pi] = y[c];
     }
 }
 
@@ -195,9 +219,14 @@ __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                double t[NR];
 #pragma unroll
-                for (int c = 0; c < NR; ++c) u[c][q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
+                for (int c = 0; c < NR; ++c) t[c] = 0.0;
+                if (src[q] >= 0) ldv<NR>(A.uvec, src[q], t);
+#pragma unroll
+                for (int c = 0; c < NR; ++c) u[c][q] = t[c];
+            }
 #pragma unroll
             for (int c = 0; c < NR; ++c)
 #pragma unroll
@@ -216,11 +245,8 @@ __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int
         }
     }
     if (live) {
-#pragma unroll
-        for (int c = 0; c < NR; ++c) {
-            if (sub < nc) A.xp[c * A.ld_xp + c0 + sub] = y[c];
-            else if (sub < f) A.uvec[c * A.ld_uvec + rp + sub - nc] = y[c];
-        }
+        if (sub < nc) stv<NR>(A.xp, c0 + sub, y);
+        else if (sub < f) stv<NR>(A.uvec, rp + sub - nc, y);
     }
 }
 template <int NR>
@@ -240,10 +266,11 @@ __device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int
         const double di = (sub < nc) ? A.Dinv[c0 + sub] : 0.0;
         const int ri = (sub >= nc && sub < f) ? T.rows[rp + sub - nc] : 0;
 #pragma unroll
-        for (int c = 0; c < NR; ++c) {
-            y[c] = 0.0;
-            if (sub < nc) y[c] = A.xp[c * A.ld_xp + c0 + sub] * di;
-            else if (sub < f) y[c] = A.xp[c * A.ld_xp + ri];
+        for (int c = 0; c < NR; ++c) y[c] = 0.0;
+        if (sub < f) ldv<NR>(A.xp, sub < nc ? c0 + sub : ri, y);
+        if (sub < nc) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) y[c] *= di;
         }
     }
     double lv[kTinyFront];
@@ -262,11 +289,9 @@ __device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int
     }
     if (live && sub < nc) {
         const int pi = T.perm[c0 + sub];
+        stv<NR>(A.xp, c0 + sub, y);
 #pragma unroll
-        for (int c = 0; c < NR; ++c) {
-            A.xp[c * A.ld_xp + c0 + sub] = y[c];
-            A.out[c * A.ld_out + pi] = y[c];
-        }
+        for (int c = 0; c < NR; ++c) A.out[c * A.ld_out + pi] = y[c];
     }
 }
 // A level's one-wave and tiny fronts are independent of each other: one launch for both (the first nwb workgroups
@@ -333,14 +358,20 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
             int src[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+            double u[NR][8];
 #pragma unroll
-            for (int c = 0; c < NR; ++c) {
-                double u[8];
+            for (int q = 0; q < 8; ++q) {
+                double t[NR];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) u[q] = src[q] >= 0 ? A.uvec[c * A.ld_uvec + src[q]] : 0.0;
+                for (int c = 0; c < NR; ++c) t[c] = 0.0;
+                if (src[q] >= 0) ldv<NR>(A.uvec, src[q], t);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) if (src[q] >= 0) v[c] += u[q];
+                for (int c = 0; c < NR; ++c) u[c][q] = t[c];
             }
+#pragma unroll
+            for (int c = 0; c < NR; ++c)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (src[q] >= 0) v[c] += u[c][q];
         }
 #pragma unroll
         for (int c = 0; c < NR; ++c) y[c * cst + i] = v[c];
@@ -377,13 +408,15 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
     }
     __syncthreads();
     for (int i = tid; i < f; i += BS) {
+        double w[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
             double v = 0.0;
             for (int ks = 0; ks < nks; ++ks) v += part[c * cst + ks * fpad + i];
-            if (i < nc) A.xp[c * A.ld_xp + c0 + i] = v;
-            else A.uvec[c * A.ld_uvec + rp + i - nc] = y[c * cst + i] - v;
+            w[c] = (i < nc) ? v : y[c * cst + i] - v;
         }
+        if (i < nc) stv<NR>(A.xp, c0 + i, w);
+        else stv<NR>(A.uvec, rp + i - nc, w);
     }
 }
 
@@ -453,22 +486,25 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
     for (int i = tid; i < f; i += BS) {
         const double di = (i < nc) ? A.Dinv[c0 + i] : 0.0;
         const int ri = (i < nc) ? 0 : T.rows[rp + i - nc];
+        double w[NR];
+        ldv<NR>(A.xp, i < nc ? c0 + i : ri, w);
 #pragma unroll
-        for (int c = 0; c < NR; ++c)
-            z[c * cst + i] = (i < nc) ? A.xp[c * A.ld_xp + c0 + i] * di : -A.xp[c * A.ld_xp + ri];
+        for (int c = 0; c < NR; ++c) z[c * cst + i] = (i < nc) ? w[c] * di : -w[c];
     }
     __syncthreads();
     bwd_items<NR>(Wt, nc, f, z, part, ncpad, cst, wv, NW, lane);
     __syncthreads();
     for (int j = tid; j < nc; j += BS) {
         const int pi = T.perm[c0 + j];
+        double w[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
             double v = 0.0;
             for (int rs = 0; rs < nrs; ++rs) v += part[c * cst + rs * ncpad + j];
-            A.xp[c * A.ld_xp + c0 + j] = v;
+            w[c] = v;
             A.out[c * A.ld_out + pi] = v;
         }
+        stv<NR>(A.xp, c0 + j, w);
     }
 }
 template <int BS, int NR>
@@ -650,7 +686,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
 #pragma unroll
             for (int q = 0; q < GP; ++q)
 #pragma unroll
-                for (int c = 0; c < NR; ++c) u[c][q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + c * A.ld_uvec + gsrc[q]) : 0.0;
+                for (int c = 0; c < NR; ++c) u[c][q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + (int64_t)(gsrc[q]) * NR + c) : 0.0;
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
                 double v = bmine[c];
@@ -667,7 +703,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
 #pragma unroll
                 for (int q = 0; q < GP; ++q)
 #pragma unroll
-                    for (int c = 0; c < NR; ++c) u[c][q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + c * A.ld_uvec + gsrc[q]) : 0.0;
+                    for (int c = 0; c < NR; ++c) u[c][q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + (int64_t)(gsrc[q]) * NR + c) : 0.0;
 #pragma unroll
                 for (int c = 0; c < NR; ++c) {
                     double v = bmine[c];
@@ -684,7 +720,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
                 double v = (i < nc) ? A.b[c * A.ld_b + T.perm[c0 + i]] : 0.0;
-                for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + c * A.ld_uvec + T.gl_src[g]);
+                for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + (int64_t)(T.gl_src[g]) * NR + c);
                 y[c * cst + i] = v;
             }
         }
@@ -722,8 +758,8 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             for (int c = 0; c < NR; ++c) {
                 double v = 0.0;
                 for (int ks = 0; ks < nks; ++ks) v += part[c * cst + ks * fpad + i];
-                if (i < nc) ST_AGENT_F64(A.xp + c * A.ld_xp + c0 + i, v);
-                else ST_AGENT_F64(A.uvec + c * A.ld_uvec + rp + i - nc, y[c * cst + i] - v);
+                if (i < nc) ST_AGENT_F64(A.xp + (int64_t)(c0 + i) * NR + c, v);
+                else ST_AGENT_F64(A.uvec + (int64_t)(rp + i - nc) * NR + c, y[c * cst + i] - v);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
@@ -775,8 +811,8 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             double zv[NR];                 // every column's value in flight before the first use
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
-                const double* xc = A.xp + c * A.ld_xp;
-                zv[c] = (tid < nc) ? LD_AGENT_F64(xc + c0 + tid) : (tid < f ? LD_AGENT_F64(xc + ridx) : 0.0);
+                const double* xc = A.xp + c;          // (columns interleaved: entry i of column c at i * NR + c)
+                zv[c] = (tid < nc) ? LD_AGENT_F64(xc + (int64_t)(c0 + tid) * NR) : (tid < f ? LD_AGENT_F64(xc + (int64_t)ridx * NR) : 0.0);
             }
 #pragma unroll
             for (int c = 0; c < NR; ++c)
@@ -784,9 +820,10 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
-            const double* xc = A.xp + c * A.ld_xp;
+            const double* xc = A.xp + c;
             for (int i = tid + BS; i < f; i += BS)
-                z[c * cst + i] = (i < nc) ? LD_AGENT_F64(xc + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(xc + T.rows[rp + i - nc]);
+                z[c * cst + i] = (i < nc) ? LD_AGENT_F64(xc + (int64_t)(c0 + i) * NR) * A.Dinv[c0 + i]
+                                          : -LD_AGENT_F64(xc + (int64_t)T.rows[rp + i - nc] * NR);
         }
         __syncthreads();
 #pragma unroll
@@ -838,7 +875,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             for (int c = 0; c < NR; ++c) {
                 double v = 0.0;
                 for (int rs = 0; rs < nrs; ++rs) v += part[c * cst + rs * ncpad + j];
-                ST_AGENT_F64(A.xp + c * A.ld_xp + c0 + j, v);
+                ST_AGENT_F64(A.xp + (int64_t)(c0 + j) * NR + c, v);
                 A.out[c * A.ld_out + pi] = v;
             }
         }
