@@ -24,6 +24,10 @@ else
 fi
 echo "$ARGS" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1
+# Counter collection serialises the kernels, and the factorisation's overlap mode needs two streams running side by side
+# (it would time out once and fall back by itself): the counter passes run with it off.  Traffic differs from the default
+# mode only by the write-through flag of the top fronts' stores.
+export HIPKKT_FACTOR_OVERLAP=0
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS > $OUT/pmc_mfma.log 2>&1

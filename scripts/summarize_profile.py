@@ -92,7 +92,7 @@ summary = dict(tag=tag, command=command, steps_profiled=steps, csrc_sha16=bench[
                trisolve_hbm_MB_per_solve=tri, factor_hbm_MB_per_factorisation=fac,
                trisolve_hbm_MB_per_solve_uncorrected=tri_raw, factor_hbm_MB_per_factorisation_uncorrected=fac_raw,
                fetch_size_scale=fetch_scale, calibration=calib,
-               note="FETCH_SIZE/WRITE_SIZE from separate rocprofv3 --pmc passes (KB as reported).  On gfx950 FETCH_SIZE "
+               note="FETCH_SIZE/WRITE_SIZE from separate rocprofv3 --pmc passes (KB as reported; counter collection serialises the kernels, so these passes run with HIPKKT_FACTOR_OVERLAP=0 -- same kernels and bytes, the top levels' tiles behind their panels instead of beside them).  On gfx950 FETCH_SIZE "
                     "reports 1/2 of the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM section); the "
                     "calibration rows show the same factor for this code's 8-byte-per-lane streams, so reads are "
                     "doubled (an upper bound for the gather-type accesses).  WRITE_SIZE is exact.  Infinity-cache hits "
