@@ -299,6 +299,17 @@ class HipKKTSystem:
         ds, dz = self._dev(s), self._dev(z)
         return self.update_dev(ds.data_ptr(), dz.data_ptr())
 
+    def update_and_solve_affine_dev(self, d_lhs, d_rhs, rhs_tau, rhs_kappa, d_var, tau, kappa):
+        """The same on device pointers: d_lhs = (dx, ds, dz), d_rhs = (rhs.x, rhs.z), d_var = (x, s, z).
+        Returns (is_success, dtau, dkappa)."""
+        tk = np.zeros(2)
+        ok = check(_lib.lib().hipkkt_kkt_system_update_and_solve_affine(
+            self.ks._h, C.c_void_p(d_lhs[0]), C.c_void_p(d_lhs[1]), C.c_void_p(d_lhs[2]), ptr(tk),
+            C.c_void_p(d_rhs[0]), C.c_void_p(d_rhs[1]), float(rhs_tau), float(rhs_kappa),
+            C.c_void_p(d_var[0]), C.c_void_p(d_var[1]), C.c_void_p(d_var[2]), float(tau), float(kappa)),
+            "hipkkt_kkt_system_update_and_solve_affine")
+        return ok, float(tk[0]), float(tk[1])
+
     def update_and_solve_affine(self, rhs_x, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa):
         """kkt_update! + kkt_solve!(:affine) in one call: the constant and the affine right-hand side share one
         2-column solve (hipkkt_kkt_system_update_and_solve_affine).  Returns (is_success, step | None)."""

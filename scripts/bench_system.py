@@ -55,6 +55,15 @@ def main():
             assert ok
         return dtau
 
+    def iteration_c_batched():
+        # kkt_update! and the affine kkt_solve! as one call: the constant and the affine right-hand side share one
+        # 2-column solve (hipkkt_kkt_system_update_and_solve_affine); the combined step follows alone
+        ok, dtau, dkappa = system.update_and_solve_affine_dev(P(d_lhs), P([d_rhs[0], d_rhs[2]]), 0.3, -0.1, P(d_var), tau, kappa)
+        assert ok
+        ok, dtau, dkappa = system.solve_dev(P(d_lhs), P(d_rhs), 0.3, -0.1, P(d_var), tau, kappa, False)
+        assert ok
+        return dtau
+
     # level B with host vectors: the algebra of kkt_solve! in numpy (ipm.py's kkt_solve), solves through the C ABI
     Pt = sp.triu(sp.csc_matrix(pb.P), format="csc")
     Pfull = (Pt + sp.triu(Pt, 1).T).tocsr()
@@ -90,7 +99,8 @@ def main():
         return dtau
 
     out = {}
-    for name, fn in (("level_C_device_resident", iteration_c), ("level_B_host_vectors", iteration_b)):
+    for name, fn in (("level_C_device_resident", iteration_c), ("level_C_batched_affine", iteration_c_batched),
+                     ("level_B_host_vectors", iteration_b)):
         fn(); fn()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -99,6 +109,7 @@ def main():
         torch.cuda.synchronize(dev)
         out[name] = dict(ms_per_iteration=(time.perf_counter() - t0) / args.steps * 1e3, dtau=float(last))
     out["agreement_dtau"] = abs(out["level_C_device_resident"]["dtau"] - out["level_B_host_vectors"]["dtau"])
+    out["agreement_dtau_batched"] = abs(out["level_C_batched_affine"]["dtau"] - out["level_B_host_vectors"]["dtau"])
     print(json.dumps(dict(workload=f"cfg2 n={args.n}: kkt_update! + 2 x kkt_solve! (3 KKT solves with refinement)", **out)))
 
 
