@@ -47,12 +47,12 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 // wall clock; on expiry flags[2] is set, everyone leaves, and the host repeats the factorisation level by level.
 #define OV_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define OV_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-__device__ inline bool ov_wait_ge(const int* counter, int target, int* abort_word, long long t0)
+__device__ inline bool ov_wait_ge(const int* counter, int target, int* abort_word, long long t0, long long limit)
 {
     for (;;) {
         if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (wall_clock64() - t0 > 5000000) {          // 50 ms at 100 MHz: far beyond any real factorisation step
+        if (wall_clock64() - t0 > limit) {            // (50 ms at 100 MHz: far beyond any real factorisation step)
             __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
                 const int c = T.child_idx[e];
                 const int need = A.ov_ntiles[c];
-                if (need > 0) ok = ov_wait_ge(A.ov_done + c, need, A.flags + 2, tw) && ok;
+                if (need > 0) ok = ov_wait_ge(A.ov_done + c, need, A.flags + 2, tw, A.ov_limit) && ok;
             }
             if (!ok) sh_ov_ok = 0;
         }
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
         const int kw = min(KC, nc - k0);
         if (OV) {
             // the panel kernel of this front publishes its 16-column blocks as they are finished
-            if (tid == 0 && !ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw)) *sh_ok = 0;
+            if (tid == 0 && !ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw, A.ov_limit)) *sh_ok = 0;
             __syncthreads();
             if (!*sh_ok) return;
         }

@@ -249,6 +249,7 @@ private:
         a.xp = xp_m.p;
         a.uvec = uvec_m.p;
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
+        a.top_limit = 5000000;       // (the multi-column path has no persistent kernel)
         a.tk_pos = nullptr; a.tk_sl = nullptr; a.tbase = nullptr; a.xf = nullptr;
         for (const Launch& L : launches) launch_fwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
         for (size_t q = launches.size(); q-- > 0;) {
@@ -344,6 +345,8 @@ private:
         a.dyn_eps = dyn_eps;
         a.dyn_delta = dyn_delta;
         a.ov_prog = d_ov_prog.p; a.ov_done = d_ov_done.p; a.ov_ntiles = d_ov_ntiles.p; a.ov = 0;
+        static const long long ov_limit = std::getenv("HIPKKT_OV_TEST_LIMIT") ? std::atoll(std::getenv("HIPKKT_OV_TEST_LIMIT")) : 5000000;
+        a.ov_limit = ov_limit;
         a.stamps = nullptr;
         a.stamp_row = 0;
         if (want_stamps) {
@@ -491,6 +494,8 @@ private:
         a.out = d_x;
         a.xp = xp.p;
         a.uvec = uvec.p;
+        static const long long top_limit = std::getenv("HIPKKT_TOP_TEST_LIMIT") ? std::atoll(std::getenv("HIPKKT_TOP_TEST_LIMIT")) : 5000000;
+        a.top_limit = top_limit;
         a.ld_b = ldb; a.ld_out = ldx; a.ld_xp = S.N; a.ld_uvec = (int64_t)std::max<size_t>(S.rows.size(), 1);
         a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;

@@ -144,6 +144,8 @@ struct FactorArgs {
     int* ov_done;
     const int* ov_ntiles;
     int ov;                      // this launch runs in overlap mode
+    long long ov_limit;          // bound of every overlap-mode wait in 100 MHz ticks (50 ms; the tests set it to 0 to
+                                 // force the give-up-and-repeat path: HIPKKT_OV_TEST_LIMIT)
     double dyn_eps, dyn_delta;
     int nbk;                     // block-column width (<= 16), chosen so the LDS buffer fits
     long long* stamps;           // diagnostic only (HIPKKT_STAMPS=1): phase time stamps of block 0, else null
@@ -163,6 +165,8 @@ struct SolveArgs {
     double* uvec;                // sum nb
     // NR right-hand sides in one launch (the single-column kernels' NR template parameter): column c of b, out, xp,
     // uvec lives at these strides
+    long long top_limit;         // bound of every wait of the persistent kernels in 100 MHz ticks (50 ms; the tests set
+                                 // it to 0 to force the give-up-and-repeat path: HIPKKT_TOP_TEST_LIMIT)
     int64_t ld_b, ld_out, ld_xp, ld_uvec;   // (b, out: columns ld apart.  The sweeps' internal vectors xp and uvec keep their
                                             //  NR columns INTERLEAVED -- entry i of column c at i * NR + c -- so that a gather
                                             //  touches one cache line for all columns; ld_xp / ld_uvec are unused)

@@ -619,7 +619,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
     int* flag_b = flags + nflag;         // backward done (nflag >= ntop: the layout does not move with the set's size)
     int* abort_word = flags + 2 * nflag;
     const long long t0 = wall_clock64();
-    const long long limit = 5000000;     // 50 ms at 100 MHz: far beyond any real sweep
+    const long long limit = A.top_limit; // (50 ms at 100 MHz: far beyond any real sweep)
 
     // ================= forward =================
     int pos = me;
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
     int* flag_b = flags + nflag;
     int* abort_word = flags + 2 * nflag;
     const long long t0 = wall_clock64();
-    const long long limit = 5000000;
+    const long long limit = A.top_limit;
 
     // ================= forward =================
     int tk = task0 + me;

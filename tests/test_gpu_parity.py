@@ -650,6 +650,29 @@ def _schedule_line(stderr):
     return dict(zip(keys, map(int, m.groups())))
 
 
+@pytest.mark.parametrize("which,env,message", [
+    ("overlap", {"HIPKKT_OV_TEST_LIMIT": "0"}, "factorisation overlap gave up waiting"),
+    ("top", {"HIPKKT_TOP_TEST_LIMIT": "0"}, "persistent top-of-tree kernel gave up waiting"),
+])
+@pytest.mark.parametrize("maker", ["problems.config2(n=20000)", "problems.config5(n=300, npsd=6, psd_dim=6, nsoc=4, soc_dim=12)"])
+def test_bounded_waits_give_up_and_the_operation_is_repeated(which, env, message, maker):
+    """The two mechanisms that order kernels by flags in memory (the factorisation's overlap mode, the persistent
+    top-of-tree sweep kernel) bound every wait; a wait that expires must end in a correct result all the same: the
+    library switches the mechanism off for the handle and repeats the operation one level after the other.  With the
+    bound set to zero ticks every wait that is not satisfied at its first poll gives up, so the fallback really runs
+    (the message on stderr proves it), and the solutions must still match the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)],
+                       env=dict(os.environ, HIPKKT_VERBOSE="1", **env), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SMALL GRID OK" in r.stdout
+    assert message in r.stderr, r.stderr
+    assert r.stderr.count("gave up") == 1, r.stderr          # once per handle: the mechanism stays off afterwards
+
+
 @pytest.mark.parametrize("cap,mult", [(3, 1.0), (5, 64.0)])
 def test_persistent_top_with_fewer_workgroups_than_fronts(cap, mult):
     """The persistent kernel over the top of the tree walks several fronts per workgroup (k_top_solve: positions me,
