@@ -496,6 +496,11 @@ private:
         a.uvec = uvec.p;
         static const long long top_limit = std::getenv("HIPKKT_TOP_TEST_LIMIT") ? std::atoll(std::getenv("HIPKKT_TOP_TEST_LIMIT")) : 5000000;
         a.top_limit = top_limit;
+        // diagnostic (HIPKKT_TOP_STAMPS=n): the n-th single-column sweep over the full persistent set records eight time
+        // stamps per front and direction, printed per level afterwards (this call then synchronises)
+        static const int stamp_call = std::getenv("HIPKKT_TOP_STAMPS") ? std::atoi(std::getenv("HIPKKT_TOP_STAMPS")) : 0;
+        a.top_stamps = nullptr;
+        bool stamp_now = false;
         a.ld_b = ldb; a.ld_out = ldx; a.ld_xp = S.N; a.ld_uvec = (int64_t)std::max<size_t>(S.rows.size(), 1);
         a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
@@ -538,7 +543,46 @@ private:
                 launch_top_solve_sliced(a, Lfull.begin, pos0, h_tbase[(size_t)pos0], top_ntask, top_sgrid, top_slds, top_flags.p,
                                         top_nflag, ++top_epoch, st);
             } else {
+                if (stamp_call > 0 && nr == 1 && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
+                    top_stamps.alloc((size_t)2 * ncount * 8);
+                    top_stamps.zero(st);
+                    a.top_stamps = (long long*)top_stamps.p;
+                    stamp_now = true;
+                }
                 launch_top_solve(a, L0.begin, ncount, std::min(tgrid, ncount), top_lds, top_flags.p, top_count, ++top_epoch, st, top_tall, nr);
+                a.top_stamps = nullptr;
+            }
+        }
+        if (stamp_now) {
+            std::vector<long long> h((size_t)2 * ncount * 8);
+            HIP_CHECK(hipMemcpyAsync(h.data(), top_stamps.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            long long t0 = h[0];
+            for (int p = 0; p < ncount; ++p) t0 = std::min(t0, h[(size_t)p * 8]);
+            const int pbase = launches[nl - ntl].begin;
+            for (int dir = 0; dir < 2; ++dir) {
+                double prev_done = 0.0;
+                for (size_t qq = 0; qq < ntl; ++qq) {
+                    const size_t q = dir == 0 ? nl - ntl + qq : nl - 1 - qq;
+                    const Launch& L = launches[q];
+                    double d[5] = {0, 0, 0, 0, 0}, first_start = 1e30, last_seen = 0, last_done = 0, crit[5] = {0, 0, 0, 0, 0};
+                    for (int t = L.begin; t < L.begin + L.count; ++t) {
+                        const long long* e = &h[((size_t)dir * ncount + (size_t)(t - pbase)) * 8];
+                        for (int k = 0; k < 5; ++k) d[k] += (e[k + 1] - e[k]) * 0.01;
+                        first_start = std::min(first_start, (e[0] - t0) * 0.01);
+                        last_seen = std::max(last_seen, (e[2] - t0) * 0.01);
+                        if ((e[5] - t0) * 0.01 > last_done) {
+                            last_done = (e[5] - t0) * 0.01;
+                            for (int k = 0; k < 5; ++k) crit[k] = (e[k + 1] - e[k]) * 0.01;
+                        }
+                    }
+                    std::fprintf(stderr, "[top stamps] %s level %2d: %4d fronts, first starts %7.2f, last sees its flags %7.2f, last publishes %7.2f "
+                                 "(hop %5.2f) us | mean: preload %5.2f wait %6.2f gather %5.2f products %5.2f reduce+store %5.2f | "
+                                 "last front: %5.2f %6.2f %5.2f %5.2f %5.2f\n", dir == 0 ? "fwd" : "bwd", L.level, L.count, first_start, last_seen,
+                                 last_done, last_done - prev_done, d[0] / L.count, d[1] / L.count, d[2] / L.count, d[3] / L.count,
+                                 d[4] / L.count, crit[0], crit[1], crit[2], crit[3], crit[4]);
+                    prev_done = last_done;
+                }
             }
         }
         for (size_t q = nl - ntl; q-- > 0;) {
@@ -647,6 +691,8 @@ private:
     DBuf<int> d_iperm;
     size_t multi_cap = 0;
     DBuf<int64_t> d_tinv_off;
+    DBuf<double> top_stamps;
+    int n_stamp_sweeps = 0;
     int n_skipw_calls = 0;
     DBuf<int> d_tinv_list;
     std::vector<int> tinv_list;

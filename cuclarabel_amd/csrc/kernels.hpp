@@ -165,6 +165,8 @@ struct SolveArgs {
     double* uvec;                // sum nb
     // NR right-hand sides in one launch (the single-column kernels' NR template parameter): column c of b, out, xp,
     // uvec lives at these strides
+    long long* top_stamps;       // diagnostic only (HIPKKT_TOP_STAMPS=1): per front of the persistent set and direction eight
+                                 // wall-clock stamps of its hop (k_top_solve), else null
     long long top_limit;         // bound of every wait of the persistent kernels in 100 MHz ticks (50 ms; the tests set
                                  // it to 0 to force the give-up-and-repeat path: HIPKKT_TOP_TEST_LIMIT)
     int64_t ld_b, ld_out, ld_xp, ld_uvec;   // (b, out: columns ld apart.  The sweeps' internal vectors xp and uvec keep their

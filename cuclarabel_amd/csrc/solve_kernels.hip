@@ -621,9 +621,11 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
     const long long t0 = wall_clock64();
     const long long limit = A.top_limit; // (50 ms at 100 MHz: far beyond any real sweep)
 
+#define TOP_STAMP(dir, slot) do { if (A.top_stamps && tid == 0) A.top_stamps[((int64_t)(dir) * ntop + pos) * 8 + (slot)] = wall_clock64(); } while (0)
     // ================= forward =================
     int pos = me;
     for (; pos < ntop; pos += G) {
+        TOP_STAMP(0, 0);
         const FrontDesc fd = T.desc[begin + pos];
         const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
         const int64_t rp = fd.rp;
@@ -669,6 +671,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         if (tid == 0) sh_ok = 1;
         __syncthreads();
+        TOP_STAMP(0, 1);
         if (wv == 0) {
             // children inside the persistent set: poll their forward flags, lanes over children
             bool ok = true;
@@ -680,6 +683,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         __syncthreads();
         if (!sh_ok) return;
+        TOP_STAMP(0, 2);
         // ---- gather (only the handed-over values are loaded now)
         if (tid < f) {
             double u[NR][GP];              // every column's values in flight before the first sum
@@ -725,6 +729,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             }
         }
         __syncthreads();
+        TOP_STAMP(0, 3);
 #pragma unroll
         for (int p = 0; p < kTopPF; ++p) {
             const int it = wv + p * NW;
@@ -753,6 +758,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
                 }
         }
         __syncthreads();
+        TOP_STAMP(0, 4);
         for (int i = tid; i < f; i += BS) {
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
@@ -764,6 +770,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
         __syncthreads();
+        TOP_STAMP(0, 5);
         if (tid == 0) __hip_atomic_store(flag_f + pos, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
@@ -773,6 +780,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         const int s = fd.s, c0 = fd.c0, nc = fd.nc, nb = fd.nb;
         const int64_t rp = fd.rp;
         const int f = nc + nb;
+        TOP_STAMP(1, 0);
         const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;
         const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
         // ---- preload
@@ -796,6 +804,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         else if (tid < f) ridx = T.rows[rp + tid - nc];
         if (tid == 0) sh_ok = 1;
         __syncthreads();
+        TOP_STAMP(1, 1);
         if (wv == 0) {
             bool ok = true;
             const int par = T.sn_parent[s];
@@ -807,6 +816,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         __syncthreads();
         if (!sh_ok) return;
+        TOP_STAMP(1, 2);
         {
             double zv[NR];                 // every column's value in flight before the first use
 #pragma unroll
@@ -826,6 +836,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
                                           : -LD_AGENT_F64(xc + (int64_t)T.rows[rp + i - nc] * NR);
         }
         __syncthreads();
+        TOP_STAMP(1, 3);
 #pragma unroll
         for (int p = 0; p < kTopPB; ++p) {
             const int it = wv + p * NW;
@@ -869,6 +880,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             }
         }
         __syncthreads();
+        TOP_STAMP(1, 4);
         for (int j = tid; j < nc; j += BS) {
             const int pi = T.perm[c0 + j];
 #pragma unroll
@@ -881,9 +893,11 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        TOP_STAMP(1, 5);
         if (tid == 0) __hip_atomic_store(flag_b + pos, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+#undef TOP_STAMP
 
 // ------------------------------------------------------------------ persistent kernel, sliced fronts
 // The same hand-over scheme as k_top_solve, for sets with very TALL fronts (cfg5: 1531 x 96 panels, 1.2 MB of W per
