@@ -359,7 +359,10 @@ private:
         // EXPERIMENT (timing only, valid when K does not change between factorisations): skip W formation after n factorisations
         static const int skip_w_after = std::getenv("HIPKKT_EXPERIMENT_SKIP_WINV") ? std::atoi(std::getenv("HIPKKT_EXPERIMENT_SKIP_WINV")) : -1;
         const bool skip_w = skip_w_after >= 0 && n_skipw_calls++ >= skip_w_after;
-#define launch_tinv(...) do { if (!skip_w) launch_tinv(__VA_ARGS__); } while (0)
+        // (every W formation of this factorisation goes through form_w)
+        auto form_w = [&](const int* list, int count, int ncmax, hipStream_t on, int max_blocks) {
+            if (!skip_w) launch_tinv(a.T, fronts.p, tinv.p, list, count, ncmax, on, max_blocks);
+        };
         // eager mode: once the tree narrows to its top levels most CUs idle, so the solve matrices
         // W = [T; M] of everything below are formed on a side stream meanwhile (HIPKKT_NO_OVERLAP=1 disables)
         static const bool no_overlap = std::getenv("HIPKKT_NO_OVERLAP") != nullptr;
@@ -380,8 +383,7 @@ private:
                 HIP_CHECK(hipEventRecord(ev_fork, st));
                 HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
                 // a bounded grid: the top panels need whole CUs (their LDS), which a full-width launch would hold
-                launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + w_done, launches[q].tinv_begin - w_done, tinv_ncmax, cap_side,
-                            kSideWinvBlocks);
+                form_w(d_tinv_list.p + w_done, launches[q].tinv_begin - w_done, tinv_ncmax, cap_side, kSideWinvBlocks);
                 eager_fork = true;
                 w_done = launches[q].tinv_begin;
                 // the fronts below the narrow top are used by the next sweep's first launches: the factorisation ends
@@ -420,7 +422,7 @@ private:
                 if (L.tinv_count > 0 && side) {
                     HIP_CHECK(hipEventRecord(ev_fork, st));
                     HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
-                    launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, side);
+                    form_w(d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, side, 0);
                     forked = true;
                 }
                 launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, st);
@@ -437,14 +439,13 @@ private:
             HIP_CHECK(hipStreamWaitEvent(st, ev_side, 0));
             HIP_CHECK(hipEventRecord(ev_fork, st));
             HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
-            launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, cap_side);
+            form_w(d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, cap_side, 0);
             HIP_CHECK(hipEventRecord(ev_join, cap_side));
             w_pending = true;
         } else {
             // one launch over every supernode, after the tree (all of them independent)
-            launch_tinv(a.T, fronts.p, tinv.p, d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st);
+            form_w(d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st, 0);
         }
-#undef launch_tinv
         HIP_CHECK(hipGetLastError());
         if (want_stamps) {
             std::vector<long long> h(launches.size() * 16);
