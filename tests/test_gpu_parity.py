@@ -650,6 +650,58 @@ def _schedule_line(stderr):
     return dict(zip(keys, map(int, m.groups())))
 
 
+@pytest.mark.parametrize("env", [{"HIPKKT_WINV_BLOCKS": "2"}, {"HIPKKT_WINV_BLOCKS": "2", "HIPKKT_WINV_EARLY": "0", "HIPKKT_WINV_TAIL": "0"},
+                                 {"HIPKKT_WINV_BLOCKS": "3", "HIPKKT_FACTOR_OVERLAP": "0"}])
+@pytest.mark.parametrize("maker", ["problems.config2()", "problems.config3(nblocks=6, blk=200)"])
+def test_sweeps_wait_for_a_slow_side_stream(env, maker):
+    """The solve matrices W are formed on a side stream beside and behind the factorisation; the next sweep must wait for
+    them by an explicit dependency, not because the side stream happens to be fast.  With a side grid of two or three
+    workgroups the formation takes far longer than the rest of the factorisation: a sweep that started on time alone
+    would read W of the previous factorisation (zeros, the first time).  Solutions must match the oracle.  (Full-size cfg2:
+    only a tree with more block-class fronts than the narrow top holds has fronts whose W the sweep uses before it waits
+    for the top's -- with the join at the end of the factorisation removed this test fails there.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # The GPU solve follows the factorisation IMMEDIATELY (the oracle is built afterwards: its seconds of CPU work would
+    # give any side stream time to finish).  Iterative refinement would repair a sweep that read unfinished W -- at the
+    # price of extra rounds -- so the number of rounds must be the oracle's too.
+    script = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver
+from tests.oracle_bindings import make_oracle
+pb = {maker}
+ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+rng = np.random.default_rng(11)
+got = []
+for rep in range(3):
+    rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    x, z = np.zeros(pb.n), np.zeros(pb.m)
+    assert ks.kktsolver_update_from_sz(pb.s0 * (1.0 + 0.1 * rep), pb.z0)
+    ks.kktsolver_setrhs(rx, rz)
+    assert ks.kktsolver_solve(x, z)
+    got.append((rx, rz, x, z, ks.last_ir_iterations))
+o = make_oracle(pb, perm=ks.perm())
+for rep, (rx, rz, x, z, ir) in enumerate(got):
+    assert o.update_scaling(pb.s0 * (1.0 + 0.1 * rep), pb.z0) and o.kktsolver_update()
+    o.kktsolver_setrhs(rx, rz)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok
+    err = max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max())
+    assert ir == o.last_ir_iters, (rep, ir, o.last_ir_iters)
+    assert err < 1e-9, (rep, err)
+print("SIDE STREAM OK")
+"""
+    r = subprocess.run([sys.executable, "-c", script.format(root=root, maker=maker)],
+                       env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SIDE STREAM OK" in r.stdout
+
+
 @pytest.mark.parametrize("which,env,message", [
     ("overlap", {"HIPKKT_OV_TEST_LIMIT": "0"}, "factorisation overlap gave up waiting"),
     ("top", {"HIPKKT_TOP_TEST_LIMIT": "0"}, "persistent top-of-tree kernel gave up waiting"),
