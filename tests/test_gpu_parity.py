@@ -633,6 +633,9 @@ for _ in range(4):
     assert ks.kktsolver_solve(x, z)
     ok, xo, zo = o.kktsolver_solve()
     assert ok
+    # (iterative refinement repairs a sweep or a factor that went slightly wrong, at the price of extra rounds: the
+    #  number of rounds must be the oracle's as well)
+    assert ks.last_ir_iterations == o.last_ir_iters, (ks.last_ir_iterations, o.last_ir_iters)
     worst = max(worst, max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()))
 print("levels", ks.info["nlevels"], "worst", worst)
 assert worst < 1e-9
