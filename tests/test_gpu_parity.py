@@ -115,7 +115,8 @@ def test_update_from_sz_and_solve_match_oracle(name, maker):
         b = np.concatenate([rx, rz, np.zeros(ks.p)])
         Kf = o.K_full()
         # extension variables are internal; recover them through the oracle's residual on x,z only
-        assert ks.last_ir_iterations <= 10
+        # refinement would hide a slightly wrong factor or sweep at the price of extra rounds: same count as the oracle
+        assert ks.last_ir_iterations == o.last_ir_iters, (ks.last_ir_iterations, o.last_ir_iters)
 
 
 @pytest.mark.parametrize("psds", [(), (2, 3, 5)])
