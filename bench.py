@@ -328,6 +328,13 @@ def main():
         barrier()
         return reduce_max(time.perf_counter() - t0, device=dev)      # MAX over ranks (RCCL, 8 bytes)
 
+    # Host memory that is unmapped while the GPU works can stall its queues for tens of ms (observed on this stack with
+    # scripts that free large host arrays between solves): nothing large is allocated or freed inside the timed regions,
+    # and the collector does not run there either.
+    import gc
+    gc.collect()
+    gc.disable()
+
     def make_solver(pb):
         from cuclarabel_amd.kktsolver import HipKKTSolver
         st = _lib.default_settings(device=local_rank, ordering=_lib.ORDER_ND if args.ordering == "nd" else _lib.ORDER_AMD)

@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nrhs", default="1,8,64,512")
     ap.add_argument("--n", type=int, default=100_000)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=9)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -75,15 +75,19 @@ def main():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        t0 = time.perf_counter()
+        # per-call times, MEDIAN reported: on this stack a call now and then takes 20-80 ms longer when the script has
+        # just freed large host arrays (the per-k right-hand sides); the library's own loop shows no such calls
         irs = 0
+        per_call = []
         for _ in range(args.reps):
+            t0 = time.perf_counter()
             irs += run()
             gather()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
+            per_call.append(time.perf_counter() - t0)
         if world > 1:
             dist.barrier()
-        dt = (time.perf_counter() - t0) / args.reps
+        dt = float(np.median(per_call))
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
