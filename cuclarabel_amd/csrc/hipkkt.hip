@@ -544,7 +544,8 @@ private:
                 launch_top_solve_sliced(a, Lfull.begin, pos0, h_tbase[(size_t)pos0], top_ntask, top_sgrid, top_slds, top_flags.p,
                                         top_nflag, ++top_epoch, st);
             } else {
-                if (stamp_call > 0 && nr == 1 && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
+                static const int stamp_nr = std::getenv("HIPKKT_TOP_STAMPS_NR") ? std::atoi(std::getenv("HIPKKT_TOP_STAMPS_NR")) : 1;
+                if (stamp_call > 0 && nr == stamp_nr && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
                     top_stamps.alloc((size_t)2 * ncount * 8);
                     top_stamps.zero(st);
                     a.top_stamps = (long long*)top_stamps.p;

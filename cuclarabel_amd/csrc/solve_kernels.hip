@@ -325,6 +325,28 @@ __global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int n
 // LDS (doubles): forward NR * (1 + nks) * fpad  (y, then the partial sums per column slice),
 //                backward NR * (fpad + nrs * ncpad); column c's share sits behind column c - 1's.
 constexpr int kItemsInFlight = 2;     // matrix items (8 loads per lane each) a wave of the block solve kernels fetches at a time
+// Sum of the n partials p[0], p[stride], p[2 stride], ... in index order (the order fixes the rounding), their LDS loads
+// issued eight at a time: a plain loop compiles to read - wait - add per term, ~70 cycles each, which was a quarter
+// of a hop of the persistent kernel (27 terms per entry in the backward sweep).
+__device__ inline double lds_sum_strided(const double* p, int n, int stride)
+{
+    double v = 0.0;
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = p[(k + q) * stride];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += t[q];
+    }
+    double t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = (k + q < n) ? p[(k + q) * stride] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (k + q < n) v += t[q];
+    return v;
+}
+
 template <int BS, int NR>
 __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, int bx)
 {
@@ -411,8 +433,7 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
         double w[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
-            double v = 0.0;
-            for (int ks = 0; ks < nks; ++ks) v += part[c * cst + ks * fpad + i];
+            const double v = lds_sum_strided(part + c * cst + i, nks, fpad);
             w[c] = (i < nc) ? v : y[c * cst + i] - v;
         }
         if (i < nc) stv<NR>(A.xp, c0 + i, w);
@@ -499,8 +520,7 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
         double w[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
-            double v = 0.0;
-            for (int rs = 0; rs < nrs; ++rs) v += part[c * cst + rs * ncpad + j];
+            const double v = lds_sum_strided(part + c * cst + j, nrs, ncpad);
             w[c] = v;
             A.out[c * A.ld_out + pi] = v;
         }
@@ -762,8 +782,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         for (int i = tid; i < f; i += BS) {
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
-                double v = 0.0;
-                for (int ks = 0; ks < nks; ++ks) v += part[c * cst + ks * fpad + i];
+                const double v = lds_sum_strided(part + c * cst + i, nks, fpad);
                 if (i < nc) ST_AGENT_F64(A.xp + (int64_t)(c0 + i) * NR + c, v);
                 else ST_AGENT_F64(A.uvec + (int64_t)(rp + i - nc) * NR + c, y[c * cst + i] - v);
             }
@@ -885,8 +904,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
             const int pi = T.perm[c0 + j];
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
-                double v = 0.0;
-                for (int rs = 0; rs < nrs; ++rs) v += part[c * cst + rs * ncpad + j];
+                const double v = lds_sum_strided(part + c * cst + j, nrs, ncpad);
                 ST_AGENT_F64(A.xp + (int64_t)(c0 + j) * NR + c, v);
                 A.out[c * A.ld_out + pi] = v;
             }
@@ -1025,8 +1043,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             }
             __syncthreads();
             for (int i = tid; i < f; i += BS) {
-                double v = 0.0;
-                for (int ks = 0; ks < nks; ++ks) v += part[ks * fpad + i];
+                const double v = lds_sum_strided(part + i, nks, fpad);
                 if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
                 else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
             }
@@ -1180,8 +1197,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         }
         __syncthreads();
         for (int lr = tid; lr < nloc; lr += BS) {
-            double v = 0.0;
-            for (int ks = 0; ks < nks; ++ks) v += part[ks * nlocp + lr];
+            const double v = lds_sum_strided(part + lr, nks, nlocp);
             const int row = R0 + lr;
             if (row < nc) { ST_AGENT_F64(A.xp + c0 + row, v); ST_AGENT_F64(A.xf + c0 + row, v); }
             else ST_AGENT_F64(A.uvec + rp + row - nc, yloc[lr] - v);
@@ -1279,8 +1295,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             }
             __syncthreads();
             for (int j = tid; j < nc; j += BS) {
-                double v = 0.0;
-                for (int rs = 0; rs < nrs; ++rs) v += part[rs * ncpad + j];
+                const double v = lds_sum_strided(part + j, nrs, ncpad);
                 ST_AGENT_F64(A.xp + c0 + j, v);
                 A.out[T.perm[c0 + j]] = v;
             }
