@@ -385,7 +385,6 @@ __device__ __forceinline__ double bcast16(double v, const int k)
 template <int BS, bool SLICED, bool OV>
 __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 {
-    static_assert(!(SLICED && OV), "overlap mode takes whole panels only");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -690,12 +689,20 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
                 WAVE_FENCE();
                 for (int idx = widx * 64 + lane; idx < w * f; idx += NWK * 64) {
                     const int jj = idx / f, r = idx - jj * f, j = kb + jj;
-                    if (r >= j) OV_ST(F + r + (int64_t)j * ff, P[r + pcol(j, f)]);
+                    if (!SLICED) {
+                        if (r >= j) OV_ST(F + r + (int64_t)j * ff, P[r + pcol(j, f)]);
+                    } else if (r >= nc) {                   // (a slice: its own rows below the top block ...
+                        OV_ST(F + (r_lo + r - nc) + (int64_t)j * ff, P[r + pcol(j, f)]);
+                    } else if (first && r >= j) {           //  ... and the top block from the first slice)
+                        OV_ST(F + r + (int64_t)j * ff, P[r + pcol(j, f)]);
+                    }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) {
                     const int arrived = __hip_atomic_fetch_add(lds_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
-                    if (arrived == NWK * epoch) __hip_atomic_store(A.ov_prog + s, kb + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (arrived == NWK * epoch)
+                        __hip_atomic_store(SLICED ? A.ov_sprog + begin + blockIdx.x : A.ov_prog + s, kb + w, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (Tc > 0) {
@@ -841,7 +848,24 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
         const int kw = min(KC, nc - k0);
         if (OV) {
             // the panel kernel of this front publishes its 16-column blocks as they are finished
-            if (tid == 0 && !ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw, A.ov_limit)) *sh_ok = 0;
+            if (tid == 0) {
+                bool ok = true;
+                const int sb = A.ov_sbase[s];
+                if (sb < 0) {
+                    ok = ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw, A.ov_limit);
+                } else {
+                    // a front factorised in row slices: the slices that hold this tile's two strips, and the first one
+                    // (it publishes the top block, whose diagonal the product scales with)
+                    const FrontDesc sd = T.sdesc[sb];
+                    const int nsl = sd.pad & 0xffff, rsmax = (nb + nsl - 1) / nsl;
+                    ok = ov_wait_ge(A.ov_sprog + sb, k0 + kw, A.flags + 2, tw, A.ov_limit);
+                    for (int q = r0 / rsmax; ok && q <= (r0 + nr - 1) / rsmax; ++q)
+                        ok = ov_wait_ge(A.ov_sprog + sb + q, k0 + kw, A.flags + 2, tw, A.ov_limit);
+                    for (int q = q0 / rsmax; ok && q <= (q0 + nq - 1) / rsmax; ++q)
+                        ok = ov_wait_ge(A.ov_sprog + sb + q, k0 + kw, A.flags + 2, tw, A.ov_limit);
+                }
+                if (!ok) *sh_ok = 0;
+            }
             __syncthreads();
             if (!*sh_ok) return;
         }
@@ -931,6 +955,7 @@ static void init_factor_lds()
         set(k_panel<512, false, true>);
         set(k_panel<1024, false, true>);
         set(k_panel<1024, true, false>);
+        set(k_panel<1024, true, true>);
         set(k_front_wave);
         return e;
     });
@@ -966,7 +991,8 @@ void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, 
 {
     if (count <= 0) return;
     init_factor_lds();
-    hipLaunchKernelGGL((k_panel<1024, true, false>), dim3(count), dim3(1024), lds, st, a, begin);
+    if (a.ov) hipLaunchKernelGGL((k_panel<1024, true, true>), dim3(count), dim3(1024), lds, st, a, begin);
+    else hipLaunchKernelGGL((k_panel<1024, true, false>), dim3(count), dim3(1024), lds, st, a, begin);
 }
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st)
 {

@@ -119,13 +119,15 @@ public:
         build_schedule();
         upload(dsigns);
         if (std::getenv("HIPKKT_VERBOSE")) {
-            int nblock = 0, nsl_fronts = 0;
+            int nblock = 0, nsl_fronts = 0, ov_slices = 0;
             for (const Launch& L : launches) if (!L.small) { nblock += L.count; nsl_fronts += L.nsliced; }
+            if (overlap_wanted()) for (size_t q = ov_first; q < launches.size(); ++q) ov_slices += launches[q].slice_count;
             std::fprintf(stderr, "[hipkkt] N %d, %d supernodes in %zu levels (%zu launches), %d block-class fronts, %d of them in "
                          "%zu row slices; persistent solve set: last %zu launches, %d fronts on %d workgroups, %d (front, slice) tasks; "
-                         "factorisation overlap: last %zu launches\n",
+                         "factorisation overlap: last %zu launches (%d row slices in them)\n",
                          S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
-                         top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, overlap_wanted() ? launches.size() - ov_first : (size_t)0);
+                         top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, overlap_wanted() ? launches.size() - ov_first : (size_t)0,
+                         ov_slices);
         }
     }
 
@@ -333,6 +335,7 @@ private:
         if (ov_on) {
             launch_zero_ints(d_ov_prog.p, S.nsuper, st);
             launch_zero_ints(d_ov_done.p, S.nsuper, st);
+            if (!slice_list.empty()) launch_zero_ints(d_ov_sprog.p, (int)slice_list.size(), st);
         }
         FactorArgs a;
         a.T = tree();
@@ -345,6 +348,7 @@ private:
         a.dyn_eps = dyn_eps;
         a.dyn_delta = dyn_delta;
         a.ov_prog = d_ov_prog.p; a.ov_done = d_ov_done.p; a.ov_ntiles = d_ov_ntiles.p; a.ov = 0;
+        a.ov_sprog = d_ov_sprog.p; a.ov_sbase = d_ov_sbase.p;
         static const long long ov_limit = std::getenv("HIPKKT_OV_TEST_LIMIT") ? std::atoll(std::getenv("HIPKKT_OV_TEST_LIMIT")) : 5000000;
         a.ov_limit = ov_limit;
         a.stamps = nullptr;
@@ -399,7 +403,8 @@ private:
                 // starts its tiles only after its panels have finished.)
                 a.ov = 1;
                 a.nbk = L.nbk;
-                launch_panel(a, L.begin, L.count, L.bs_panel, L.lds_panel, st);
+                launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
+                launch_panel_sliced(a, L.slice_begin, L.slice_count, L.lds_sliced, st);
                 if (q == ov_first) {
                     HIP_CHECK(hipEventRecord(ev_ov_fork, st));
                     HIP_CHECK(hipStreamWaitEvent(ov_stream, ev_ov_fork, 0));
@@ -724,7 +729,7 @@ private:
     // overlap mode of the factorisation (factor_kernels.hip): the launches from ov_first on (the narrow top of the tree)
     size_t ov_first = 0;         // == launches.size(): none
     bool ov_disabled = false;
-    DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles;
+    DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase;
     hipStream_t ov_stream = nullptr;
     hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
     size_t nr_cap = 1;           // right-hand sides xp / uvec are sized for
@@ -925,7 +930,8 @@ private:
             size_t first = launches.size();
             while (first > 0) {
                 const Launch& L = launches[first - 1];
-                if (L.small || L.nsliced > 0 || L.count > ov_max) break;
+                // (workgroups of the launch: whole panels plus row slices)
+                if (L.small || L.count - L.nsliced + L.slice_count > ov_max) break;
                 --first;
             }
             ov_first = (launches.size() - first >= 3) ? first : launches.size();
@@ -940,6 +946,12 @@ private:
                 }
             }
             d_ov_ntiles.upload(nt);
+            // fronts factorised in row slices publish their progress per slice
+            std::vector<int> sbase((size_t)std::max(S.nsuper, 1), -1);
+            for (size_t q = slice_list.size(); q-- > 0;) sbase[(size_t)slice_list[q][0]] = (int)q;      // (slices of a front are consecutive)
+            d_ov_sbase.upload(sbase);
+            d_ov_sprog.alloc(std::max<size_t>(slice_list.size(), 1));
+            HIP_CHECK(hipMemset(d_ov_sprog.p, 0, std::max<size_t>(slice_list.size(), 1) * sizeof(int)));
             d_ov_prog.alloc((size_t)S.nsuper);
             d_ov_done.alloc((size_t)S.nsuper);
             HIP_CHECK(hipMemset(d_ov_prog.p, 0, (size_t)std::max(S.nsuper, 1) * sizeof(int)));

@@ -143,6 +143,10 @@ struct FactorArgs {
     int* ov_prog;
     int* ov_done;
     const int* ov_ntiles;
+    //   ov_sprog[q]   the same progress per ROW SLICE q (position in TreeDev::sdesc) of a front factorised in slices
+    //   ov_sbase[s]   first slice of supernode s in sdesc (-1: s is factorised whole)
+    int* ov_sprog;
+    const int* ov_sbase;
     int ov;                      // this launch runs in overlap mode
     long long ov_limit;          // bound of every overlap-mode wait in 100 MHz ticks (50 ms; the tests set it to 0 to
                                  // force the give-up-and-repeat path: HIPKKT_OV_TEST_LIMIT)

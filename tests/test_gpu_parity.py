@@ -750,15 +750,17 @@ def test_persistent_top_with_fewer_workgroups_than_fronts(cap, mult):
 
 @pytest.mark.parametrize("maker,cap", [("problems.config2(n=6000)", 2500), ("problems.config3(nblocks=4, blk=150)", 1500),
                                        ("problems.config5(n=120, npsd=6, psd_dim=8, nsoc=4, soc_dim=12)", 1200)])
-def test_row_sliced_panels(maker, cap):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_row_sliced_panels(maker, cap, overlap):
     """Panels too tall for one CU's LDS are factorised in row slices, one workgroup each, every slice redoing the
     top block (k_panel SLICED).  A small HIPKKT_PANEL_CAP (read at handle creation) forces slices on small problems;
-    the solutions must still match the oracle."""
+    the solutions must still match the oracle -- with the overlap mode on (the slices publish their rows block by
+    block, the front's tiles wait for the slices that hold their strips) and off."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_PANEL_CAP=str(cap), HIPKKT_VERBOSE="1")
+    env = dict(os.environ, HIPKKT_PANEL_CAP=str(cap), HIPKKT_VERBOSE="1", HIPKKT_FACTOR_OVERLAP=overlap)
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -766,6 +768,34 @@ def test_row_sliced_panels(maker, cap):
     assert "gave up" not in r.stderr, r.stderr
     sched = _schedule_line(r.stderr)
     assert sched["sliced_fronts"] > 0 and sched["row_slices"] > sched["sliced_fronts"], sched    # the sliced path ran
+    import re
+    m = re.search(r"factorisation overlap: last (\d+) launches", r.stderr)
+    assert m and (overlap == "1" or int(m.group(1)) == 0), r.stderr
+
+
+@pytest.mark.parametrize("maker", ["problems.config3(nblocks=4, blk=400)",
+                                   "problems.config5(n=400, npsd=10, psd_dim=16, nsoc=4, soc_dim=20)"])
+@pytest.mark.parametrize("limit", [None, "0"])
+def test_sliced_panels_in_overlap_mode(maker, limit):
+    """Fronts factorised in row slices inside the overlap mode's launches: every slice publishes its rows of a 16-column
+    block (the first slice the top block as well) and advances its own progress word; the front's Schur tiles wait for
+    the slices that hold their two strips and for the first one.  Solutions and refinement-round counts must match the
+    oracle; with the wait bound forced to zero the mode must give up once and the repeated factorisation be right."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPKKT_VERBOSE="1")
+    if limit is not None:
+        env["HIPKKT_OV_TEST_LIMIT"] = limit
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SMALL GRID OK" in r.stdout
+    m = re.search(r"factorisation overlap: last (\d+) launches \((\d+) row slices in them\)", r.stderr)
+    assert m and int(m.group(1)) >= 3 and int(m.group(2)) > 0, r.stderr
+    assert ("gave up" in r.stderr) == (limit is not None), r.stderr
 
 
 @pytest.mark.parametrize("maker,kb", [("problems.config2(n=6000)", 8), ("problems.config3(nblocks=4, blk=150)", 16),
