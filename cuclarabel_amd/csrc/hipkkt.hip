@@ -792,8 +792,13 @@ private:
             auto slices_of = [&](int s) {        // row slices the panel kernel needs for this front (1: fits one CU)
                 if (panel_cap <= 0) return 1;
                 const int nc = ncols(s), nb = front_size(s) - nc;
-                const int r = panel_slices_needed(nc, nb, panel_cap, std::min(panel_max_slices, std::max(1, nb)));
+                int r = panel_slices_needed(nc, nb, panel_cap, std::min(panel_max_slices, std::max(1, nb)));
                 if (r == 0) throw std::runtime_error("panel does not fit LDS even in row slices (panel_cap too large?)");
+                // A sliced front's assembly and trailing work are bound by what ONE CU can load (a 16-piece round of the
+                // extend-add is 6-7 us however tall the slice): more, shorter slices than LDS needs spread them over
+                // more CUs; the price is one more redundant copy of the diagonal block's factorisation per slice.
+                static const int slice_rows = std::getenv("HIPKKT_SLICE_ROWS") ? std::atoi(std::getenv("HIPKKT_SLICE_ROWS")) : 0;
+                if (r > 1 && slice_rows > 0) r = std::max(r, std::min(panel_max_slices, (nb + slice_rows - 1) / slice_rows));
                 return r;
             };
             auto work = [&](int s) { return (double)front_size(s) * front_size(s) * ncols(s); };
