@@ -546,8 +546,41 @@ private:
                 // the set holds very tall fronts: the (front, slice) kernel; positions count from the full set's first front
                 const Launch& Lfull = launches[nl - top_launches];
                 const int pos0 = top_count - ncount;
-                launch_top_solve_sliced(a, Lfull.begin, pos0, h_tbase[(size_t)pos0], top_ntask, top_sgrid, top_slds, top_flags.p,
+                const int task0 = h_tbase[(size_t)pos0];
+                bool sl_stamp = false;
+                if (stamp_call > 0 && nr == 1 && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
+                    top_stamps.alloc((size_t)2 * (top_ntask - task0) * 8);
+                    top_stamps.zero(st);
+                    a.top_stamps = (long long*)top_stamps.p;
+                    sl_stamp = true;
+                }
+                launch_top_solve_sliced(a, Lfull.begin, pos0, task0, top_ntask, top_sgrid, top_slds, top_flags.p,
                                         top_nflag, ++top_epoch, st);
+                a.top_stamps = nullptr;
+                if (sl_stamp) {
+                    // (front, slice) tasks: per direction the mean time from a task's start to its flags seen, from there
+                    // to its publication, and the sweep's span
+                    const size_t nt = (size_t)(top_ntask - task0);
+                    std::vector<long long> h(2 * nt * 8);
+                    HIP_CHECK(hipMemcpyAsync(h.data(), top_stamps.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    for (int dir = 0; dir < 2; ++dir) {
+                        double wait = 0, work = 0;
+                        long long lo = h[(size_t)dir * nt * 8], hi = 0;
+                        std::vector<double> works;
+                        for (size_t t = 0; t < nt; ++t) {
+                            const long long* e = &h[((size_t)dir * nt + t) * 8];
+                            wait += (e[2] - e[0]) * 0.01;
+                            work += (e[5] - e[2]) * 0.01;
+                            works.push_back((e[5] - e[2]) * 0.01);
+                            lo = std::min(lo, e[0]); hi = std::max(hi, e[5]);
+                        }
+                        std::sort(works.begin(), works.end());
+                        std::fprintf(stderr, "[top stamps] sliced %s: %zu tasks, span %.1f us; per task: start->flags seen %.2f us (mean), flags seen->publish "
+                                     "%.2f us (mean), %.2f (median), %.2f (max)\n", dir == 0 ? "fwd" : "bwd", nt, (hi - lo) * 0.01, wait / nt, work / nt,
+                                     works[nt / 2], works.back());
+                    }
+                }
             } else {
                 static const int stamp_nr = std::getenv("HIPKKT_TOP_STAMPS_NR") ? std::atoi(std::getenv("HIPKKT_TOP_STAMPS_NR")) : 1;
                 if (stamp_call > 0 && nr == stamp_nr && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {

@@ -27,11 +27,25 @@ __device__ inline double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// Sum over the wave's 64 lanes, returned in every lane.  DPP row shifts inside the 16-lane rows, then the two row
+// broadcasts: 6 steps of two 32-bit DPP moves and one add, no LDS crossbar (the __shfl_xor butterfly costs two
+// ds_bpermute round trips per step: a 45-column slice of the backward sweep spent most of its time in them).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);           // (lanes without a source, or outside the row mask, add +0.0)
+}
 __device__ inline double wave_reduce_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add_step<0x111, 0xf>(v);               // row_shr:1
+    v = dpp_add_step<0x112, 0xf>(v);               // row_shr:2
+    v = dpp_add_step<0x114, 0xf>(v);               // row_shr:4
+    v = dpp_add_step<0x118, 0xf>(v);               // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add_step<0x142, 0xa>(v);               // row_bcast:15 into rows 1 and 3
+    v = dpp_add_step<0x143, 0xc>(v);               // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return readlane_f64(v, 63);
 }
 
 // Every kernel below takes NR right-hand sides at once (NR = 1, 2 or 4; column c of a vector v lives at
@@ -929,6 +943,44 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
 // k_top_solve everything static (matrix entries, gather indices, b, D^{-1}, row indices) is parked before the wait.
 constexpr int kSlPF = 2;         // forward items per wave parked (the kernel must fit 128 VGPRs)
 constexpr int kSlGP = 4;         // gather indices per row parked
+// (front, slice) tasks: wave 0 waits for every task of the children of s inside the set.  Lanes over children for each
+// child's FIRST task, then -- children cut into several tasks, one after the other -- lanes over the remaining tasks:
+// a chain's only child has up to a dozen tasks, and polling them one by one cost a dozen L2 round trips per hop.
+__device__ inline bool wait_children_tasks(const TreeDev& T, const int* __restrict__ tbase, int s, int begin, int pos0, int* flag,
+                                           int epoch, int* abort_word, long long t0, long long limit, int lane)
+{
+    bool ok = true;
+    const int ce1 = T.child_ptr[s + 1];
+    for (int e0 = T.child_ptr[s]; e0 < ce1; e0 += 64) {
+        int a = 0, b = 0;
+        if (e0 + lane < ce1) {
+            const int cp = T.spos[T.child_idx[e0 + lane]] - begin;
+            if (cp >= pos0) { a = tbase[cp]; b = tbase[cp + 1]; }
+        }
+        if (b > a) ok = wait_flag(flag + a, epoch, abort_word, t0, limit) && ok;
+        unsigned long long more = __ballot(b - a > 1);
+        while (more) {
+            const int c = __ffsll((long long)more) - 1;
+            more &= more - 1;
+            const int ca = __builtin_amdgcn_readlane(a, c), cb = __builtin_amdgcn_readlane(b, c);
+            for (int q = ca + 1 + lane; q < cb; q += 64) ok = wait_flag(flag + q, epoch, abort_word, t0, limit) && ok;
+        }
+    }
+    return ok;
+}
+// ... and for every task of the parent (backward), lanes over its tasks
+__device__ inline bool wait_parent_tasks(const TreeDev& T, const int* __restrict__ tbase, int s, int begin, int* flag, int epoch,
+                                         int* abort_word, long long t0, long long limit, int lane)
+{
+    bool ok = true;
+    const int par = T.sn_parent[s];
+    if (par >= 0) {
+        const int pp = T.spos[par] - begin;        // the parent of a front of the set is in the set
+        for (int q = tbase[pp] + lane; q < tbase[pp + 1]; q += 64) ok = wait_flag(flag + q, epoch, abort_word, t0, limit) && ok;
+    }
+    return ok;
+}
+
 template <int BS>
 __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int begin, int pos0, int task0, int task1, int* flags,
                                                              int epoch, int nflag)
@@ -946,9 +998,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
     const long long t0 = wall_clock64();
     const long long limit = A.top_limit;
 
+#define SL_STAMP(dir, slot) do { if (A.top_stamps && tid == 0) A.top_stamps[((int64_t)(dir) * (task1 - task0) + (tk - task0)) * 8 + (slot)] = wall_clock64(); } while (0)
     // ================= forward =================
     int tk = task0 + me;
     for (; tk < task1; tk += G) {
+        SL_STAMP(0, 0);
         const int pos = A.tk_pos[tk];
         const int slr = A.tk_sl[tk];
         const int sl = slr & 0xff, R = slr >> 8;
@@ -992,16 +1046,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             __syncthreads();
             if (wv == 0) {
                 // children inside the persistent set: poll their forward flags, lanes over children
-                bool ok = true;
-                for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
-                    const int cp = T.spos[T.child_idx[e]] - begin;
-                    if (cp >= pos0)
-                        for (int q = A.tbase[cp]; q < A.tbase[cp + 1]; ++q) ok = wait_flag(flag_f + q, epoch, abort_word, t0, limit) && ok;
-                }
-                if (!ok) sh_ok = 0;
+                if (!wait_children_tasks(T, A.tbase, s, begin, pos0, flag_f, epoch, abort_word, t0, limit, lane)) sh_ok = 0;
             }
             __syncthreads();
             if (!sh_ok) return;
+            SL_STAMP(0, 2);
             // ---- gather (only the handed-over values are loaded now)
             if (tid < f) {
                 double u[GP];
@@ -1049,6 +1098,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
             __syncthreads();
+            SL_STAMP(0, 5);
             if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     
             continue;
@@ -1114,16 +1164,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         if (tid == 0) sh_ok = 1;
         __syncthreads();
         if (wv == 0) {
-            bool ok = true;
-            for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
-                const int cp = T.spos[T.child_idx[e]] - begin;
-                if (cp >= pos0)
-                    for (int q = A.tbase[cp]; q < A.tbase[cp + 1]; ++q) ok = wait_flag(flag_f + q, epoch, abort_word, t0, limit) && ok;
-            }
-            if (!ok) sh_ok = 0;
+            if (!wait_children_tasks(T, A.tbase, s, begin, pos0, flag_f, epoch, abort_word, t0, limit, lane)) sh_ok = 0;
         }
         __syncthreads();
         if (!sh_ok) return;
+        SL_STAMP(0, 2);
         // ---- gather: only the handed-over values are loaded now
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
@@ -1204,11 +1249,13 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SL_STAMP(0, 5);
+            if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // ================= backward =================
     for (tk -= G; tk >= task0; tk -= G) {
+        SL_STAMP(1, 0);
         const int pos = A.tk_pos[tk];
         const int slr = A.tk_sl[tk];
         const int sl = slr & 0xff, R = slr >> 8;
@@ -1242,16 +1289,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             if (tid == 0) sh_ok = 1;
             __syncthreads();
             if (wv == 0) {
-                bool ok = true;
-                const int par = T.sn_parent[s];
-                if (lane == 0 && par >= 0) {
-                    const int pp = T.spos[par] - begin;        // the parent of a front of the set is in the set
-                    for (int q = A.tbase[pp]; q < A.tbase[pp + 1]; ++q) ok = wait_flag(flag_b + q, epoch, abort_word, t0, limit) && ok;
-                }
-                if (!ok) sh_ok = 0;
+                if (!wait_parent_tasks(T, A.tbase, s, begin, flag_b, epoch, abort_word, t0, limit, lane)) sh_ok = 0;
             }
             __syncthreads();
             if (!sh_ok) return;
+            SL_STAMP(1, 2);
             if (tid < nc) z[tid] = LD_AGENT_F64(A.xp + c0 + tid) * dinv;
             else if (tid < f) z[tid] = -LD_AGENT_F64(A.xp + ridx);
             for (int i = tid + BS; i < f; i += BS)
@@ -1301,6 +1343,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            SL_STAMP(1, 5);
             if (tid == 0) __hip_atomic_store(flag_b + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     
             continue;
@@ -1335,16 +1378,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         if (tid == 0) sh_ok = 1;
         __syncthreads();
         if (wv == 0) {
-            bool ok = true;
-            const int par = T.sn_parent[s];
-            if (lane == 0 && par >= 0) {
-                const int pp = T.spos[par] - begin;
-                for (int q = A.tbase[pp]; q < A.tbase[pp + 1]; ++q) ok = wait_flag(flag_b + q, epoch, abort_word, t0, limit) && ok;
-            }
-            if (!ok) sh_ok = 0;
+            if (!wait_parent_tasks(T, A.tbase, s, begin, flag_b, epoch, abort_word, t0, limit, lane)) sh_ok = 0;
         }
         __syncthreads();
         if (!sh_ok) return;
+        SL_STAMP(1, 2);
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int i = tid + x * BS;
@@ -1391,9 +1429,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(flag_b + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SL_STAMP(1, 5);
+            if (tid == 0) __hip_atomic_store(flag_b + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+#undef SL_STAMP
 
 // ------------------------------------------------------------------ W = [L11^{-1} ; L21 L11^{-1}]
 // Runs once after the factorisation, all supernodes in parallel (off the critical path of the tree).
