@@ -1080,7 +1080,7 @@ private:
             {
                 // Sets with very tall fronts (solve matrix > 3 x slice_kb: far more than a CU should stream per hop) run the
                 // (front, slice) kernel: such a front is cut into slices of ~slice_kb (at most 8), the others are one task
-                static const int slice_kb = std::getenv("HIPKKT_SOLVE_SLICE_KB") ? std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_KB")) : 200;
+                static const int slice_kb = std::getenv("HIPKKT_SOLVE_SLICE_KB") ? std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_KB")) : 120;
                 std::vector<int> tp, ts;
                 h_tbase.assign((size_t)top_count + 1, 0);
                 const int b0 = top_launches ? launches[launches.size() - top_launches].begin : 0;
