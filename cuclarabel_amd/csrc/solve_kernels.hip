@@ -37,6 +37,14 @@ __device__ __forceinline__ double dpp_add_step(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return v + __hiloint2double(hi, lo);           // (lanes without a source, or outside the row mask, add +0.0)
 }
+// ... and over aligned groups of eight lanes (the tiny fronts): neighbours, the quad's other pair, the other quad
+__device__ inline double group8_sum(double v)
+{
+    v = dpp_add_step<0xB1, 0xf>(v);                // quad_perm [1,0,3,2]
+    v = dpp_add_step<0x4E, 0xf>(v);                // quad_perm [2,3,0,1] -> every lane holds its quad's sum
+    v = dpp_add_step<0x141, 0xf>(v);               // row_half_mirror: the other quad's sum
+    return v;
+}
 __device__ inline double wave_reduce_sum(double v)
 {
     v = dpp_add_step<0x111, 0xf>(v);               // row_shr:1
@@ -294,10 +302,7 @@ __device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int
     for (int j = kTinyFront - 1; j >= 0; --j) {
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
-            double sum = lv[j] * y[c];
-            sum += __shfl_xor(sum, 4, 8);
-            sum += __shfl_xor(sum, 2, 8);
-            sum += __shfl_xor(sum, 1, 8);
+            const double sum = group8_sum(lv[j] * y[c]);
             if (j < nc && sub == j) y[c] -= sum;
         }
     }
