@@ -501,6 +501,10 @@ def main():
     ks = make_solver(pb)
     setup_s = time.perf_counter() - t0
     st = resident(pb, np.random.default_rng(0))
+    # (set-up has freed large host arrays; let the unmapping settle before any timed GPU work: see the note at gc.disable)
+    gc.collect()
+    torch.cuda.synchronize(dev)
+    time.sleep(0.5)
 
     for _ in range(args.warmup):
         unit(ks, st, may_repeat=True)
