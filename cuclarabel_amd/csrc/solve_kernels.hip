@@ -385,6 +385,22 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
     double* y = smem;                        // column c: y at c * cst, its partial sums behind it
     double* part = smem + fpad;
 
+    // The wave's FIRST batch of matrix items is fetched now: it depends on nothing but the descriptor, so its loads fly
+    // during the gather's chain of dependent loads (pointers -> indices -> values) instead of after it.
+    constexpr int U = kItemsInFlight;
+    double m[U][8];
+    auto load_items = [&](int it0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = it0 + u * NW;
+            const int ks = it / nrb, rb = it - ks * nrb;
+            const int r = rb * 64 + lane, k0 = 8 * ks;
+            const bool live = it < nrb * nks && !(rb * 64 + 63 < k0);      // (wholly above T's diagonal: zeros)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[u][q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
+        }
+    };
+    load_items(wv);
     // gather: right-hand side entry plus the children's contributions to each row, in child order
     for (int i = tid; i < f; i += BS) {
         double v[NR];
@@ -419,18 +435,8 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
     }
     __syncthreads();
     // kItemsInFlight items at a time: their loads are independent, so a wave keeps 8 x kItemsInFlight of them in flight
-    constexpr int U = kItemsInFlight;
     for (int it0 = wv; it0 < nrb * nks; it0 += U * NW) {
-        double m[U][8];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int it = it0 + u * NW;
-            const int ks = it / nrb, rb = it - ks * nrb;
-            const int r = rb * 64 + lane, k0 = 8 * ks;
-            const bool live = it < nrb * nks && !(rb * 64 + 63 < k0);      // (wholly above T's diagonal: zeros)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) m[u][q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
-        }
+        if (it0 != wv) load_items(it0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int it = it0 + u * NW;
@@ -462,23 +468,30 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
 
 // backward items: 64 columns (lanes) x 8 rows of W' (= Wt, nc x f col-major), partial sums per row slice;
 // column c's z / part at c * cst
+struct BwdBatch { double m[kItemsInFlight][8]; };
+// the batch of matrix items starting at it0 (the first one is fetched before z is built: bwd_block_body)
+__device__ inline void bwd_load_items(BwdBatch& B, const double* __restrict__ Wt, int nc, int f, int it0, int NW, int lane)
+{
+    const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3;
+#pragma unroll
+    for (int u = 0; u < kItemsInFlight; ++u) {
+        const int it = it0 + u * NW;
+        const int rs = it / ncb, cb = it - rs * ncb;
+        const int j = cb * 64 + lane, r0 = 8 * rs;
+        const bool live = it < ncb * nrs && !(r0 + 7 < cb * 64);       // (rows above the column block's diagonal: zeros)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) B.m[u][q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
+    }
+}
 template <int NR>
-__device__ inline void bwd_items(const double* __restrict__ Wt, int nc, int f, const double* z, double* part, int ncpad,
+__device__ inline void bwd_items(BwdBatch& B, const double* __restrict__ Wt, int nc, int f, const double* z, double* part, int ncpad,
                                  int cst, int wv, int NW, int lane)
 {
     const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3;
     constexpr int U = kItemsInFlight;
     for (int it0 = wv; it0 < ncb * nrs; it0 += U * NW) {
-        double m[U][8];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int it = it0 + u * NW;
-            const int rs = it / ncb, cb = it - rs * ncb;
-            const int j = cb * 64 + lane, r0 = 8 * rs;
-            const bool live = it < ncb * nrs && !(r0 + 7 < cb * 64);       // (rows above the column block's diagonal: zeros)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) m[u][q] = (live && j < nc && r0 + q < f) ? Wt[j + (int64_t)(r0 + q) * nc] : 0.0;
-        }
+        if (it0 != wv) bwd_load_items(B, Wt, nc, f, it0, NW, lane);
+        double (&m)[U][8] = B.m;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int it = it0 + u * NW;
@@ -522,6 +535,8 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
     double* z = smem;
     double* part = smem + fpad;
 
+    BwdBatch first;                           // (in flight while z is built)
+    bwd_load_items(first, Wt, nc, f, wv, NW, lane);
     // z = [D^{-1} y_s ; -x_below]
     for (int i = tid; i < f; i += BS) {
         const double di = (i < nc) ? A.Dinv[c0 + i] : 0.0;
@@ -532,7 +547,7 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
         for (int c = 0; c < NR; ++c) z[c * cst + i] = (i < nc) ? w[c] * di : -w[c];
     }
     __syncthreads();
-    bwd_items<NR>(Wt, nc, f, z, part, ncpad, cst, wv, NW, lane);
+    bwd_items<NR>(first, Wt, nc, f, z, part, ncpad, cst, wv, NW, lane);
     __syncthreads();
     for (int j = tid; j < nc; j += BS) {
         const int pi = T.perm[c0 + j];
