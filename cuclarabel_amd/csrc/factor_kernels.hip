@@ -449,17 +449,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = src[q] >= 0 ? A.Kval[src[q]] : 0.0;
-            if (SLICED) {
-                // (sliced fronts keep kdst = lrow + lcol * ff)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (dst[q] < 0) continue;
-                    const int lc = dst[q] / ff;
-                    int r = dst[q] - lc * ff;
-                    if (r >= nc) r = (r >= r_lo && r < r_lo + rs) ? nc + (r - r_lo) : -1;
-                    dst[q] = r >= 0 ? r + pcol(lc, f) : -1;
-                }
-            }
+            // (a row slice has a K list of its own with positions in its LDS image: hipkkt.hip, upload)
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (dst[q] >= 0) P[dst[q]] = v[q];
         }

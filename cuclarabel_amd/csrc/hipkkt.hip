@@ -750,6 +750,8 @@ private:
     DBuf<int64_t> d_desc;        // FrontDesc = 8 x int64
     DBuf<int64_t> d_sdesc;       // FrontDesc per row slice of the sliced panels
     std::vector<std::array<int, 3>> slice_list;   // (supernode, slice, slices) in launch order
+    std::vector<int64_t> slice_kptr;              // per slice: its K scatter list in ksrc / kdst
+    std::vector<int> slice_nk;
     int64_t panel_cap = 0;
     int panel_max_slices = 1;
     DBuf<int> d_spos, d_sn_parent, top_flags;
@@ -941,7 +943,9 @@ private:
         d_child_ptr.upload(S.child_ptr);
         d_child_idx.upload(S.child_idx);
         d_kptr.upload(S.kptr);
-        d_ksrc.upload(S.ksrc);
+        std::vector<int> ks_all(S.ksrc);
+        slice_kptr.assign(slice_list.size(), 0);
+        slice_nk.assign(slice_list.size(), 0);
         {
             // the panel kernel keeps a block-class front as a trapezoid in LDS (factor_kernels.hip: pcol): its K
             // entries get their packed position; one-wave fronts keep lrow + lcol*f
@@ -957,7 +961,26 @@ private:
                     }
                 }
             }
+            // A row slice of a sliced front gets a K list of its own, with the positions in ITS LDS image (top block +
+            // its rows, as a trapezoid): the panel kernel neither scans the other slices' entries nor divides per entry.
+            for (size_t q = 0; q < slice_list.size(); ++q) {
+                const int s = slice_list[q][0], sl = slice_list[q][1], nsl = slice_list[q][2];
+                const int ff = front_size(s), nc = S.sn_start[s + 1] - S.sn_start[s], nb = ff - nc;
+                const int rsmax = (nb + nsl - 1) / nsl, r_lo = nc + sl * rsmax;
+                const int rs = std::max(0, std::min(rsmax, ff - r_lo)), f = nc + rs;
+                slice_kptr[q] = (int64_t)ks_all.size();
+                for (int64_t e = S.kptr[s]; e < S.kptr[s + 1]; ++e) {
+                    const int lcol = S.kdst[e] / ff;
+                    int r = S.kdst[e] - lcol * ff;
+                    if (r >= nc) { if (r < r_lo || r >= r_lo + rs) continue; r = nc + (r - r_lo); }
+                    ks_all.push_back(S.ksrc[e]);
+                    kd.push_back(r + (int)(((int64_t)lcol * (2 * f - 1 - lcol)) >> 1));
+                }
+                slice_nk[q] = (int)((int64_t)ks_all.size() - slice_kptr[q]);
+            }
+            if (ks_all.size() >= ((size_t)1 << 31)) throw std::runtime_error("K scatter lists exceed int32 indexing");
             d_kdst.upload(kd);
+            d_ksrc.upload(ks_all);
         }
         d_sched.upload(sched);
         d_tiles.upload(tiles);
@@ -1031,6 +1054,7 @@ private:
             for (size_t q = 0; q < slice_list.size(); ++q) {
                 FrontDesc d = desc[(size_t)pos_of[slice_list[q][0]]];
                 d.pad = (slice_list[q][1] << 16) | slice_list[q][2];
+                d.kptr = slice_kptr[q]; d.nk = slice_nk[q];             // (its own K list, positions in the slice's image)
                 std::memcpy(raws.data() + q * 8, &d, sizeof(FrontDesc));
             }
             d_sdesc.upload(raws);
