@@ -420,7 +420,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     int64_t it0 = 0, it1 = 0;
     ExtItem it_first{};
     {
-        const int64_t* __restrict__ wc = T.wave_cut + (int64_t)s * 17;
+        const int64_t* __restrict__ wc = T.wave_cut + (int64_t)(SLICED ? T.nsuper + begin + (int)blockIdx.x : s) * 17;
         constexpr int SPW = 16 / NW > 0 ? 16 / NW : 1;      // slices per wave
         if (wv * SPW < 16) {
             it0 = wc[wv * SPW];

@@ -780,6 +780,7 @@ private:
     TreeDev tree() const
     {
         TreeDev t;
+        t.nsuper = S.nsuper;
         t.sn_start = d_sn_start.p; t.rowptr = d_rowptr.p; t.rows = d_rows.p; t.rel = d_rel.p;
         t.ncolpar = d_ncolpar.p; t.front_off = d_front_off.p; t.upd_off = d_upd_off.p;
         t.child_ptr = d_child_ptr.p; t.child_idx = d_child_idx.p; t.kptr = d_kptr.p;
@@ -1252,11 +1253,8 @@ private:
                     }
                 }
             }
-            std::vector<int64_t> raw(std::max<size_t>(items.size(), 1) * 4);
-            std::memcpy(raw.data(), items.data(), items.size() * sizeof(ExtItem));
-            d_items.upload(raw);
             // 16 slices of each supernode's panel items, cut on column boundaries
-            std::vector<int64_t> wcut((size_t)S.nsuper * 17, 0);
+            std::vector<int64_t> wcut(((size_t)S.nsuper + slice_list.size()) * 17, 0);
             for (int s = 0; s < S.nsuper; ++s) {
                 const int nc = S.sn_start[s + 1] - S.sn_start[s];
                 const int64_t* cp = pptr.data() + S.sn_start[s];      // nc + 1 column pointers
@@ -1269,6 +1267,38 @@ private:
                 }
                 wcut[(size_t)s * 17 + 16] = I1;
             }
+            // A row slice of a sliced front gets an item list of its own: the pieces that reach its rows or the top block,
+            // in the same order, cut into 16 wave slices of whole columns again -- instead of every slice walking the whole
+            // front's list in rounds that are mostly skipped pieces.
+            for (size_t q = 0; q < slice_list.size(); ++q) {
+                const int s = slice_list[q][0], sl = slice_list[q][1], nsl = slice_list[q][2];
+                const int ff = front_size(s), nc = S.sn_start[s + 1] - S.sn_start[s], nb = ff - nc;
+                const int rsmax = (nb + nsl - 1) / nsl, r_lo = nc + sl * rsmax;
+                const int rs = std::max(0, std::min(rsmax, ff - r_lo));
+                const int64_t* cp = pptr.data() + S.sn_start[s];
+                std::vector<int64_t> scp((size_t)nc + 1);
+                for (int j = 0; j < nc; ++j) {
+                    scp[(size_t)j] = (int64_t)items.size();
+                    for (int64_t it = cp[j]; it < cp[j + 1]; ++it) {
+                        const ExtItem e = items[(size_t)it];
+                        if (e.rfirst >= nc && (e.rlast < r_lo || e.rfirst >= r_lo + rs)) continue;
+                        items.push_back(e);
+                    }
+                }
+                scp[(size_t)nc] = (int64_t)items.size();
+                const int64_t I0 = scp[0], I1 = scp[(size_t)nc];
+                int j = 0;
+                int64_t* w = wcut.data() + ((size_t)S.nsuper + q) * 17;
+                for (int k = 0; k < 16; ++k) {
+                    const int64_t target = I0 + ((I1 - I0) * k) / 16;
+                    while (j < nc && scp[(size_t)j] < target) ++j;
+                    w[k] = scp[(size_t)j];
+                }
+                w[16] = I1;
+            }
+            std::vector<int64_t> raw(std::max<size_t>(items.size(), 1) * 4);
+            std::memcpy(raw.data(), items.data(), items.size() * sizeof(ExtItem));
+            d_items.upload(raw);
             d_wave_cut.upload(wcut);
             if (const char* vb = std::getenv("HIPKKT_VERBOSE")) {
                 if (std::atoi(vb) >= 2) {            // the extend-add work of the last fronts of the schedule

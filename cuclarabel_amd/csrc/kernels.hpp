@@ -81,6 +81,7 @@ struct FrontDesc {               // everything a kernel needs to know about one 
 };
 
 struct TreeDev {                 // device copies of the symbolic structure
+    int nsuper;
     const int* sn_start;         // nsuper+1
     const int64_t* rowptr;       // nsuper+1
     const int* rows;             // sum nb
@@ -119,7 +120,7 @@ struct TreeDev {                 // device copies of the symbolic structure
     const int* cuts;
     // per supernode: 17 item indices splitting its panel items (local columns < nc) into 16 slices
     // that end on column boundaries: a wave takes whole columns, so no two waves share a target column
-    const int64_t* wave_cut;     // nsuper * 17
+    const int64_t* wave_cut;     // (nsuper + row slices) * 17: supernode s at s, row slice q of sdesc at nsuper + q (its own item list)
     const int64_t* tinv_off;     // nsuper+1: offset of the solve matrix W = [L11^{-1}; L21 L11^{-1}] (f x nc)
     // Schur tiles: sub-items of tile t are sitems[tile_cut[5t] .. tile_cut[5t+4]), sorted by tile column;
     // wave w of the tile's workgroup takes [tile_cut[5t+w], tile_cut[5t+w+1]) -- whole columns
