@@ -123,7 +123,14 @@ def run_configs(args):
               "4": lambda: [problems.config4(j=j) for j in range(8)], "5": lambda: [problems.config5()],
               # the per-GPU share of cfg4 as ONE block-diagonal problem: all 8 in the same per-level launches
               "4b": lambda: [problems.block_diagonal([problems.config4(j=j) for j in range(8)])]}
+    import tempfile
     for c in args.configs.split(","):
+        # the library reports a bounded wait that expired (overlap mode / persistent kernel falling back) on stderr only:
+        # capture this configuration's stderr and put the count into its row, so that a slow row explains itself
+        sys.stderr.flush()
+        err_copy = os.dup(2)
+        err_file = tempfile.TemporaryFile(mode="w+b")
+        os.dup2(err_file.fileno(), 2)
         pbs = makers[c]()
         per_unit = 8 if c == "4b" else 1
         t0 = time.perf_counter()
@@ -207,6 +214,14 @@ def run_configs(args):
             scale = max(np.abs(xo).max(), np.abs(zo).max())
             row.update(cpu_ms_per_unit=med * 1e3 / per_unit, cpu_units_per_s=per_unit / med, cpu_nnzL=int(o.nnzL), cpu_cores=1,
                        speedup=med / dt, rel_err_vs_oracle=float(max(np.abs(x - xo).max(), np.abs(z - zo).max()) / scale))
+        sys.stderr.flush()
+        os.dup2(err_copy, 2)
+        os.close(err_copy)
+        err_file.seek(0)
+        err_text = err_file.read().decode(errors="replace")
+        err_file.close()
+        sys.stderr.write(err_text)
+        row["fallbacks_reported"] = err_text.count("gave up")
         print(json.dumps(row), flush=True)
         # Host memory released while the GPU works can stall its queues for tens of ms on this stack (a factorisation of
         # the NEXT configuration once read 10.6 instead of 5.6 ms): release this configuration's arrays now, well before

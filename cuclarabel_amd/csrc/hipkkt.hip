@@ -830,10 +830,13 @@ private:
                 const int nc = ncols(s), nb = front_size(s) - nc;
                 int r = panel_slices_needed(nc, nb, panel_cap, std::min(panel_max_slices, std::max(1, nb)));
                 if (r == 0) throw std::runtime_error("panel does not fit LDS even in row slices (panel_cap too large?)");
-                // A sliced front's assembly and trailing work are bound by what ONE CU can load (a 16-piece round of the
-                // extend-add is 6-7 us however tall the slice): more, shorter slices than LDS needs spread them over
-                // more CUs; the price is one more redundant copy of the diagonal block's factorisation per slice.
-                static const int slice_rows = std::getenv("HIPKKT_SLICE_ROWS") ? std::atoi(std::getenv("HIPKKT_SLICE_ROWS")) : 0;
+                // More, shorter slices than LDS needs: a slice's block step is bound by its WORKER waves when it holds many
+                // rows (250 rows x 90 columns: 75 trailing tiles per block on 12 waves = 4-5 us against the diagonal
+                // chain's 3.7), and its assembly by what one CU can load; the price is one more redundant copy of the
+                // diagonal block's factorisation per slice.  128 rows (0 = as few slices as LDS allows): cfg5's
+                // factorisation 5.30 -> 5.06 ms, cfg3's 1.21 -> 1.23 (slices have K and item lists of their own, so the
+                // per-slice overhead no longer grows with their number).
+                static const int slice_rows = std::getenv("HIPKKT_SLICE_ROWS") ? std::atoi(std::getenv("HIPKKT_SLICE_ROWS")) : 128;
                 if (r > 1 && slice_rows > 0) r = std::max(r, std::min(panel_max_slices, (nb + slice_rows - 1) / slice_rows));
                 return r;
             };
