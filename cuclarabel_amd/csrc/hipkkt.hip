@@ -995,8 +995,11 @@ private:
             size_t first = launches.size();
             while (first > 0) {
                 const Launch& L = launches[first - 1];
-                // (workgroups of the launch: whole panels plus row slices)
-                if (L.small || L.count - L.nsliced + L.slice_count > ov_max) break;
+                // (workgroups of the launch: whole panels plus row slices.  A launch that holds BOTH kinds runs them as two
+                //  kernels one after the other: the level's tiles, submitted behind both, can reach the CUs while the
+                //  first one still runs and leave none for the second -- seen as sporadic give-ups on cfg5; such launches
+                //  stay out of the overlap mode)
+                if (L.small || L.count - L.nsliced + L.slice_count > ov_max || (L.nsliced > 0 && L.nsliced < L.count)) break;
                 --first;
             }
             ov_first = (launches.size() - first >= 3) ? first : launches.size();
