@@ -774,7 +774,7 @@ def test_row_sliced_panels(maker, cap, overlap):
 
 
 @pytest.mark.parametrize("maker", ["problems.config3(nblocks=4, blk=400)",
-                                   "problems.config5(n=400, npsd=10, psd_dim=16, nsoc=4, soc_dim=20)"])
+                                   "problems.config5(n=200, npsd=3, psd_dim=28, nsoc=2, soc_dim=12)"])
 @pytest.mark.parametrize("limit", [None, "0"])
 def test_sliced_panels_in_overlap_mode(maker, limit):
     """Fronts factorised in row slices inside the overlap mode's launches: every slice publishes its rows of a 16-column
