@@ -7,7 +7,11 @@ One "step" = one interior-point iteration's KKT work on the BASELINE.json worklo
     1 x numeric LDL^T                                            (refactor!, a11)
     3 x solve with iterative refinement                          (kktsolver_solve!, a13-a14:
         constant RHS, affine RHS, combined RHS -- kktsystem.jl:87-88,170-171)
-with (s, z) and the three right-hand sides already resident in HBM.  N > 1 GPUs: every rank
+issued the way solver.jl:278-319 issues it -- kkt_update!, kkt_solve!(:affine), kkt_solve!(:combined), three SEPARATE
+calls on the reduced-system layer (level C of the C ABI, hipkkt_kkt_system_*), including its right-hand-side
+construction and step recovery -- with the iterate and the right-hand sides already resident in HBM.  The handle is in
+lazy mode (hipkkt_kkt_system_set_lazy): kkt_update! leaves the constant-RHS solve to the affine kkt_solve!, which
+sends both right-hand sides through the triangular sweeps as one 2-column solve.  N > 1 GPUs: every rank
 runs the same workload on its own problem instance (seed + rank), no data-path collective
 (independent problems shard: SURVEY.md section 8e) -> weak scaling; one tiny RCCL all-reduce
 of the timing at the end.
@@ -28,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6       # MI355X_MICROARCH.md: dense FP64 matrix peak
+FP64_MFMA_MEASURED_TF = 49.1   # scripts/fp64_mfma_peak.hip on an MI355X box (profiles/r02a_fp64_peak.json)
 
 
 def algorithmic_bytes(info):
@@ -80,31 +85,50 @@ def cpu_baseline(pb, n_units):
     build = native_oracle()
     from tests.oracle_bindings import make_oracle
     from cuclarabel_amd import _lib
+    from tests.oracle_bindings import min_degree
     o0 = make_oracle(pb, perm=np.arange(pb.n + pb.m + 2 * sum(1 for c in pb.cones if c.kind == 2 and c.dim > 4)))
-    perm, _ = _lib.symbolic_analyse(o0.K(), ordering=_lib.ORDER_AMD)      # the reference orders with AMD
+    K0 = o0.K()
     del o0
-    o = make_oracle(pb, perm=perm)
     rng = np.random.default_rng(0)
     rhs = [(rng.standard_normal(pb.n), rng.standard_normal(pb.m)) for _ in range(3)]
-    times = []
-    ir = 0
-    for it in range(n_units + 2):
-        t0 = time.perf_counter()
-        assert o.update_scaling(pb.s0, pb.z0)
-        assert o.kktsolver_update()
-        for rx, rz in rhs:
-            o.kktsolver_setrhs(rx, rz)
-            ok, _, _ = o.kktsolver_solve()
-            assert ok
-            ir += o.last_ir_iters
-        times.append(time.perf_counter() - t0)
-    times = sorted(times[2:])
-    med = times[len(times) // 2]
+
+    def timed_units(o, units):
+        times = []
+        for it in range(units + 2):
+            t0 = time.perf_counter()
+            assert o.update_scaling(pb.s0, pb.z0)
+            assert o.kktsolver_update()
+            for rx, rz in rhs:
+                o.kktsolver_setrhs(rx, rz)
+                ok, _, _ = o.kktsolver_solve()
+                assert ok
+            times.append(time.perf_counter() - t0)
+        times = sorted(times[2:])
+        return times[len(times) // 2]
+
+    # The reference orders with AMD (directldl_qdldl.jl:18-25).  The oracle's own ordering is a plain minimum-degree
+    # (oracle/kkt_oracle.c, orc_min_degree: ~12 % more fill than AMD on this workload); the permutation that gives the
+    # CPU side its best case is the AMD of the product's HOST-side symbolic analysis (hipkkt_symbolic_analyse,
+    # ordering = AMD; no GPU involved).  `value` is quoted with the latter -- the faster CPU figure -- and the oracle
+    # on its own ordering is timed beside it.
+    perm, _ = _lib.symbolic_analyse(K0, ordering=_lib.ORDER_AMD)
+    o = make_oracle(pb, perm=perm)
+    med = timed_units(o, n_units)
+    nnzL_amd = int(o.nnzL)
+    del o
+    own = None
+    if n_units >= 4:
+        o = make_oracle(pb, perm=min_degree(K0))
+        med_own = timed_units(o, max(2, n_units // 3))
+        own = dict(value=1.0 / med_own, ms_per_unit=med_own * 1e3, nnzL=int(o.nnzL),
+                   ordering="oracle's own minimum degree (orc_min_degree)")
+        del o
     return dict(value=1.0 / med, unit="KKT factorize+solve/s", cores=1, kind="port",
                 sample=f"{n_units} timed units (+2 warm-ups) of the same workload, median; oracle/kkt_oracle.c "
-                       f"({build}; scalar up-looking LDL', AMD ordering, nnzL={o.nnzL}), host {host_cpu_model()}, "
-                       f"threads=1 of {os.cpu_count()}",
-                ms_per_unit=med * 1e3)
+                       f"({build}; scalar up-looking LDL' as QDLDL, nnzL={nnzL_amd}), permutation = AMD computed by the "
+                       f"product's host-side symbolic analysis (hipkkt_symbolic_analyse; the reference orders with AMD too), "
+                       f"host {host_cpu_model()}, threads=1 of {os.cpu_count()}",
+                ms_per_unit=med * 1e3, own_ordering=own)
 
 
 def run_configs(args):
@@ -182,6 +206,7 @@ def run_configs(args):
         dt = (time.perf_counter() - t0) / (args.steps * len(sol))
         prof = sol[0].profile()
         info = sol[0].info
+        fallbacks = [sum(k.fallbacks[i] for k in sol) for i in (0, 1)]       # (overlap mode, persistent sweep kernel): the ABI's counters
         row = dict(config=c, problems_on_gpu=len(sol), N=info["N"], nnzK=info["nnzK"], nnzL=info["nnzL"],
                    nnzL_stored=info["nnzL_stored"], levels=info["nlevels"], max_front=info["max_front"],
                    factor_gflop=info["factor_flops"] / 1e9, setup_s=setup_s / len(sol),
@@ -221,6 +246,7 @@ def run_configs(args):
         err_text = err_file.read().decode(errors="replace")
         err_file.close()
         sys.stderr.write(err_text)
+        row["fallbacks"] = fallbacks
         row["fallbacks_reported"] = err_text.count("gave up")
         print(json.dumps(row), flush=True)
         # Host memory released while the GPU works can stall its queues for tens of ms on this stack (a factorisation of
@@ -286,6 +312,9 @@ def main():
     ap.add_argument("--problems", type=int, default=64)
     ap.add_argument("--per-handle", type=int, default=8)
     ap.add_argument("--nrhs", type=int, default=512)
+    ap.add_argument("--rhs-block", type=int, default=32,
+                    help="--mode rhs with N > 1: columns per rank solved (and exchanged) at a time; block i's (x, z) "
+                         "solutions are all-gathered while block i + 1 is being solved")
     ap.add_argument("--ordering", default="nd", choices=["nd", "amd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-units", type=int, default=10)
@@ -405,6 +434,36 @@ def main():
             if rc != 0:
                 raise RuntimeError("deferred status %d: a factorisation / solve of this step failed or stopped refining early" % rc)
 
+    def make_system(pb, rng, lazy=True):
+        """The reduced-system layer on the device (level C: DefaultKKTSystem, kktsystem.jl:21-215) with a synthetic
+        iterate and right-hand sides resident in HBM."""
+        from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+        st = _lib.default_settings(device=local_rank, ordering=_lib.ORDER_ND if args.ordering == "nd" else _lib.ORDER_AMD)
+        ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
+        ks.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        system = HipKKTSystem(ks)
+        system.init(pb.q, pb.b)
+        system.set_lazy(lazy)
+        dd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        var = [dd(rng.standard_normal(pb.n)), dd(pb.s0), dd(pb.z0)]
+        rhs = [[dd(rng.standard_normal(k)) for k in (pb.n, pb.m, pb.m)] for _ in range(2)]      # affine, combined
+        lhs = [torch.zeros(k, dtype=torch.float64, device=dev) for k in (pb.n, pb.m, pb.m)]
+        P = lambda ts: [t.data_ptr() for t in ts]
+        return ks, system, dict(var=P(var), rhs=[P(rhs[0]), P(rhs[1])], lhs=P(lhs), keep=(var, rhs, lhs), tau=1.1, kappa=0.9)
+
+    def unit_c(system, st):
+        """One interior-point iteration's reduced-system work as solver.jl:278-319 issues it: kkt_update!, then
+        kkt_solve!(:affine), then kkt_solve!(:combined) -- three separate calls, each returning its own status (and
+        (dtau, dkappa)) to the host.  In lazy mode the first leaves its constant-RHS solve to the second, which sends
+        both right-hand sides through the sweeps together; 3 solves with refinement per step either way."""
+        if not system.update_dev(st["var"][1], st["var"][2]):
+            raise RuntimeError("kkt_update! failed")
+        for i, affine in enumerate((True, False)):
+            ok, dtau, dkappa = system.solve_dev(st["lhs"], st["rhs"][i], 0.3, -0.1, st["var"], st["tau"], st["kappa"], affine)
+            if not ok:
+                raise RuntimeError("kkt_solve! failed")
+        return dtau
+
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic"}
     if dry:
@@ -420,11 +479,12 @@ def main():
             rng = np.random.default_rng(0)
             for g in groups:
                 pb = problems.block_diagonal([problems.config4(j=j, n=n) for j in g])
-                handles.append((make_solver(pb), resident(pb, rng), g))
+                ks, system, st = make_system(pb, rng)
+                handles.append((ks, st, g, system))
 
         def step():
-            for ks, st, _ in handles:
-                unit(ks, st)
+            for ks, st, _, system in handles:
+                unit_c(system, st)
 
         elapsed = timed(step)
         # per-problem records [index, status, refinement rounds of the last solve, N of its handle]: the one exchange
@@ -442,6 +502,8 @@ def main():
                        config={"workload": "cfg4: %d independent SOCPs n=%d m=%d NN(%d)+%dxSOC(100), dealt round-robin to the ranks, "
                                            "%d per block-diagonal handle; per problem 1 update + 1 LDL' refactor + 3 solves with IR per step"
                                            % (args.problems, n, 2 * n, n, n // 100, args.per_handle),
+                               "calls": "kkt_update! / kkt_solve!(:affine) / kkt_solve!(:combined) as three separate level-C calls, lazy constant-RHS solve",
+                               "fallbacks": [sum(h[0].fallbacks[i] for h in handles) for i in (0, 1)],
                                "problems_per_rank": len(mine), "handles_per_rank": len(groups),
                                "parallelism": "independent problems per GPU, record all-gather over RCCL"})
             print(json.dumps(out), flush=True)
@@ -459,23 +521,39 @@ def main():
         if not dry:
             pb = problems.config2(seed=1002, n=n)                     # the same K on every rank: the factor is replicated
             ks = make_solver(pb)
+            ks.set_deferred_status(False)      # solve_multi reports per call (2..8 columns per rank would otherwise only enqueue)
             if not ks.kktsolver_update_from_sz(pb.s0, pb.z0):
                 raise RuntimeError("factorisation failed")
             g = torch.Generator(device="cpu").manual_seed(7)
             RX = torch.randn(k, pb.n, dtype=torch.float64, generator=g)[mine].to(dev)       # row j = column j (contiguous)
             RZ = torch.randn(k, pb.m, dtype=torch.float64, generator=g)[mine].to(dev)
             LZ = torch.zeros(max(km, 1), pb.m, dtype=torch.float64, device=dev)
+        pm = pb.m if not dry else 96
         LX = torch.zeros(max(km, 1), pn, dtype=torch.float64, device=dev)
+        if dry:
+            LZ = torch.zeros(max(km, 1), pm, dtype=torch.float64, device=dev)
         rounds = [0]
+        # N > 1: the (x, z) solutions -- the solution of K [x; z] = [rx; rz] is both -- are exchanged in blocks of
+        # --rhs-block columns per rank, block i on the links while block i + 1 is solved (BlockedColumnGather)
+        from cuclarabel_amd.distributed import BlockedColumnGather
+        gather = BlockedColumnGather(k, (pn, pm), args.rhs_block if world > 1 else max(km, 1), device=dev)
 
         def step():
-            if km and not dry:
-                ok, ir = ks.kktsolver_solve_multi_dev(km, RX.data_ptr(), RZ.data_ptr(), LX.data_ptr(), LZ.data_ptr())
-                if not ok:
-                    raise RuntimeError("solve failed")
-                rounds[0] += int(ir.sum())
+            for q0, q1 in gather.blocks():
+                kb = max(0, min(q1, km) - q0)
+                if kb and not dry:
+                    esz = 8
+                    ok, ir = ks.kktsolver_solve_multi_dev(kb, RX.data_ptr() + q0 * pb.n * esz, RZ.data_ptr() + q0 * pb.m * esz,
+                                                          LX.data_ptr() + q0 * pb.n * esz, LZ.data_ptr() + q0 * pb.m * esz)
+                    if not ok:
+                        raise RuntimeError("solve failed")
+                    if (ir < 0).any():
+                        raise RuntimeError("refinement-round counts missing (deferred status?)")
+                    rounds[0] += int(ir.sum())
+                if world > 1:
+                    gather.post(q0, q1, [LX[q0:q1], LZ[q0:q1]])
             if world > 1:
-                gather_columns(LX, k)                                  # RCCL all-gather: the one exchange of this mode
+                gather.finish()
 
         elapsed = timed(step)
         if rank == 0:
@@ -484,7 +562,9 @@ def main():
                        scaling="strong",
                        config={"workload": "cfg2's factor (n=%d) replicated per rank; %d right-hand sides dealt round-robin, "
                                            "hipkkt_kkt_solve_multi_dev on each share, solutions all-gathered" % (n, k),
-                               "columns_per_rank": km, "parallelism": "RHS columns per GPU, one all-gather over RCCL"})
+                               "columns_per_rank": km, "columns_per_block": args.rhs_block if world > 1 else km,
+                               "parallelism": "RHS columns per GPU; (x, z) solutions all-gathered over RCCL in blocks of "
+                                              "columns, block i's exchange overlapping block i + 1's solves"})
             if not dry:
                 info = ks.info
                 sweeps = 1.0 + rounds[0] / max(km * (args.steps + args.warmup), 1)
@@ -513,7 +593,7 @@ def main():
         return
     pb = problems.config2(seed=1002 + rank, n=n)
     t0 = time.perf_counter()
-    ks = make_solver(pb)
+    ks, system, stc = make_system(pb, np.random.default_rng(0), lazy=not args.sequential_solves)
     setup_s = time.perf_counter() - t0
     st = resident(pb, np.random.default_rng(0))
     # (set-up has freed large host arrays; let the unmapping settle before any timed GPU work: see the note at gc.disable)
@@ -521,35 +601,57 @@ def main():
     torch.cuda.synchronize(dev)
     time.sleep(0.5)
 
+    # ---- the timed pass: level C, three separate calls per step, no instrumentation
     for _ in range(args.warmup):
-        unit(ks, st, may_repeat=True)
+        unit_c(system, stc)
+    fb0 = ks.fallbacks
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        unit(ks, st)
+        unit_c(system, stc)
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0, device=dev)
-    # the per-phase breakdown comes from a second, instrumented pass over the same steps (hipEvents around every phase
-    # on the kernels' stream: ~16 event records per step, each a marker packet the stream waits on -- instrumentation
-    # that does not belong in the timed region)
-    # ... and with single-column solves only: every phase launch is then one single-column sweep / residual, which is
-    # what the roofline objects are quoted for.  The same pass un-instrumented gives the step both ways.
+    fb1 = ks.fallbacks
+    if fb1 != fb0:
+        raise RuntimeError("a fallback was taken inside the timed region (overlap, top) %s -> %s" % (fb0, fb1))
+    # ---- the same step with the constant-RHS solve issued by kkt_update! itself (eager: three single-column solves)
+    system.set_lazy(False)
+    unit_c(system, stc)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        unit(ks, st, batched=False)
+        unit_c(system, stc)
     barrier()
     elapsed_seq = time.perf_counter() - t0
+    # the per-phase breakdown comes from an instrumented pass over the same steps (hipEvents around every phase on the
+    # kernels' stream: ~16 event records per step, each a marker packet the stream waits on -- instrumentation that does
+    # not belong in the timed region), with single-column solves only: every phase launch is then one single-column
+    # sweep / residual, which is what the roofline objects are quoted for.
     ks.profile_enable(True)
     ks.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        unit(ks, st, batched=False)
+        unit_c(system, stc)
     barrier()
     elapsed_profiled = time.perf_counter() - t0
     prof = ks.profile()
     ks.profile_enable(False)
+    # ---- for continuity with rounds 1-2: the bare level-B sequence (update, three solves on given right-hand sides, no
+    #      right-hand-side construction / step recovery), deferred status, constant + affine as an explicit 2-column call
+    level_b = {}
+    system.set_lazy(not args.sequential_solves)
+    ks.set_deferred_status(not args.sync_status)
+    for name, batched in (("batched_2col", True), ("three_single_solves", False)):
+        unit(ks, st, batched, may_repeat=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            unit(ks, st, batched)
+        barrier()
+        level_b[name] = (time.perf_counter() - t0) / args.steps * 1e3
+    ks.set_deferred_status(False)
+    fb2 = ks.fallbacks
 
     if rank == 0:
         info = ks.info
@@ -583,7 +685,9 @@ def main():
             if phase == "factor" and d["frac_fp64_mfma_peak"] > d["frac"]:
                 # roofline.achieved(factor) = max(B_fact/t/8 TB/s, F_fact/t/78.6 TF)
                 r.update(bound="mfma", achieved=d["achieved_TFLOPs"], peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
-                         frac=d["frac_fp64_mfma_peak"])
+                         frac=d["frac_fp64_mfma_peak"],
+                         # the box's own v_mfma_f64_16x16x4_f64 rate (scripts/fp64_mfma_peak.hip, profiles/r02a_fp64_peak.json)
+                         frac_vs_measured_peak=d["achieved_TFLOPs"] / FP64_MFMA_MEASURED_TF, measured_peak=FP64_MFMA_MEASURED_TF)
             r["note"] = ("phase = all kernel launches of one %s (a dependency chain over the elimination-tree levels, "
                          "so latency- rather than roofline-bound); algorithmic bytes/flops per SURVEY.md 8(d); "
                          "traffic = FETCH_SIZE+WRITE_SIZE bytes per launch of the phase from the committed PMC passes "
@@ -620,15 +724,23 @@ def main():
                        "factor_flops": info["factor_flops"], "ordering": args.ordering,
                        "ir_rounds_per_step": prof["ir_iterations"] / max(args.steps, 1),
                        "setup_s": setup_s, "parallelism": "independent problems per GPU",
-                       "status": "per call" if args.sync_status else "deferred: one status query per step",
+                       "calls": "level C (hipkkt_kkt_system_*): kkt_update!, kkt_solve!(:affine), kkt_solve!(:combined) as "
+                                "three separate calls per step (solver.jl:278-319), each returning its status and "
+                                "(dtau, dkappa) to the host; right-hand-side construction and step recovery included; "
+                                + ("eager constant-RHS solve" if args.sequential_solves else
+                                   "lazy mode: kkt_update! leaves the constant-RHS solve to the affine kkt_solve! (one 2-column solve)"),
                        "csrc_sha16": traffic_summary()[2]},
             "roofline": roofline,
             "roofline_trisolve": rt,      # the north-star's named roofline target
             "phases": phases,
             "ms_per_step_sequential_solves": elapsed_seq / args.steps * 1e3,
             "solves": ("3 single-column solves per step" if args.sequential_solves else
-                       "k = 2: constant + affine right-hand sides share one 2-column solve, combined alone (3 solves per step); "
-                       "ms_per_step_sequential_solves is the same step with three single-column solves (k = 1)"),
+                       "constant + affine right-hand sides share one 2-column solve (issued by the affine kkt_solve! in lazy "
+                       "mode), combined alone (3 solves per step); ms_per_step_sequential_solves is the same step with "
+                       "kkt_update! solving the constant right-hand side itself (three single-column solves)"),
+            "fallbacks": {"overlap": fb2[0], "top": fb2[1], "in_timed_region": 0},
+            # rounds 1-2 quoted this: level B alone (no right-hand-side construction / step recovery), deferred status
+            "level_B_ms_per_step": level_b,
             "ms_per_step_instrumented": elapsed_profiled / args.steps * 1e3,
             "ms_per_step_outside_phases": elapsed_profiled / args.steps * 1e3 - phase_sum,
         })

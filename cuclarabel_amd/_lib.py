@@ -53,7 +53,8 @@ class Profile(C.Structure):
                 ("residual_ms", C.c_double), ("other_ms", C.c_double),
                 ("n_update", C.c_int64), ("n_factor", C.c_int64), ("n_trisolve", C.c_int64),
                 ("n_residual", C.c_int64), ("ir_iterations", C.c_int64),
-                ("dynamic_regularizations", C.c_int64)]
+                ("dynamic_regularizations", C.c_int64),
+                ("overlap_fallbacks", C.c_int64), ("top_fallbacks", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -78,6 +79,7 @@ SYMBOLS = {
     "hipkkt_ldl_solve_multi_dev": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64]),
     "hipkkt_ldl_info": (C.c_int, [_P, _P]),
     "hipkkt_ldl_get_perm": (C.c_int, [_P, _P]),
+    "hipkkt_ldl_fallbacks": (C.c_int, [_P, _P]),
     "hipkkt_kkt_create": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, C.c_int]),
     "hipkkt_kkt_destroy": (None, [_P]),
     "hipkkt_kkt_info": (C.c_int, [_P, _P]),
@@ -102,6 +104,12 @@ SYMBOLS = {
                                           _P, _P, _P, C.c_double, C.c_double, C.c_int]),
     "hipkkt_kkt_system_update_and_solve_affine": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                                             _P, _P, _P, C.c_double, C.c_double]),
+    "hipkkt_kkt_system_set_lazy": (C.c_int, [_P, C.c_int]),
+    "hipkkt_kkt_system_update_cones": (C.c_int, [_P] * 10),
+    "hipkkt_kkt_system_update_host": (C.c_int, [_P, _P, _P]),
+    "hipkkt_kkt_system_solve_initial_point_host": (C.c_int, [_P, _P, _P, _P]),
+    "hipkkt_kkt_system_solve_host": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
+                                               _P, _P, _P, C.c_double, C.c_double, C.c_int]),
     "hipkkt_equilibrate": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P,
                                      C.c_int32, C.c_double, C.c_double, _P, _P, _P, C.c_int, C.c_int]),
     "hipkkt_scale_matrix_values": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_int, C.c_int]),
@@ -112,6 +120,7 @@ SYMBOLS = {
     "hipkkt_kkt_get_perm": (C.c_int, [_P, _P]),
     "hipkkt_kkt_get_Hs": (C.c_int, [_P, _P]),
     "hipkkt_kkt_get_scaling": (C.c_int, [_P, _P, _P, _P]),
+    "hipkkt_kkt_get_scaling_w": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_last_regularizer": (C.c_double, [_P]),
     "hipkkt_kkt_last_ir_iterations": (C.c_int64, [_P]),
     "hipkkt_kkt_set_stream": (C.c_int, [_P, _P]),

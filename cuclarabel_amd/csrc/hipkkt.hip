@@ -360,9 +360,14 @@ private:
         }
         int li = 0;
         bool forked = false;
-        // EXPERIMENT (timing only, valid when K does not change between factorisations): skip W formation after n factorisations
+#ifdef HIPKKT_EXPERIMENTS
+        // EXPERIMENT (timing only, wrong results unless K stays the same between factorisations; compiled in only with
+        // -DHIPKKT_EXPERIMENTS, never in the default build): skip W formation after n factorisations
         static const int skip_w_after = std::getenv("HIPKKT_EXPERIMENT_SKIP_WINV") ? std::atoi(std::getenv("HIPKKT_EXPERIMENT_SKIP_WINV")) : -1;
         const bool skip_w = skip_w_after >= 0 && n_skipw_calls++ >= skip_w_after;
+#else
+        const bool skip_w = false;
+#endif
         // (every W formation of this factorisation goes through form_w)
         auto form_w = [&](const int* list, int count, int ncmax, hipStream_t on, int max_blocks) {
             if (!skip_w) launch_tinv(a.T, fronts.p, tinv.p, list, count, ncmax, on, max_blocks);
@@ -477,6 +482,9 @@ private:
         if ((size_t)nr <= nr_cap) return;
         wait_w(stream);
         HIP_CHECK(hipStreamSynchronize(stream));
+        // (solve graphs captured so far have the old xp / uvec baked in)
+        for (auto& kv : solve_graphs) (void)hipGraphExecDestroy(kv.second);
+        solve_graphs.clear();
         xp.alloc((size_t)S.N * nr);
         uvec.alloc(std::max<size_t>(S.rows.size(), 1) * nr);
         nr_cap = (size_t)nr;
@@ -680,9 +688,11 @@ public:
     // device word set by the persistent kernel when one of its bounded waits expired (nullptr: no such kernel)
     const int* top_abort_word() const { return (top_flags.p && top_launches > 0) ? top_flags.p + 2 * top_nflag : nullptr; }
     // The caller has synchronised and found the abort word set: clear it and never use the kernel again.
+    int64_t n_ov_fallbacks = 0, n_top_fallbacks = 0;      // lifetime counts (hipkkt_profile, hipkkt_ldl_fallbacks)
     void top_gave_up()
     {
         top_disabled = true;
+        ++n_top_fallbacks;
         release_top();
         launch_zero_ints(top_flags.p + 2 * top_nflag, 1, stream);
         std::fprintf(stderr, "[hipkkt] persistent top-of-tree kernel gave up waiting (GPU shared with another "
@@ -711,6 +721,7 @@ public:
     void ov_gave_up()
     {
         ov_disabled = true;
+        ++n_ov_fallbacks;
         std::fprintf(stderr, "[hipkkt] factorisation overlap gave up waiting; falling back to one level after the other\n");
     }
     static bool overlap_wanted()
@@ -733,7 +744,9 @@ private:
     DBuf<int64_t> d_tinv_off;
     DBuf<double> top_stamps;
     int n_stamp_sweeps = 0;
+#ifdef HIPKKT_EXPERIMENTS
     int n_skipw_calls = 0;
+#endif
     DBuf<int> d_tinv_list;
     std::vector<int> tinv_list;
     int tinv_ncmax = 1;
@@ -1547,6 +1560,9 @@ struct hipkkt_kkt_s {
     DBuf<double> sq, snegq, sb, sx1, sz1, sx2, sz2, sworkx, sworkz, sconic, spa, spb;
     DBuf<double> sys_partial, sys_dots, sys_cached, sys_in, sys_out;
     bool sys_ready = false;
+    bool sys_lazy = false;           // hipkkt_kkt_system_set_lazy: kkt_update! leaves (x2, z2) = K \ (-q, b) to the affine kkt_solve!
+    bool sys_const_pending = false;  // ... and that solve is still due
+    DBuf<double> hst;                // staging of the *_host entry points of level C: 3 x (n + 2 m) doubles (rhs, variables, lhs)
     // solve_multi work space, N x mcap each (grown on demand)
     DBuf<double> mB, mX, mC, mE, mE2, mpartial, mnorms;
     DBuf<int> mmask;
@@ -1838,6 +1854,16 @@ int hipkkt_ldl_get_perm(hipkkt_ldl_t h, int64_t* perm)
     return guarded([&]() {
         if (!h || !perm) throw ArgError("hipkkt_ldl_get_perm: bad argument");
         for (int64_t i = 0; i < h->N; ++i) perm[i] = h->eng->S.perm[i];
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_ldl_fallbacks(hipkkt_ldl_t h, int64_t out[2])
+{
+    return guarded([&]() {
+        if (!h || !out) throw ArgError("hipkkt_ldl_fallbacks: bad argument");
+        out[0] = h->eng->n_ov_fallbacks;
+        out[1] = h->eng->n_top_fallbacks;
         return HIPKKT_OK;
     });
 }
@@ -2353,15 +2379,14 @@ int hipkkt_kkt_deferred_status(hipkkt_kkt_t h)
         h->prof.acc.dynamic_regularizations += (int64_t)s[4];
         if (s[5] != 0.0 || !h->st.static_regularization_enable) h->last_eps = h->st.static_regularization_enable ? s[5] : 0.0;
         if (s[6] > 0.0) h->last_ir = (int64_t)(s[3] / s[6] + 0.5);      // mean rounds per solve since the last query
+        // The give-up words come first (as on the synchronous paths: kkt_update_device, kkt_solve_core): after a bounded
+        // wait expired the factor or the solution is void and may well be non-finite -- that is not a numeric failure of
+        // the problem but a step to repeat, with the mechanism switched off.
+        bool gave_up = false;
+        if (s[7] != 0.0) { h->eng->ov_gave_up(); gave_up = true; }      // never expected; see LDLEngine::ov_gave_up
+        if (s[2] != 0.0 && h->eng->top_abort_word() != nullptr) { h->eng->top_gave_up(); gave_up = true; }   // see TopOwner
+        if (gave_up) return HIPKKT_REFINEMENT_INCOMPLETE;               // (the step's results are void: repeat it)
         if (s[0] != 0.0) return HIPKKT_NUMERIC_FAILURE;
-        if (s[7] != 0.0) {                                              // never expected; see LDLEngine::ov_gave_up
-            h->eng->ov_gave_up();
-            return HIPKKT_REFINEMENT_INCOMPLETE;                        // (the step's results are void: repeat it)
-        }
-        if (s[2] != 0.0 && h->eng->top_abort_word() != nullptr) {       // never expected; see TopOwner
-            h->eng->top_gave_up();
-            return HIPKKT_REFINEMENT_INCOMPLETE;
-        }
         if (s[1] != 0.0) {                                              // some solve would have gone on refining
             h->r_spec = std::min(max_iter, h->r_spec + 1);
             return HIPKKT_REFINEMENT_INCOMPLETE;
@@ -2615,9 +2640,9 @@ int hipkkt_kkt_solve_multi_dev(hipkkt_kkt_t h, int64_t nrhs, const double* d_rhs
             std::swap(h->b.p, h->mB.p);
             launch_pack_rhs(h->b.p, d_rhsx, d_rhsz, h->K.n, h->K.m, h->K.p, h->stream);
             int rc;
-            try { rc = kkt_solve_core(h); } catch (...) { std::swap(h->b.p, h->mB.p); throw; }
+            try { rc = kkt_solve_core(h, true); } catch (...) { std::swap(h->b.p, h->mB.p); throw; }
             std::swap(h->b.p, h->mB.p);
-            if (ir_iterations) ir_iterations[0] = h->last_ir;
+            if (ir_iterations) ir_iterations[0] = h->last_ir;      // (-1 in deferred-status mode, as for 2..8 columns)
             if (rc != HIPKKT_OK) return rc;
             launch_unpack_lhs(d_lhsx, d_lhsz, h->cur_x, h->K.n, h->K.m, h->stream);
             return HIPKKT_OK;
@@ -2741,16 +2766,47 @@ int hipkkt_kkt_system_solve_constant_rhs(hipkkt_kkt_t h)
     return guarded([&]() {
         if (!h || !h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
         HIP_CHECK(hipSetDevice(h->device));
+        h->sys_const_pending = false;
         return sys_constant_rhs(h);
     });
+}
+
+int hipkkt_kkt_system_set_lazy(hipkkt_kkt_t h, int lazy)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        if (!lazy && h->sys_const_pending) {           // leaving the mode with a solve still due: run it now
+            if (!h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
+            HIP_CHECK(hipSetDevice(h->device));
+            h->sys_const_pending = false;
+            h->sys_lazy = false;
+            return sys_constant_rhs(h);
+        }
+        h->sys_lazy = lazy != 0;
+        return HIPKKT_OK;
+    });
+}
+
+// the constant-RHS part of kkt_update! (kktsystem.jl:74-77): at once, or noted for the affine kkt_solve! (lazy mode)
+static int sys_after_update(hipkkt_kkt_t h)
+{
+    if (!h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
+    if (h->deferred) throw ArgError("hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)");
+    if (h->sys_lazy) { h->sys_const_pending = true; return HIPKKT_OK; }
+    h->sys_const_pending = false;
+    return sys_constant_rhs(h);
 }
 
 int hipkkt_kkt_system_update(hipkkt_kkt_t h, const double* d_s, const double* d_z)
 {
     // kkt_update! (kktsystem.jl:62-78)
+    if (h && h->deferred) {
+        g_last_error = "hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)";
+        return HIPKKT_ERR_ARG;         // (before anything is enqueued: a deferred factorisation's status would be left unread)
+    }
     int rc = hipkkt_kkt_update_from_sz_dev(h, d_s, d_z);
-    if (rc != HIPKKT_OK) return rc;
-    return hipkkt_kkt_system_solve_constant_rhs(h);
+    if (rc != HIPKKT_OK) return rc;                    // "bail if the factorization has failed" (:71)
+    return guarded([&]() { return sys_after_update(h); });
 }
 
 int hipkkt_kkt_system_solve_initial_point(hipkkt_kkt_t h, double* d_x, double* d_s, double* d_z)
@@ -2787,27 +2843,24 @@ static void sys_finish_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, do
 {
     const int n = h->K.n, m = h->K.m;
     hipStream_t st = h->stream;
-    const double sc_in[4] = {rhs_tau, rhs_kappa, var_tau, var_kappa};
-    HIP_CHECK(hipMemcpyAsync(h->sys_in.p, sc_in, sizeof(sc_in), hipMemcpyHostToDevice, st));
-    launch_P_spmv(sys_spmv(h), h->Kval.p, h->sx1.p, h->spa.p, n, st);                          // P x1
-    launch_sys_axpby(h->sworkx.p, d_var_x, h->sys_in.p + 2, h->sx2.p, nullptr, -1.0, n, st);   // xi - x2
-    launch_P_spmv(sys_spmv(h), h->Kval.p, h->sworkx.p, h->spb.p, n, st);                       // P (xi - x2)
+    // P x1 and P (xi - x2), xi = x / tau, in one pass (xi - x2 kept in workx for its dot product)
+    launch_P_spmv2(sys_spmv(h), h->Kval.p, h->sx1.p, d_var_x, h->sx2.p, var_tau, h->spa.p, h->spb.p, h->sworkx.p, n, st);
     DotPairs P{};
     P.npairs = 4;
     P.a[0] = h->sq.p; P.b[0] = h->sx1.p; P.len[0] = n;
     P.a[1] = h->sb.p; P.b[1] = h->sz1.p; P.len[1] = m;
     P.a[2] = d_var_x; P.b[2] = h->spa.p; P.len[2] = n;
     P.a[3] = h->sworkx.p; P.b[3] = h->spb.p; P.len[3] = n;
-    launch_dots(P, h->sys_partial.p, h->sys_dots.p, st);
-    launch_sys_scalars(h->sys_dots.p, h->sys_cached.p, h->sys_in.p, h->sys_out.p, st);
+    launch_dots4_scalars(P, h->sys_partial.p, h->sys_cached.p, rhs_tau, rhs_kappa, var_tau, var_kappa, h->sys_out.p, st);
     // (dx, dz) = (x1, z1) + dtau (x2, z2)                                 (:200-203)
-    launch_sys_axpby(d_lhs_x, h->sx1.p, nullptr, h->sx2.p, h->sys_out.p, 0.0, n, st);
-    launch_sys_axpby(d_lhs_z, h->sz1.p, nullptr, h->sz2.p, h->sys_out.p, 0.0, m, st);
+    launch_sys_step(d_lhs_x, d_lhs_z, h->sx1.p, h->sz1.p, h->sx2.p, h->sz2.p, h->sys_out.p, n, m, st);
     // ds = -(Hs dz + const)                                               (:206-212)
-    launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st);
-    launch_neg_sum(d_lhs_s, d_lhs_s, h->sconic.p, m, st);
-    HIP_CHECK(hipMemcpyAsync(lhs_tau_kappa, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));            // also keeps sc_in alive for its copy
+    launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st, h->sconic.p);
+    // (dtau, dkappa) through the handle's pinned block: a copy into pageable memory would be staged
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 48, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    lhs_tau_kappa[0] = h->pin->h[48];
+    lhs_tau_kappa[1] = h->pin->h[49];
 }
 // the x2-only terms of tau_den (kktsystem.jl:194-196) are the same for both solves of the iteration
 static void sys_cache_constant_terms(hipkkt_kkt_t h)
@@ -2821,30 +2874,65 @@ static void sys_cache_constant_terms(hipkkt_kkt_t h)
     launch_dots(P, h->sys_partial.p, h->sys_cached.p, h->stream);
 }
 
+// kkt_solve! (kktsystem.jl:145-215).  With the constant-RHS solve of the preceding kkt_update! still due (lazy mode)
+// an affine step sends both right-hand sides through the sweeps together.
+static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,
+                          const double* d_rhs_x, const double* d_rhs_s, const double* d_rhs_z, double rhs_tau,
+                          double rhs_kappa, const double* d_var_x, const double* d_var_s, const double* d_var_z,
+                          double var_tau, double var_kappa, int steptype)
+{
+    if (!h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
+    const int n = h->K.n, m = h->K.m;
+    const bool affine = steptype == 0;
+    // (the affine step does not read rhs.s: kktsystem.jl:157-158)
+    if ((n && (!d_lhs_x || !d_rhs_x || !d_var_x)) || (m && (!d_lhs_s || !d_lhs_z || !d_rhs_z || !d_var_s || !d_var_z)) ||
+        (m && !affine && !d_rhs_s) || !lhs_tau_kappa || (steptype != 0 && steptype != 1))
+        throw ArgError("hipkkt_kkt_system_solve: bad argument");
+    if (!h->scaling_valid) throw ArgError("hipkkt_kkt_system_solve: needs the cone scaling of hipkkt_kkt_system_update");
+    if (h->deferred) throw ArgError("hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)");
+    HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const bool pair = h->sys_const_pending && affine && h->eng->supports_nr(2);
+    if (h->sys_const_pending && !pair) {
+        // (x2, z2) is due and cannot ride with this solve: by itself first, as kkt_update! would have done it
+        h->sys_const_pending = false;
+        int rc = sys_constant_rhs(h);
+        if (rc != HIPKKT_OK) return rc;
+    }
+    // Delta_s constant term and the z part of the right-hand side (kktsystem.jl:150-166)
+    if (!launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, affine ? d_var_s : d_rhs_s,
+                           d_var_z, d_rhs_z, m, affine, st))
+        throw ArgError("hipkkt_kkt_system_solve: unsupported cone kind");
+    if (pair) {
+        // _kkt_solve_constant_rhs! (:80-92) and this solve (:170-173) as ONE 2-column solve: column 0 = (-q, b),
+        // column 1 = (rhs.x, s - rhs.z); each column is refined by the reference's rule on its own
+        h->sys_const_pending = false;
+        const size_t N = (size_t)h->K.N;
+        launch_pack_rhs(h->b.p, h->snegq.p, h->sb.p, n, m, h->K.p, st);
+        launch_pack_rhs(h->b.p + N, d_rhs_x, h->sworkz.p, n, m, h->K.p, st);
+        int rc = kkt_solve_core(h, false, 2, nullptr);
+        if (rc != HIPKKT_OK) return rc;
+        launch_unpack_lhs(h->sx2.p, h->sz2.p, h->x.p, n, m, st);
+        launch_unpack_lhs(h->sx1.p, h->sz1.p, h->x.p + N, n, m, st);
+        sys_cache_constant_terms(h);
+    } else {
+        // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
+        int rc = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
+        if (rc != HIPKKT_OK) return rc;
+    }
+    sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
+    return HIPKKT_OK;
+}
+
 int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,
                             const double* d_rhs_x, const double* d_rhs_s, const double* d_rhs_z, double rhs_tau,
                             double rhs_kappa, const double* d_var_x, const double* d_var_s, const double* d_var_z,
                             double var_tau, double var_kappa, int steptype)
 {
     return guarded([&]() {
-        if (!h || !h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
-        const int n = h->K.n, m = h->K.m;
-        if ((n && (!d_lhs_x || !d_rhs_x || !d_var_x)) || (m && (!d_lhs_s || !d_lhs_z || !d_rhs_s || !d_rhs_z || !d_var_s || !d_var_z)) ||
-            !lhs_tau_kappa || (steptype != 0 && steptype != 1))
-            throw ArgError("hipkkt_kkt_system_solve: bad argument");
-        if (!h->scaling_valid) throw ArgError("hipkkt_kkt_system_solve: needs the cone scaling of hipkkt_kkt_system_update");
-        HIP_CHECK(hipSetDevice(h->device));
-        hipStream_t st = h->stream;
-        // Delta_s constant term and the z part of the right-hand side (kktsystem.jl:150-166)
-        const bool affine = steptype == 0;
-        if (!launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, affine ? d_var_s : d_rhs_s,
-                               d_var_z, d_rhs_z, m, affine, st))
-            throw ArgError("hipkkt_kkt_system_solve: unsupported cone kind");
-        // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
-        int rc = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
-        if (rc != HIPKKT_OK) return rc;
-        sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
-        return HIPKKT_OK;
+        if (!h) throw ArgError("null handle");
+        return sys_solve_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, d_rhs_x, d_rhs_s, d_rhs_z, rhs_tau, rhs_kappa,
+                              d_var_x, d_var_s, d_var_z, var_tau, var_kappa, steptype);
     });
 }
 
@@ -2853,39 +2941,129 @@ int hipkkt_kkt_system_update_and_solve_affine(hipkkt_kkt_t h, double* d_lhs_x, d
                                               double rhs_tau, double rhs_kappa, const double* d_var_x, const double* d_var_s,
                                               const double* d_var_z, double var_tau, double var_kappa)
 {
-    // kkt_update! (kktsystem.jl:62-78): scaling, refactor ...
-    int rc = hipkkt_kkt_update_from_sz_dev(h, d_var_s, d_var_z);
+    // kkt_update! in lazy mode followed by the affine kkt_solve!: exactly what the two separate calls do
+    if (!h) { g_last_error = "null handle"; return HIPKKT_ERR_ARG; }
+    const bool was_lazy = h->sys_lazy;
+    h->sys_lazy = true;
+    int rc = hipkkt_kkt_system_update(h, d_var_s, d_var_z);
+    h->sys_lazy = was_lazy;
     if (rc != HIPKKT_OK) return rc;
     return guarded([&]() {
-        if (!h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
-        const int n = h->K.n, m = h->K.m;
-        if ((n && (!d_lhs_x || !d_rhs_x || !d_var_x)) || (m && (!d_lhs_s || !d_lhs_z || !d_rhs_z)) || !lhs_tau_kappa)
-            throw ArgError("hipkkt_kkt_system_update_and_solve_affine: bad argument");
-        if (h->deferred) throw ArgError("hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)");
+        return sys_solve_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, d_rhs_x, nullptr, d_rhs_z, rhs_tau, rhs_kappa,
+                              d_var_x, d_var_s, d_var_z, var_tau, var_kappa, 0);
+    });
+}
+
+// kkt_update! from the caller's cone objects (the Julia glue): kktsolver_update!'s data plus the NT scaling that
+// kkt_solve!'s right-hand-side construction and step recovery read from the same cones
+int hipkkt_kkt_system_update_cones(hipkkt_kkt_t h, const double* Hs, const double* soc_u, const double* soc_v,
+                                   const double* soc_eta2, const double* w, const double* eta, const double* lambda,
+                                   const double* psd_R, const double* psd_Rinv)
+{
+    if (h && h->deferred) {
+        g_last_error = "hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)";
+        return HIPKKT_ERR_ARG;
+    }
+    int rc = hipkkt_kkt_update_cones(h, Hs, soc_u, soc_v, soc_eta2);
+    if (rc != HIPKKT_OK) return rc;
+    return guarded([&]() {
+        const size_t m = (size_t)h->K.m, nc = h->K.cones.size();
+        if ((m && (!w || !lambda)) || (h->nsoc > 0 && !eta) || (h->npsd > 0 && (!psd_R || !psd_Rinv)))
+            throw ArgError("hipkkt_kkt_system_update_cones: missing scaling data");
+        if (h->psd_too_big) throw ArgError("hipkkt_kkt_system_*: PSD cones with side > 48 are not covered by level C");
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
-        if (!h->eng->supports_nr(2)) {
-            // one right-hand side per sweep on this structure: the two calls one after the other
-            int rc2 = sys_constant_rhs(h);
-            if (rc2 != HIPKKT_OK) return rc2;
-            launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, d_var_s, d_var_z, d_rhs_z, m, true, st);
-            rc2 = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
-            if (rc2 != HIPKKT_OK) return rc2;
-            sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
-            return HIPKKT_OK;
+        if (m) {
+            HIP_CHECK(hipMemcpyAsync(h->w.p, w, m * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(h->lam.p, lambda, m * sizeof(double), hipMemcpyHostToDevice, st));
         }
-        // ... then _kkt_solve_constant_rhs! (:80-92) and the affine kkt_solve! (:145-173) as ONE 2-column solve:
-        // column 0 = (-q, b), column 1 = (rhs.x, s - rhs.z) (the affine step's Delta_s constant term is variables.s, :157-158)
-        launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, d_var_s, d_var_z, d_rhs_z, m, true, st);
-        const size_t N = (size_t)h->K.N;
-        launch_pack_rhs(h->b.p, h->snegq.p, h->sb.p, n, m, h->K.p, st);
-        launch_pack_rhs(h->b.p + N, d_rhs_x, h->sworkz.p, n, m, h->K.p, st);
-        int rc2 = kkt_solve_core(h, false, 2, nullptr);
-        if (rc2 != HIPKKT_OK) return rc2;
-        launch_unpack_lhs(h->sx2.p, h->sz2.p, h->x.p, n, m, st);
-        launch_unpack_lhs(h->sx1.p, h->sz1.p, h->x.p + N, n, m, st);
-        sys_cache_constant_terms(h);
-        sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
+        if (eta && nc) HIP_CHECK(hipMemcpyAsync(h->eta.p, eta, nc * sizeof(double), hipMemcpyHostToDevice, st));
+        if (h->npsd > 0) {
+            HIP_CHECK(hipMemcpyAsync(h->psdR.p, psd_R, h->psdR.n * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(h->psdRinv.p, psd_Rinv, h->psdRinv.n * sizeof(double), hipMemcpyHostToDevice, st));
+            launch_psd_A_from_R(h->cone_dev(), h->cone_state(), st);       // A = R R' (mul_Hs!, coneops_psdtrianglecone.jl:164-187)
+        }
+        HIP_CHECK(hipStreamSynchronize(st));           // the caller's arrays may go away
+        h->scaling_valid = true;
+        return sys_after_update(h);
+    });
+}
+
+// ---- host-vector variants: the iterate, right-hand side and step live in host memory (DefaultVariables)
+static double* sys_host_stage(hipkkt_kkt_t h)
+{
+    const size_t len = (size_t)h->K.n + 2 * (size_t)h->K.m;
+    if (h->hst.n < 3 * len) h->hst.alloc(3 * len);
+    return h->hst.p;
+}
+
+int hipkkt_kkt_system_update_host(hipkkt_kkt_t h, const double* s, const double* z)
+{
+    int rc = guarded([&]() {
+        if (!h || (h->K.m && (!s || !z))) throw ArgError("hipkkt_kkt_system_update_host: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        const size_t bytes = (size_t)h->K.m * sizeof(double);
+        if (bytes) {
+            HIP_CHECK(hipMemcpyAsync(h->sbuf.p, s, bytes, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(h->zbuf.p, z, bytes, hipMemcpyHostToDevice, h->stream));
+        }
+        return HIPKKT_OK;
+    });
+    if (rc != HIPKKT_OK) return rc;
+    return hipkkt_kkt_system_update(h, h->sbuf.p, h->zbuf.p);
+}
+
+int hipkkt_kkt_system_solve_initial_point_host(hipkkt_kkt_t h, double* x, double* s, double* z)
+{
+    if (!h) { g_last_error = "null handle"; return HIPKKT_ERR_ARG; }
+    const size_t n = (size_t)h->K.n, m = (size_t)h->K.m;
+    double* d = nullptr;
+    int rc = guarded([&]() {
+        if ((n && !x) || (m && (!s || !z))) throw ArgError("hipkkt_kkt_system_solve_initial_point_host: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        d = sys_host_stage(h);
+        return HIPKKT_OK;
+    });
+    if (rc != HIPKKT_OK) return rc;
+    rc = hipkkt_kkt_system_solve_initial_point(h, d, d + n, d + n + m);
+    if (rc != HIPKKT_OK) return rc;
+    return guarded([&]() {
+        if (n) HIP_CHECK(hipMemcpyAsync(x, d, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(s, d + n, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (m) HIP_CHECK(hipMemcpyAsync(z, d + n + m, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
+int hipkkt_kkt_system_solve_host(hipkkt_kkt_t h, double* lhs_x, double* lhs_s, double* lhs_z, double* lhs_tau_kappa,
+                                 const double* rhs_x, const double* rhs_s, const double* rhs_z, double rhs_tau,
+                                 double rhs_kappa, const double* var_x, const double* var_s, const double* var_z,
+                                 double var_tau, double var_kappa, int steptype)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        const size_t n = (size_t)h->K.n, m = (size_t)h->K.m, len = n + 2 * m;
+        const bool affine = steptype == 0;
+        if ((n && (!lhs_x || !rhs_x || !var_x)) || (m && (!lhs_s || !lhs_z || !rhs_z || !var_s || !var_z)) ||
+            (m && !affine && !rhs_s) || !lhs_tau_kappa)
+            throw ArgError("hipkkt_kkt_system_solve_host: bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        double* d = sys_host_stage(h);
+        double *dr = d, *dv = d + len, *dl = d + 2 * len;
+        hipStream_t st = h->stream;
+        auto up = [&](double* dst, const double* src, size_t k) {
+            if (k && src) HIP_CHECK(hipMemcpyAsync(dst, src, k * sizeof(double), hipMemcpyHostToDevice, st));
+        };
+        up(dr, rhs_x, n); up(dr + n, affine ? nullptr : rhs_s, m); up(dr + n + m, rhs_z, m);
+        up(dv, var_x, n); up(dv + n, var_s, m); up(dv + n + m, var_z, m);
+        int rc = sys_solve_step(h, dl, dl + n, dl + n + m, lhs_tau_kappa, dr, dr + n, dr + n + m, rhs_tau, rhs_kappa,
+                                dv, dv + n, dv + n + m, var_tau, var_kappa, steptype);
+        if (rc != HIPKKT_OK) return rc;
+        if (n) HIP_CHECK(hipMemcpyAsync(lhs_x, dl, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (m) HIP_CHECK(hipMemcpyAsync(lhs_s, dl + n, m * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (m) HIP_CHECK(hipMemcpyAsync(lhs_z, dl + n + m, m * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
         return HIPKKT_OK;
     });
 }
@@ -3090,6 +3268,19 @@ int hipkkt_kkt_get_scaling(hipkkt_kkt_t h, double* lambda, double* psd_R, double
     });
 }
 
+int hipkkt_kkt_get_scaling_w(hipkkt_kkt_t h, double* w, double* eta)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        if (!h->scaling_valid) throw ArgError("hipkkt_kkt_get_scaling_w needs a device-side scaling (hipkkt_kkt_update_from_sz)");
+        HIP_CHECK(hipSetDevice(h->device));
+        if (w && h->K.m) HIP_CHECK(hipMemcpyAsync(w, h->w.p, (size_t)h->K.m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (eta && h->eta.n) HIP_CHECK(hipMemcpyAsync(eta, h->eta.p, h->eta.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return HIPKKT_OK;
+    });
+}
+
 double hipkkt_kkt_last_regularizer(hipkkt_kkt_t h) { return h ? h->last_eps : 0.0; }
 int64_t hipkkt_kkt_last_ir_iterations(hipkkt_kkt_t h) { return h ? h->last_ir : 0; }
 
@@ -3143,6 +3334,8 @@ int hipkkt_kkt_profile_get(hipkkt_kkt_t h, hipkkt_profile* out)
         if (!h || !out) throw ArgError("hipkkt_kkt_profile_get: bad argument");
         h->prof.resolve();
         *out = h->prof.acc;
+        out->overlap_fallbacks = h->eng->n_ov_fallbacks;
+        out->top_fallbacks = h->eng->n_top_fallbacks;
         return HIPKKT_OK;
     });
 }

@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void k_cone_psd(ConeDev C, ConeState S, const 
 
 // y = (A (x)_s A) x = svec(A X A) for PSD cones
 __global__ __launch_bounds__(256) void k_mul_Hs_psd(ConeDev C, ConeState S, double* __restrict__ y,
-                                                    const double* __restrict__ x)
+                                                    const double* __restrict__ x, const double* __restrict__ addend)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
@@ -838,7 +838,8 @@ __global__ __launch_bounds__(256) void k_mul_Hs_psd(ConeDev C, ConeState S, doub
         svec_index(idx, r, cl);
         double a1 = 0.0, a2 = 0.0;
         for (int q = 0; q < k; ++q) { a1 = fma(Am[r + q * k], Tm[q + cl * k], a1); a2 = fma(Am[cl + q * k], Tm[q + r * k], a2); }
-        y[off + idx] = (r == cl) ? a1 : (a1 + a2) * is2;
+        const double v = (r == cl) ? a1 : (a1 + a2) * is2;
+        y[off + idx] = addend ? -(v + addend[off + idx]) : v;
     }
 }
 
@@ -855,17 +856,22 @@ void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, 
     }
 }
 
-// y = W'W x : zero -> 0, NN -> w*(w*x), SOC -> eta^2 (2 w (w'x) - J x)   (mul_Hs!)
-__global__ void k_mul_Hs_elementwise(ConeDev C, ConeState S, double* __restrict__ y, const double* __restrict__ x, int m)
+// y = W'W x : zero -> 0, NN -> w*(w*x), SOC -> eta^2 (2 w (w'x) - J x)   (mul_Hs!); with an addend: y = -(W'W x + addend),
+// the Delta_s recovery of kkt_solve! (kktsystem.jl:206-212) in the same pass
+__global__ void k_mul_Hs_elementwise(ConeDev C, ConeState S, double* __restrict__ y, const double* __restrict__ x, int m,
+                                     const double* __restrict__ addend)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const int kind = C.kind[C.elem_cone[i]];
-        if (kind == 0) y[i] = 0.0;
-        else if (kind == 1) y[i] = S.w[i] * (S.w[i] * x[i]);
+        double v;
+        if (kind == 0) v = 0.0;
+        else if (kind == 1) v = S.w[i] * (S.w[i] * x[i]);
+        else continue;
+        y[i] = addend ? -(v + addend[i]) : v;
     }
 }
 __global__ __launch_bounds__(64) void k_mul_Hs_soc(ConeDev C, ConeState S, double* __restrict__ y,
-                                                   const double* __restrict__ x)
+                                                   const double* __restrict__ x, const double* __restrict__ addend)
 {
     const int c = C.soc_list[blockIdx.x];
     const int off = C.off[c], n = C.numel[c], lane = threadIdx.x;
@@ -876,16 +882,35 @@ __global__ __launch_bounds__(64) void k_mul_Hs_soc(ConeDev C, ConeState S, doubl
     const double e2 = S.eta[c] * S.eta[c];
     for (int i = lane; i < n; i += 64) {
         const double xi = x[off + i];
-        y[off + i] = ((i == 0 ? -xi : xi) + dot * w[i]) * e2;
+        const double v = ((i == 0 ? -xi : xi) + dot * w[i]) * e2;
+        y[off + i] = addend ? -(v + addend[off + i]) : v;
     }
 }
-void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st)
+// A = R R' per PSD cone, from a caller-supplied R (hipkkt_kkt_system_update_cones); one workgroup per cone
+__global__ __launch_bounds__(256) void k_psd_A_from_R(ConeDev C, ConeState S)
 {
-    if (m > 0) hipLaunchKernelGGL(k_mul_Hs_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, y, x, m);
-    if (C.nsoc > 0) hipLaunchKernelGGL(k_mul_Hs_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, y, x);
+    const int c = C.psd_list[blockIdx.x];
+    const int k = C.psd_dim[c];
+    const double* R = S.psdR + C.psd_aoff[c];
+    double* A = S.psdA + C.psd_aoff[c];
+    for (int idx = threadIdx.x; idx < k * k; idx += 256) {
+        const int r = idx % k, cl = idx / k;
+        double acc = 0.0;
+        for (int q = 0; q < k; ++q) acc = fma(R[r + q * k], R[cl + q * k], acc);
+        A[idx] = acc;
+    }
+}
+void launch_psd_A_from_R(const ConeDev& C, const ConeState& S, hipStream_t st)
+{
+    if (C.npsd > 0) hipLaunchKernelGGL(k_psd_A_from_R, dim3(C.npsd), dim3(256), 0, st, C, S);
+}
+void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend)
+{
+    if (m > 0) hipLaunchKernelGGL(k_mul_Hs_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, y, x, m, addend);
+    if (C.nsoc > 0) hipLaunchKernelGGL(k_mul_Hs_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, y, x, addend);
     if (C.npsd > 0) {
         const size_t lds = (size_t)3 * C.psd_kmax * C.psd_kmax * sizeof(double);
-        hipLaunchKernelGGL(k_mul_Hs_psd, dim3(C.npsd), dim3(256), lds, st, C, S, y, x);
+        hipLaunchKernelGGL(k_mul_Hs_psd, dim3(C.npsd), dim3(256), lds, st, C, S, y, x, addend);
     }
 }
 
@@ -1037,6 +1062,42 @@ void launch_P_spmv(const SpmvDev& A, const double* Kval, const double* x, double
     hipLaunchKernelGGL(k_P_spmv, dim3(g), dim3(256), 0, st, A, Kval, x, y, n);
 }
 
+// pa = P x1 and pb = P xm with xm = x / tau - x2 formed on the fly (and stored to xm_out by the row that owns it):
+// the two quad_form products of kkt_solve! (kktsystem.jl:185-196) in one pass over P's rows
+__global__ __launch_bounds__(256) void k_P_spmv2(SpmvDev A, const double* __restrict__ K, const double* __restrict__ x1,
+                                                 const double* __restrict__ x, const double* __restrict__ x2, double tau,
+                                                 double* __restrict__ pa, double* __restrict__ pb,
+                                                 double* __restrict__ xm_out, int n)
+{
+    const int sub = threadIdx.x & 7;
+    for (int row = blockIdx.x * 32 + (threadIdx.x >> 3); row < n; row += gridDim.x * 32) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int64_t q = A.ptr[row] + sub; q < A.ptr[row + 1]; q += 8) {
+            const int c = A.col[q];
+            if (c < n) {
+                const double v = A.val ? A.val[q] : K[A.vmap[q]];
+                a1 = fma(v, x1[c], a1);
+                a2 = fma(v, x[c] / tau - x2[c], a2);
+            }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 8); a2 += __shfl_down(a2, o, 8); }
+        if (sub == 0) {
+            pa[row] = a1;
+            pb[row] = a2;
+            xm_out[row] = x[row] / tau - x2[row];
+        }
+    }
+}
+void launch_P_spmv2(const SpmvDev& A, const double* Kval, const double* x1, const double* x, const double* x2, double tau,
+                    double* pa, double* pb, double* xm_out, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    int g = (n + 31) / 32;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_P_spmv2, dim3(g), dim3(256), 0, st, A, Kval, x1, x, x2, tau, pa, pb, xm_out, n);
+}
+
 __global__ void k_sys_axpby(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ alpha,
                             const double* __restrict__ b, const double* __restrict__ beta, double beta_host, int n)
 {
@@ -1108,6 +1169,53 @@ __global__ void k_sys_scalars(const double* __restrict__ dots, const double* __r
 void launch_sys_scalars(const double* dots, const double* cached, const double* scal_in, double* out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_sys_scalars, dim3(1), dim3(64), 0, st, dots, cached, scal_in, out);
+}
+// the second stage of the four dot products and the scalars of kkt_solve! in one single-workgroup kernel; the
+// caller's scalars come by value (a 32-byte copy from pageable host memory would drain the stream first)
+__global__ __launch_bounds__(64) void k_dots_finish_scalars(const double* __restrict__ partial, const double* __restrict__ cached,
+                                                            double rhs_tau, double rhs_kappa, double tau, double kappa,
+                                                            double* __restrict__ out)
+{
+    __shared__ double d[4];
+    const int p = threadIdx.x;
+    if (p < 4) {
+        double acc = 0.0;
+        for (int i = 0; i < kDotBlocks; ++i) acc += partial[p * kDotBlocks + i];      // (the order of k_dots_finish)
+        d[p] = acc;
+    }
+    __syncthreads();
+    if (p != 0) return;
+    const double tau_num = rhs_tau - rhs_kappa / tau + d[0] + d[1] + 2.0 * (d[2] / tau);
+    double tau_den = kappa / tau - cached[0] - cached[1];
+    tau_den += d[3] - cached[2];
+    const double dtau = tau_num / tau_den;
+    out[0] = dtau;
+    out[1] = -(rhs_kappa + kappa * dtau) / tau;
+    out[2] = tau_num;
+    out[3] = tau_den;
+}
+void launch_dots4_scalars(const DotPairs& P, double* partial, const double* cached, double rhs_tau, double rhs_kappa, double tau,
+                          double kappa, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dots, dim3(kDotBlocks, 4), dim3(256), 0, st, P, partial);
+    hipLaunchKernelGGL(k_dots_finish_scalars, dim3(1), dim3(64), 0, st, partial, cached, rhs_tau, rhs_kappa, tau, kappa, out);
+}
+// (dx, dz) = (x1, z1) + dtau (x2, z2) in one launch (kktsystem.jl:200-203); dtau = scal[0] on the device
+__global__ void k_sys_step(double* __restrict__ dx, double* __restrict__ dz, const double* __restrict__ x1,
+                           const double* __restrict__ z1, const double* __restrict__ x2, const double* __restrict__ z2,
+                           const double* __restrict__ scal, int n, int m)
+{
+    const double dtau = scal[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x) {
+        if (i < n) dx[i] = x1[i] + dtau * x2[i];
+        else dz[i - n] = z1[i - n] + dtau * z2[i - n];
+    }
+}
+void launch_sys_step(double* dx, double* dz, const double* x1, const double* z1, const double* x2, const double* z2,
+                     const double* scal, int n, int m, hipStream_t st)
+{
+    if (n + m <= 0) return;
+    hipLaunchKernelGGL(k_sys_step, dim3(grid_for(n + m, 256)), dim3(256), 0, st, dx, dz, x1, z1, x2, z2, scal, n, m);
 }
 
 __global__ void k_neg_sum(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int n)

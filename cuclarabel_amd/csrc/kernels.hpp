@@ -353,7 +353,9 @@ struct ConeState {
 constexpr int kPsdMaxDim = 48;   // largest PSD side handled by the in-LDS scaling kernel
 void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, const double* z, int m,
                          hipStream_t st);
-void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st);
+// addend != null: y = -(W'W x + addend) (the Delta_s recovery of kkt_solve!, kktsystem.jl:206-212)
+void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend = nullptr);
+void launch_psd_A_from_R(const ConeDev& C, const ConeState& S, hipStream_t st);    // psdA = psdR psdR' per PSD cone
 
 // ---- the reduced-system algebra around the three solves of an IPM iteration (kktsystem.jl:135-215), device-resident
 // konst = Delta_s_from_Delta_z_offset!(cones, ds, z) (coneops_compositecone.jl:185-202; zero :137-150, nonnegative
@@ -374,6 +376,13 @@ void launch_dots(const DotPairs& P, double* partial, double* out, hipStream_t st
 // scal_in = {rhs_tau, rhs_kappa, var_tau, var_kappa}; out = {dtau, dkappa, tau_num, tau_den}
 void launch_sys_scalars(const double* dots, const double* cached, const double* scal_in, double* out, hipStream_t st);
 void launch_neg_sum(double* y, const double* a, const double* b, int n, hipStream_t st);      // y = -(a + b)
+// fused forms of the above for kkt_solve!'s step recovery (fewer dependent launches, scalars by value)
+void launch_P_spmv2(const SpmvDev& A, const double* Kval, const double* x1, const double* x, const double* x2, double tau,
+                    double* pa, double* pb, double* xm_out, int n, hipStream_t st);
+void launch_dots4_scalars(const DotPairs& P, double* partial, const double* cached, double rhs_tau, double rhs_kappa, double tau,
+                          double kappa, double* out, hipStream_t st);
+void launch_sys_step(double* dx, double* dz, const double* x1, const double* z1, const double* x2, const double* z2,
+                     const double* scal, int n, int m, hipStream_t st);
 void launch_neg_copy(double* y, const double* a, int n, hipStream_t st);                    // y = -a
 
 

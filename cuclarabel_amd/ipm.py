@@ -101,6 +101,9 @@ class _Zero(_Cone):
     def mul_Hs(self, x):
         return np.zeros(self.n)
 
+    def get_Hs(self):                                    # coneops_zerocone.jl get_Hs!: zeros
+        return np.zeros(self.n)
+
     def step_length(self, dz, ds, z, s, amax):
         return amax
 
@@ -133,6 +136,9 @@ class _NN(_Cone):
 
     def mul_Hs(self, x):
         return self.w * (self.w * x)
+
+    def get_Hs(self):                                    # coneops_nncone.jl get_Hs!: w.^2
+        return self.w ** 2
 
     def step_length(self, dz, ds, z, s, amax):
         a = amax
@@ -230,6 +236,35 @@ class _SOC(_Cone):
         y = x.copy()
         y[0] = -x[0]
         return (y + c * self.w) * self.eta ** 2
+
+    @property
+    def sparse(self):                                    # SOC_NO_EXPANSION_MAX_SIZE = 4 (cone_types.jl)
+        return self.n > 4
+
+    def sparse_data(self):                               # coneops_socone.jl:126-150: (u, v, d) of the rank-2 form of W'W
+        w = self.w
+        wsq = w[0] * w[0] + w[1:] @ w[1:]
+        wsqinv = 1.0 / wsq
+        d = wsqinv / 2
+        u0 = np.sqrt(wsq - d)
+        u1 = 2 * w[0] / u0
+        v1 = np.sqrt(2 * (2 + wsqinv) / (2 * wsq - wsqinv))
+        u, v = u1 * w, v1 * w
+        u[0], v[0] = u0, 0.0
+        return u, v, d
+
+    def get_Hs(self):                                    # coneops_socone.jl:154-186
+        e2 = self.eta ** 2
+        if self.sparse:
+            out = np.full(self.n, e2)
+            out[0] *= self.sparse_data()[2]
+            return out
+        w = self.w
+        blk = [(np.sqrt(2.0) * w[0] - 1.0) * (np.sqrt(2.0) * w[0] + 1.0)]
+        for col in range(1, self.n):
+            for row in range(col + 1):
+                blk.append(2 * w[row] * w[col] + (1.0 if row == col else 0.0))
+        return np.array(blk) * e2
 
     @staticmethod
     def _step(x, y, amax):                               # :443-512
@@ -339,6 +374,15 @@ class _PSD(_Cone):
     def mul_Hs(self, x):                                 # :164-187
         return self._Wt(self._W(x))
 
+    def get_Hs(self):                                    # :146-162: packed upper triangle of (R R') (x)_s (R R')
+        t = self.n
+        M = np.empty((t, t))
+        for e in range(t):
+            unit = np.zeros(t)
+            unit[e] = 1.0
+            M[:, e] = self.mul_Hs(unit)
+        return np.concatenate([M[:col + 1, col] for col in range(t)]) if t else np.zeros(0)
+
     def _step_component(self, d, amax):                  # :439-466
         if self.n == 0:
             return amax
@@ -357,6 +401,30 @@ def adopt_device_scaling(cones, dev_scaling):
     for c in cones:
         if isinstance(c, _PSD):
             c.R, c.Rinv, c.lam = next(it)
+
+
+def host_cone_data(cones):
+    """What the Julia glue reads from the reference's cone objects for kkt_update! (hipkkt_kkt_system_update_cones):
+    get_Hs! blocks, the sparse second-order cones' (u, v, eta^2), and the NT scaling w (m), eta (per cone), lambda (m),
+    R / Rinv of the PSD cones (column-major, concatenated).  After update_scaling on every cone."""
+    m = cones[-1].off + cones[-1].n if cones else 0
+    Hs, u, v, e2, R, Ri = [], [], [], [], [], []
+    w, lam, eta = np.ones(m), np.zeros(m), np.ones(len(cones))
+    for i, c in enumerate(cones):
+        Hs.append(c.get_Hs())
+        if isinstance(c, (_NN, _SOC)):
+            w[c.rng] = c.w
+            lam[c.rng] = c.lam
+        if isinstance(c, _SOC):
+            eta[i] = c.eta
+            if c.sparse:
+                uu, vv, _ = c.sparse_data()
+                u.append(uu); v.append(vv); e2.append(c.eta ** 2)
+        if isinstance(c, _PSD) and c.n:
+            lam[c.off:c.off + c.k] = c.lam
+            R.append(np.asarray(c.R).ravel(order="F")); Ri.append(np.asarray(c.Rinv).ravel(order="F"))
+    cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0)
+    return cat(Hs), cat(u), cat(v), np.array(e2), w, eta, lam, cat(R), cat(Ri)
 
 
 def _make_cones(specs):
@@ -565,6 +633,9 @@ def solve(P, q, A, b, cone_specs, backend, settings=None):
             ir_total += backend.last_ir_iterations
             if ok and any(isinstance(c, _PSD) and c.n for c in cones):
                 adopt_device_scaling(cones, backend.ks.scaling()[1])
+        elif system is not None and getattr(backend, "host_cones", False):
+            # kkt_update!(kktsystem, data, cones) as the Julia glue issues it: everything from the caller's cone objects
+            ok = system.update_cones(*host_cone_data(cones))
         elif system is not None:
             ok = system.update(s, z)                   # kkt_update!: scaling, refactor, constant-RHS solve
             # The scaled space of a PSD cone is fixed only up to the signs of the singular vectors of L2'L1.  With the
@@ -702,8 +773,14 @@ class HipSystemBackend(HipBackend):
     """As HipBackend, but the reduced-system layer (kktsystem.jl) runs on the device too (level C of the
     C ABI): the driver hands over iterates and right-hand sides and gets the step back."""
 
-    def __init__(self, P, A, cone_specs, settings=None, batch_affine=False):
+    def __init__(self, P, A, cone_specs, settings=None, batch_affine=False, lazy=False, host_cones=False, staging="host"):
         super().__init__(P, A, cone_specs, settings=settings)
         from .kktsolver import HipKKTSystem
         self.system = HipKKTSystem(self.ks)
-        self.batch_affine = batch_affine           # kkt_update! + affine kkt_solve! as one 2-column solve
+        self.system.staging = staging              # "host": the *_host entry points; "torch": device tensors + *_dev
+        self.batch_affine = batch_affine           # kkt_update! + affine kkt_solve! as one 2-column solve, ONE call
+        self.host_cones = host_cones               # kkt_update! from the driver's own cone objects (the Julia glue's route)
+        if lazy:
+            # the same pairing through the reference's TWO calls (solver.jl:278-295 untouched): kkt_update! leaves the
+            # constant-RHS solve to the affine kkt_solve!, which sends both right-hand sides through the sweeps together
+            self.system.set_lazy(True)

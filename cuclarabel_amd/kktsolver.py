@@ -218,6 +218,18 @@ class HipKKTSolver:
             off += c.numel
         return lam[:self.m], out
 
+    def scaling_w(self):
+        """(w (m), eta (per cone)) of the device's NT scaling."""
+        w, eta = np.zeros(max(self.m, 1)), np.zeros(max(len(self.cones), 1))
+        check(_lib.lib().hipkkt_kkt_get_scaling_w(self._h, ptr(w), ptr(eta)), "hipkkt_kkt_get_scaling_w")
+        return w[:self.m], eta[:len(self.cones)]
+
+    @property
+    def fallbacks(self):
+        """(overlap-mode, persistent-sweep-kernel) fallbacks taken by this handle so far; expected (0, 0)."""
+        p = self.profile()
+        return int(p["overlap_fallbacks"]), int(p["top_fallbacks"])
+
     @property
     def diagonal_regularizer(self):
         return _lib.lib().hipkkt_kkt_last_regularizer(self._h)
@@ -284,7 +296,31 @@ class HipKKTSystem:
             0 if affine else 1), "hipkkt_kkt_system_solve")
         return ok, tk[0], tk[1]
 
-    # ---- numpy interface (stages through device tensors)
+    # ---- lazy constant-RHS solve (hipkkt_kkt_system_set_lazy): kkt_update! + kkt_solve!(:affine) as two SEPARATE calls
+    #      whose two solves still share one 2-column sweep
+    def set_lazy(self, on=True):
+        return check(_lib.lib().hipkkt_kkt_system_set_lazy(self.ks._h, int(on)), "hipkkt_kkt_system_set_lazy")
+
+    def update_cones(self, Hsblocks, soc_u, soc_v, soc_eta2, w, eta, lam, psd_R=None, psd_Rinv=None):
+        """kkt_update!(kktsystem, data, cones) from the CALLER's cone objects (what the Julia glue has): the data of
+        kktsolver_update! plus the NT scaling (w, eta per cone, lambda, and R / Rinv of the PSD cones concatenated
+        column-major) that kkt_solve!'s right-hand sides and step recovery use."""
+        a = [f64(v if v is not None else []) for v in (Hsblocks, soc_u, soc_v, soc_eta2, w, eta, lam, psd_R, psd_Rinv)]
+        i = self.ks.info
+        if a[0].size != i["nHs"] or a[1].size != i["sparse_soc_len"] or a[2].size != a[1].size or \
+                a[3].size != i["nsparse_soc"] or a[4].size != self.ks.m or a[6].size != self.ks.m or \
+                a[5].size != len(self.ks.cones):
+            raise ValueError("cone data has the wrong length")
+        tot = sum(c.dim * c.dim for c in self.ks.cones if c.kind == 3)
+        if a[7].size != tot or a[8].size != tot:
+            raise ValueError("psd_R / psd_Rinv have the wrong length")
+        return check(_lib.lib().hipkkt_kkt_system_update_cones(self.ks._h, *[ptr(v) for v in a]),
+                     "hipkkt_kkt_system_update_cones")
+
+    # ---- numpy interface.  staging = "host": the *_host entry points of the C ABI (vectors staged by the library: what
+    #      a caller with host-resident DefaultVariables uses); "torch": device tensors + the device-pointer entry points
+    staging = "host"
+
     @property
     def _devstr(self):
         import torch
@@ -296,6 +332,11 @@ class HipKKTSystem:
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self._devstr)
 
     def update(self, s, z):
+        if self.staging == "host":
+            s, z = f64(s), f64(z)
+            if s.size != self.ks.m or z.size != self.ks.m:
+                raise ValueError("s, z must have length m")
+            return check(_lib.lib().hipkkt_kkt_system_update_host(self.ks._h, ptr(s), ptr(z)), "hipkkt_kkt_system_update_host")
         ds, dz = self._dev(s), self._dev(z)
         return self.update_dev(ds.data_ptr(), dz.data_ptr())
 
@@ -319,30 +360,46 @@ class HipKKTSystem:
         rhs = [self._dev(rhs_x), self._dev(rhs_z)]
         var = [self._dev(x), self._dev(s), self._dev(z)]
         lhs = [torch.zeros(max(k, 1), dtype=torch.float64, device=dev) for k in (n, m, m)]
-        tk = np.zeros(2)
-        ok = check(_lib.lib().hipkkt_kkt_system_update_and_solve_affine(
-            self.ks._h, C.c_void_p(lhs[0].data_ptr()), C.c_void_p(lhs[1].data_ptr()), C.c_void_p(lhs[2].data_ptr()), ptr(tk),
-            C.c_void_p(rhs[0].data_ptr()), C.c_void_p(rhs[1].data_ptr()), float(rhs_tau), float(rhs_kappa),
-            C.c_void_p(var[0].data_ptr()), C.c_void_p(var[1].data_ptr()), C.c_void_p(var[2].data_ptr()), float(tau), float(kappa)),
-            "hipkkt_kkt_system_update_and_solve_affine")
+        ok, dtau, dkappa = self.update_and_solve_affine_dev([t.data_ptr() for t in lhs], [t.data_ptr() for t in rhs],
+                                                            rhs_tau, rhs_kappa, [t.data_ptr() for t in var], tau, kappa)
         if not ok:
             return False, None
         dx, ds, dz = lhs[0][:n].cpu().numpy(), lhs[1][:m].cpu().numpy(), lhs[2][:m].cpu().numpy()
-        return True, (dx, dz, ds, float(tk[0]), float(tk[1]))
+        return True, (dx, dz, ds, dtau, dkappa)
 
     def solve_initial_point(self):
+        n, m = self.ks.n, self.ks.m
+        if self.staging == "host":
+            x, s, z = np.zeros(max(n, 1)), np.zeros(max(m, 1)), np.zeros(max(m, 1))
+            ok = check(_lib.lib().hipkkt_kkt_system_solve_initial_point_host(self.ks._h, ptr(x), ptr(s), ptr(z)),
+                       "hipkkt_kkt_system_solve_initial_point_host")
+            return ok, x[:n], s[:m], z[:m]
         import torch
         dev = self._devstr
-        x = torch.zeros(max(self.ks.n, 1), dtype=torch.float64, device=dev)
-        s = torch.zeros(max(self.ks.m, 1), dtype=torch.float64, device=dev)
-        z = torch.zeros(max(self.ks.m, 1), dtype=torch.float64, device=dev)
+        x = torch.zeros(max(n, 1), dtype=torch.float64, device=dev)
+        s = torch.zeros(max(m, 1), dtype=torch.float64, device=dev)
+        z = torch.zeros(max(m, 1), dtype=torch.float64, device=dev)
         ok = self.solve_initial_point_dev(x.data_ptr(), s.data_ptr(), z.data_ptr())
-        return ok, x[:self.ks.n].cpu().numpy(), s[:self.ks.m].cpu().numpy(), z[:self.ks.m].cpu().numpy()
+        return ok, x[:n].cpu().numpy(), s[:m].cpu().numpy(), z[:m].cpu().numpy()
 
     def solve(self, rhs_x, rhs_s, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa, affine):
+        n, m = self.ks.n, self.ks.m
+        if self.staging == "host":
+            a = [f64(v) for v in (rhs_x, rhs_s, rhs_z, x, s, z)]
+            for v, k in zip(a, (n, m, m, n, m, m)):
+                if v.size != k:
+                    raise ValueError("vector of the wrong length")
+            lhs = [np.zeros(max(k, 1)) for k in (n, m, m)]
+            tk = np.zeros(2)
+            ok = check(_lib.lib().hipkkt_kkt_system_solve_host(
+                self.ks._h, ptr(lhs[0]), ptr(lhs[1]), ptr(lhs[2]), ptr(tk), ptr(a[0]), ptr(a[1]), ptr(a[2]),
+                float(rhs_tau), float(rhs_kappa), ptr(a[3]), ptr(a[4]), ptr(a[5]), float(tau), float(kappa),
+                0 if affine else 1), "hipkkt_kkt_system_solve_host")
+            if not ok:
+                return False, None
+            return True, (lhs[0][:n], lhs[2][:m], lhs[1][:m], float(tk[0]), float(tk[1]))
         import torch
         dev = self._devstr
-        n, m = self.ks.n, self.ks.m
         rhs = [self._dev(rhs_x), self._dev(rhs_s), self._dev(rhs_z)]
         var = [self._dev(x), self._dev(s), self._dev(z)]
         lhs = [torch.zeros(max(k, 1), dtype=torch.float64, device=dev) for k in (n, m, m)]
@@ -422,3 +479,9 @@ class HipDirectLDLSolver:
         out = np.zeros(self.N, dtype=np.int64)
         check(_lib.lib().hipkkt_ldl_get_perm(self._h, ptr(out)), "hipkkt_ldl_get_perm")
         return out
+
+    @property
+    def fallbacks(self):
+        out = np.zeros(2, dtype=np.int64)
+        check(_lib.lib().hipkkt_ldl_fallbacks(self._h, ptr(out)), "hipkkt_ldl_fallbacks")
+        return int(out[0]), int(out[1])

@@ -96,6 +96,12 @@ typedef struct {
     int64_t n_update, n_factor, n_trisolve, n_residual;
     int64_t ir_iterations;     /* refinement rounds beyond the first residual check */
     int64_t dynamic_regularizations;
+    /* Fallbacks taken over the handle's LIFETIME (not cleared by hipkkt_kkt_profile_reset): a bounded wait of the
+     * factorisation's overlap mode / of the persistent top-of-tree sweep kernel expired, the mechanism was switched off
+     * for the handle and the operation repeated level by level.  The reference has nothing like it (its only report is the
+     * Bool of refactor! / solve!, directldl_qdldl.jl:79): results stay correct, but a non-zero count means a 50 ms stall
+     * happened and the handle runs on its slower path from then on.  Expected value: 0. */
+    int64_t overlap_fallbacks, top_fallbacks;
 } hipkkt_profile;
 
 /* -------------------------------------------------------------------- general */
@@ -136,6 +142,8 @@ int hipkkt_ldl_solve_multi_dev(hipkkt_ldl_t h, int64_t nrhs, double *d_X, int64_
 /* linear_solver_info (directldl_qdldl.jl:35-42) */
 int hipkkt_ldl_info(hipkkt_ldl_t h, hipkkt_info *info);
 int hipkkt_ldl_get_perm(hipkkt_ldl_t h, int64_t *perm /* N, 0-based */);
+/* out[0] = overlap-mode fallbacks, out[1] = persistent-sweep-kernel fallbacks of this handle so far (see hipkkt_profile) */
+int hipkkt_ldl_fallbacks(hipkkt_ldl_t h, int64_t out[2]);
 
 /* ---------------------------------------------- Level B: AbstractKKTSolver */
 /* constructor (kktsolver_directldl.jl:46-92): P n x n triu CSC, A m x n CSC, cone list.
@@ -168,7 +176,9 @@ int hipkkt_kkt_solve(hipkkt_kkt_t h, double *lhsx, double *lhsz);
 int hipkkt_kkt_setrhs_dev(hipkkt_kkt_t h, const double *d_rhsx, const double *d_rhsz);
 int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double *d_lhsx, double *d_lhsz);
 /* Deferred status (no counterpart in the reference, whose calls are synchronous): with defer = 1 the device-pointer
- * entry points hipkkt_kkt_update_from_sz_dev and hipkkt_kkt_solve_dev only ENQUEUE their work and return 0 at once;
+ * entry points hipkkt_kkt_update_from_sz_dev, hipkkt_kkt_solve_dev and hipkkt_kkt_solve_multi_dev with nrhs <= 8 (the
+ * columns that share the single-column sweeps; ir_iterations then receives -1 per column) only ENQUEUE their work and
+ * return 0 at once (hipkkt_kkt_solve_multi_dev with more than 8 columns always synchronises and returns its own status);
  * what they would have returned is accumulated on the device.  The refinement loop's accept / stop decisions
  * (kktsolver_directldl.jl:389-449) are taken on the device either way; in this mode a solve runs as many refinement
  * rounds ahead as the previous solves on the handle needed (at least one).  hipkkt_kkt_deferred_status synchronises,
@@ -226,6 +236,37 @@ int hipkkt_kkt_system_update_and_solve_affine(hipkkt_kkt_t h, double *d_lhs_x, d
                                               const double *d_var_x, const double *d_var_s, const double *d_var_z,
                                               double var_tau, double var_kappa);
 
+/* Lazy constant-RHS solve: the same pairing reached through the reference's own TWO calls, so that solver.jl:278-295
+ * stays as it is.  With lazy = 1, kkt_update! (hipkkt_kkt_system_update / _update_cones) scales, scatters and
+ * refactors, returns the factorisation's status and only NOTES that (x2, z2) = K \ (-q, b) is due
+ * (kktsystem.jl:71-77 would solve it at once); the next hipkkt_kkt_system_solve with steptype :affine sends both
+ * right-hand sides through the sweeps as one 2-column solve and returns the AND of the two solves' status -- which is
+ * what solver.jl:279-295 computes from the two calls (`is_kkt_solve_success = kkt_update!(...)`, then
+ * `is_kkt_solve_success && kkt_solve!(..., :affine)`), so the loop's control flow is unchanged.  Any other consumer of
+ * (x2, z2) -- a :combined solve arriving first, a structure that takes one right-hand side per sweep -- makes the
+ * pending solve run by itself first; hipkkt_kkt_system_solve_initial_point does not read (x2, z2) and leaves it
+ * pending (the next kkt_update! supersedes it: solver.jl:389-393). */
+int hipkkt_kkt_system_set_lazy(hipkkt_kkt_t h, int lazy);
+/* kkt_update!(kktsystem, data, cones) for a caller that keeps the reference's cone objects (the Julia glue: kkt_update!
+ * gets `cones`, not the iterate): the reference's data for kktsolver_update! (as hipkkt_kkt_update_cones) plus the NT
+ * scaling the step recovery of kkt_solve! reads from the same cones -- w (m: nonnegative cones sqrt(s/z), second-order
+ * cones the normalised w, coneops_nncone.jl:75-86, coneops_socone.jl:75-123), eta (one per cone; second-order cones),
+ * lambda (m; a PSD cone of side k keeps its k values in the first k of its slots), and R, Rinv of the PSD cones
+ * (k x k column-major, concatenated in cone order; coneops_psdtrianglecone.jl:127-132).  Then the constant-RHS solve,
+ * or its note in lazy mode. */
+int hipkkt_kkt_system_update_cones(hipkkt_kkt_t h, const double *Hsblocks, const double *soc_u, const double *soc_v,
+                                   const double *soc_eta2, const double *w, const double *eta, const double *lambda,
+                                   const double *psd_R, const double *psd_Rinv);
+/* The same entry points for a caller whose iterate lives in HOST memory (DefaultVariables are Vector{T},
+ * variables.jl:1-30): vectors are staged through buffers the handle owns (n + 2m doubles each way per call). */
+int hipkkt_kkt_system_update_host(hipkkt_kkt_t h, const double *s, const double *z);
+int hipkkt_kkt_system_solve_initial_point_host(hipkkt_kkt_t h, double *x, double *s, double *z);
+int hipkkt_kkt_system_solve_host(hipkkt_kkt_t h, double *lhs_x, double *lhs_s, double *lhs_z, double *lhs_tau_kappa,
+                                 const double *rhs_x, const double *rhs_s, const double *rhs_z,
+                                 double rhs_tau, double rhs_kappa,
+                                 const double *var_x, const double *var_s, const double *var_z,
+                                 double var_tau, double var_kappa, int steptype);
+
 /* ------------------------------------------- problem-data scaling (before the KKT solver is built)
  * data_equilibrate! (/root/reference/src/problemdata.jl:133-221): Ruiz equilibration of
  * [P A'; A 0], q, b on the device.  P: n x n upper-triangular CSC,
@@ -264,6 +305,8 @@ int hipkkt_kkt_get_Hs(hipkkt_kkt_t h, double *Hsblocks /* |Hs|, positive */);
  * of side k keeps its k singular values, descending, in the first k of its slots), and for the PSD cones R and Rinv
  * (coneops_psdtrianglecone.jl:127-132), k x k column-major each, concatenated in cone order.  Any may be NULL. */
 int hipkkt_kkt_get_scaling(hipkkt_kkt_t h, double *lambda, double *psd_R, double *psd_Rinv);
+/* the rest of the device's NT scaling: w (m) and eta (one per cone), as hipkkt_kkt_system_update_cones takes them */
+int hipkkt_kkt_get_scaling_w(hipkkt_kkt_t h, double *w, double *eta);
 double hipkkt_kkt_last_regularizer(hipkkt_kkt_t h);
 int64_t hipkkt_kkt_last_ir_iterations(hipkkt_kkt_t h);
 

@@ -1,8 +1,9 @@
 # HipKKTExt.jl -- Clarabel.jl-side binding of libhipkkt.so (include/hipkkt.h).
 #
-# NOT executed in the build container (Julia is not installed there: SURVEY.md F4); written
+# NOT executed in the build container (Julia is not installed there: SURVEY.md F4); the call sequences of B and C are
+# executed by their tested Python mirrors (cuclarabel_amd/ipm.py: HipBackend, HipSystemBackend(lazy=True, host_cones=True)).  Written
 # against Clarabel.jl v0.11.0 following the pattern of its own out-of-tree backends
-# (ext/directldl_hsl.jl, ext/directldl_pardiso.jl).  Two bindings:
+# (ext/directldl_hsl.jl, ext/directldl_pardiso.jl).  Three bindings:
 #
 #   A.  HipDirectLDLSolver <: AbstractDirectLDLSolver     select with
 #           Clarabel.Settings(direct_solve_method = :hipldl)
@@ -10,6 +11,10 @@
 #   B.  HipKKTSolver <: AbstractKKTSolver                  moves assembly, regularisation and
 #       iterative refinement to the device as well; needs the one-line dispatch in
 #       src/kktsystem.jl:33 shown at the bottom (that call site hard-codes DirectLDLKKTSolver).
+#   C.  HipKKTSystem <: AbstractKKTSystem                  the reduced-system layer on the device too (right-hand-side
+#       construction, the three solves per iteration, step recovery); the constant and the affine right-hand side share
+#       one 2-column solve although solver.jl still issues kkt_update! and kkt_solve!(:affine) as two calls (lazy
+#       mode); needs the one-line dispatch in src/solver.jl:139 shown at the bottom.
 #
 # Load as a package extension ([weakdeps]/[extensions] in Project.toml, as HSLExt is) or simply
 # `include` it after `using Clarabel`.  ENV["HIPKKT_LIB"] may point at libhipkkt.so.
@@ -224,6 +229,96 @@ function kktsolver_linear_solver_info(ks::HipKKTSolver{T}) where {T}
     LinearSolverInfo(:hipkkt, 1, true, info[].nnzK, info[].nnzL)
 end
 
+# ------------------------------------------------------------------ C. the reduced-system layer (level C)
+# HipKKTSystem <: AbstractKKTSystem replaces DefaultKKTSystem (src/kktsystem.jl:5-232): the three solves per iteration,
+# their right-hand-side construction and the recovery of (dx, dz, ds, dtau, dkappa) run on the device.  solver.jl's
+# loop is untouched: it keeps calling kkt_update!, kkt_solve!(…, :affine), kkt_solve!(…, :combined) separately
+# (solver.jl:278-295, :317-323).  The handle is put in LAZY mode: kkt_update! scales, scatters and refactors and leaves
+# (x2, z2) = K \ (-q, b) to the affine kkt_solve!, which sends both right-hand sides through the sweeps as ONE 2-column
+# solve and returns the AND of the two statuses -- what `is_kkt_solve_success = kkt_update!(...)` followed by
+# `is_kkt_solve_success && kkt_solve!(...)` computes from the two calls.
+import Clarabel: AbstractKKTSystem, DefaultProblemData, DefaultVariables
+import Clarabel: kkt_update!, kkt_solve_initial_point!, kkt_solve!, kkt_update_P!, kkt_update_A!, kkt_linear_solver_info
+
+mutable struct HipKKTSystem{T} <: AbstractKKTSystem{T}
+    kktsolver::HipKKTSolver{T}       # owns the handle (and the get_Hs! / sparse-SOC staging vectors)
+    w::Vector{T}                     # NT scaling handed to the device with every kkt_update!: w (m), eta (per cone),
+    eta::Vector{T}                   #   lambda (m), R / Rinv of the PSD cones (column-major, concatenated)
+    lambda::Vector{T}
+    psd_R::Vector{T}
+    psd_Rinv::Vector{T}
+    tk::Vector{T}                    # (dtau, dkappa) read-back
+
+    function HipKKTSystem{T}(data::DefaultProblemData{T}, cones::CompositeCone{T}, settings::Settings{T}) where {T}
+        ks = HipKKTSolver{T}(data.P, data.A, cones, data.m, data.n, settings)
+        GC.@preserve data check(ccall((:hipkkt_kkt_system_init, libhipkkt), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}),
+            ks.handle, data.q, data.b), "hipkkt_kkt_system_init")
+        check(ccall((:hipkkt_kkt_system_set_lazy, libhipkkt), Cint, (Ptr{Cvoid}, Cint), ks.handle, 1), "hipkkt_kkt_system_set_lazy")
+        npsd = sum(c isa PSDTriangleCone ? c.n^2 : 0 for c in cones; init = 0)
+        return new(ks, ones(T, data.m), ones(T, length(cones)), zeros(T, data.m), zeros(T, npsd), zeros(T, npsd), zeros(T, 2))
+    end
+end
+
+kkt_linear_solver_info(s::HipKKTSystem{T}) where {T} = kktsolver_linear_solver_info(s.kktsolver)
+kkt_update_P!(s::HipKKTSystem{T}, P::SparseMatrixCSC{T}) where {T} = kktsolver_update_P!(s.kktsolver, P)
+kkt_update_A!(s::HipKKTSystem{T}, A::SparseMatrixCSC{T}) where {T} = kktsolver_update_A!(s.kktsolver, A)
+
+# kkt_update! gets the CONES, not the iterate (solver.jl:279): everything the device needs is read from them --
+# the data of kktsolver_update! (get_Hs!, sparse-SOC u / v / eta^2, as in B above) and the NT scaling that
+# kkt_solve!'s Delta_s_from_Delta_z_offset! / mul_Hs! use (fields of the same cone objects, cone_types.jl:40-60,
+# 84-115, 125-160).
+function kkt_update!(s::HipKKTSystem{T}, data::DefaultProblemData{T}, cones::CompositeCone{T}) where {T}
+    ks = s.kktsolver
+    get_Hs!(cones, ks.Hsblocks)
+    off = 0; k = 0; zoff = 0; poff = 0
+    for (i, c) in enumerate(cones)
+        d = numel(c)
+        if c isa NonnegativeCone
+            s.w[zoff+1:zoff+d] .= c.w;  s.lambda[zoff+1:zoff+d] .= c.λ
+        elseif c isa SecondOrderCone
+            s.w[zoff+1:zoff+d] .= c.w;  s.lambda[zoff+1:zoff+d] .= c.λ;  s.eta[i] = c.η
+            if is_sparse_expandable(c)
+                ks.soc_u[off+1:off+d] .= c.sparse_data.u
+                ks.soc_v[off+1:off+d] .= c.sparse_data.v
+                k += 1; ks.soc_eta2[k] = c.η^2
+                off += d
+            end
+        elseif c isa PSDTriangleCone
+            n = c.n
+            s.lambda[zoff+1:zoff+n] .= c.data.λ
+            s.psd_R[poff+1:poff+n*n]    .= vec(c.data.R)
+            s.psd_Rinv[poff+1:poff+n*n] .= vec(c.data.Rinv)
+            poff += n * n
+        end
+        zoff += d
+    end
+    GC.@preserve s ks check(ccall((:hipkkt_kkt_system_update_cones, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+         Ptr{Cdouble}, Ptr{Cdouble}),
+        ks.handle, ks.Hsblocks, ks.soc_u, ks.soc_v, ks.soc_eta2, s.w, s.eta, s.lambda, s.psd_R, s.psd_Rinv),
+        "hipkkt_kkt_system_update_cones")
+end
+
+function kkt_solve_initial_point!(s::HipKKTSystem{T}, variables::DefaultVariables{T}, data::DefaultProblemData{T}) where {T}
+    GC.@preserve variables check(ccall((:hipkkt_kkt_system_solve_initial_point_host, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        s.kktsolver.handle, variables.x, variables.s, variables.z), "hipkkt_kkt_system_solve_initial_point_host")
+end
+
+function kkt_solve!(s::HipKKTSystem{T}, lhs::DefaultVariables{T}, rhs::DefaultVariables{T}, data::DefaultProblemData{T},
+                    variables::DefaultVariables{T}, cones::CompositeCone{T}, steptype::Symbol) where {T}
+    ok = GC.@preserve s lhs rhs variables check(ccall((:hipkkt_kkt_system_solve_host, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+         Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint),
+        s.kktsolver.handle, lhs.x, lhs.s, lhs.z, s.tk, rhs.x, rhs.s, rhs.z, rhs.τ, rhs.κ,
+        variables.x, variables.s, variables.z, variables.τ, variables.κ, steptype === :affine ? 0 : 1),
+        "hipkkt_kkt_system_solve_host")
+    ok || return false
+    lhs.τ = s.tk[1]
+    lhs.κ = s.tk[2]
+    return true
+end
+
 end # module
 
 # ---- boundary B only: the one-line dispatch at src/kktsystem.jl:33 ("Always LDL for now")
@@ -231,3 +326,12 @@ end # module
 #   kktsolver = settings.direct_solve_method === :hipkkt ?
 #       HipKKTExt.HipKKTSolver{T}(data.P, data.A, cones, m, n, settings) :
 #       DirectLDLKKTSolver{T}(data.P, data.A, cones, m, n, settings)
+#
+# ---- boundary C: the one-line dispatch at src/solver.jl:139, inside setup! (outside the IPM loop, like boundary B's)
+#
+#   s.kktsystem = s.settings.direct_solve_method === :hipkkt ?
+#       HipKKTExt.HipKKTSystem{T}(s.data, s.cones, s.settings) :
+#       DefaultKKTSystem{T}(s.data, s.cones, s.settings)
+#
+# solver.jl:278-323 (kkt_update!, kkt_solve! :affine, kkt_solve! :combined), :389-394 (default start) and
+# data_updating.jl:67,97 then reach the methods above by dispatch on the type of s.kktsystem.

@@ -149,3 +149,53 @@ def test_two_rank_rhs_column_sharding_and_solution_gather():
         o.kktsolver_setrhs(RX[j], RZ[j])
         _, x, _ = o.kktsolver_solve()
         np.testing.assert_array_equal(out[0][2][j], x)
+
+
+def _worker_blocked(rank, world, port, n_columns, block, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cuclarabel_amd.distributed import BlockedColumnGather, gather_columns, shard_columns
+        n, m = 7, 11
+        mine = shard_columns(n_columns, world, rank)
+        # column j's "solution": x part = j + 0.01 * index, z part = -j - 0.01 * index
+        LX = torch.zeros(max(len(mine), 1), n, dtype=torch.float64)
+        LZ = torch.zeros(max(len(mine), 1), m, dtype=torch.float64)
+        for qi, j in enumerate(mine):
+            LX[qi] = j + 0.01 * torch.arange(n, dtype=torch.float64)
+            LZ[qi] = -j - 0.01 * torch.arange(m, dtype=torch.float64)
+        g = BlockedColumnGather(n_columns, (n, m), block)
+        for q0, q1 in g.blocks():                  # solve block, post its exchange, go on with the next block
+            g.post(q0, q1, [LX[q0:q1], LZ[q0:q1]])
+        X, Z = g.finish()
+        ref = gather_columns(LX, n_columns)        # the one-shot exchange of the same data
+        q.put((rank, X.numpy(), Z.numpy(), ref.numpy(), len(g.blocks())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_columns,block", [(9, 2), (8, 4), (5, 16)])
+def test_two_rank_blocked_asynchronous_column_gather(n_columns, block):
+    """bench.py --mode rhs exchanges the (x, z) solutions in blocks of columns, block i on the links while block i + 1
+    is solved (BlockedColumnGather): every rank must end with every column, x and z parts, in order -- also with a
+    short last block and with ranks holding different numbers of columns -- and agree with the one-shot gather."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_blocked, args=(r, world, port, n_columns, block, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, X, Z, ref, nblocks in out:
+        assert X.shape == (n_columns, 7) and Z.shape == (n_columns, 11)
+        for j in range(n_columns):
+            np.testing.assert_array_equal(X[j], j + 0.01 * np.arange(7))
+            np.testing.assert_array_equal(Z[j], -j - 0.01 * np.arange(11))
+        np.testing.assert_array_equal(X, ref)
+        per = (n_columns + world - 1) // world
+        assert nblocks == (per + block - 1) // block

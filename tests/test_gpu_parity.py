@@ -1048,3 +1048,138 @@ def test_factorisation_overlap_mode(maker, overlap):
     import re
     m = re.search(r"factorisation overlap: last (\d+) launches", r.stderr)
     assert m and (int(m.group(1)) >= 3 if overlap == "1" else int(m.group(1)) == 0), r.stderr
+
+
+# ---- BASELINE.json's other configurations at FULL size (the reference's backend-swap test runs every data set at its
+#      real size: test/OptTests/linear_solvers.jl:11-71) -------------------------------------------------------------------
+_FULL_SIZE_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver
+from tests.oracle_bindings import make_oracle
+pb = {maker}
+ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+rng = np.random.default_rng(11)
+got = []
+# two value sets through the same handle (a refactorisation in place), two right-hand sides each; the GPU work runs
+# back to back BEFORE the oracle is built (its seconds of host work would let any side stream finish)
+for rep in range(2):
+    assert ks.kktsolver_update_from_sz(pb.s0 * (1.0 + 0.1 * rep), pb.z0)
+    for _ in range(2):
+        rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        ks.kktsolver_setrhs(rx, rz)
+        assert ks.kktsolver_solve(x, z)
+        got.append((rep, rx, rz, x, z, ks.last_ir_iterations))
+fallbacks = ks.fallbacks
+o = make_oracle(pb, perm=ks.perm())
+worst, cur = 0.0, -1
+for rep, rx, rz, x, z, ir in got:
+    if rep != cur:
+        assert o.update_scaling(pb.s0 * (1.0 + 0.1 * rep), pb.z0) and o.kktsolver_update()
+        cur = rep
+    o.kktsolver_setrhs(rx, rz)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok
+    # refinement would repair a slightly wrong factor or sweep at the price of extra rounds: the count must be the oracle's
+    assert ir == o.last_ir_iters, (rep, ir, o.last_ir_iters)
+    worst = max(worst, max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()))
+print("RESULT " + json.dumps(dict(worst=worst, fallbacks=list(fallbacks), N=ks.info["N"], levels=ks.info["nlevels"],
+                                   max_front=ks.info["max_front"], nnzL=ks.info["nnzL"])))
+assert worst < 1e-9, worst
+assert fallbacks == (0, 0), fallbacks
+print("FULL SIZE OK")
+"""
+
+
+@pytest.mark.parametrize("name,maker,expect", [
+    # cfg3: portfolio QP n = 50k, 100 dense 500 x 500 blocks of P: 514-row fronts, factorised in row slices by default
+    ("cfg3", "problems.config3()", dict(N=100001, min_front=500, sliced_panels=True, sliced_sweep=False)),
+    # cfg5: SDP, 200 x PSD(20) + 100 x SOC(50): 1531-row fronts -> row-sliced panels AND the (front, slice) sweep kernel
+    ("cfg5", "problems.config5()", dict(N=52200, min_front=1500, sliced_panels=True, sliced_sweep=True)),
+    # cfg4: one GPU's share of the batch (8 independent SOCPs n = 10k) as ONE block-diagonal handle
+    ("cfg4b", "problems.block_diagonal([problems.config4(j=j) for j in range(8)])",
+     dict(N=8 * 30200, min_front=200, sliced_panels=False, sliced_sweep=False)),
+])
+def test_full_size_baseline_configurations_match_oracle(name, maker, expect):
+    """BASELINE.json configs[2], [3] (per-GPU share) and [4] at their real sizes: HIP path against the oracle on the
+    same K, b -- solutions to 1e-9 AND the oracle's refinement-round counts, across a refactorisation in place --
+    with the paths the default schedule selects at that size (row-sliced panels, the sliced persistent sweep kernel,
+    the factorisation's overlap mode) and no fallback taken (the ABI's counters and stderr)."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FULL_SIZE_SCRIPT.format(root=root, maker=maker)],
+                       env=dict(os.environ, HIPKKT_VERBOSE="1"), cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FULL SIZE OK" in r.stdout
+    res = json.loads(re.search(r"RESULT (.*)", r.stdout).group(1))
+    assert res["N"] == expect["N"] and res["max_front"] >= expect["min_front"], res
+    assert res["fallbacks"] == [0, 0] and "gave up" not in r.stderr, r.stderr
+    sched = _schedule_line(r.stderr)
+    assert (sched["sliced_fronts"] > 0) == expect["sliced_panels"], sched
+    assert (sched["top_tasks"] > 0) == expect["sliced_sweep"], sched          # k_top_solve_sliced selected by default
+    assert sched["top_launches"] >= 3, sched                                  # the persistent sweep kernel is in use
+    m = re.search(r"factorisation overlap: last (\d+) launches", r.stderr)
+    assert m and int(m.group(1)) >= 3, r.stderr                               # ... and the overlap mode
+
+
+def test_deferred_status_reports_a_give_up_as_a_step_to_repeat():
+    """Deferred-status mode with both bounded waits forced to expire (limit of zero ticks): the give-up words must be
+    looked at BEFORE the numeric-failure word -- after a give-up the factor / solution is void and may be non-finite --
+    so the query answers REFINEMENT_INCOMPLETE (repeat the step), switches the mechanism off (counted in the profile),
+    and the repeated step is clean and matches the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import _lib, problems
+from cuclarabel_amd.kktsolver import HipKKTSolver
+from tests.oracle_bindings import make_oracle
+pb = problems.config2(n=20000)
+dev = torch.device("cuda", 0)
+d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+ks.set_deferred_status(True)
+rng = np.random.default_rng(5)
+rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+ds, dz, drx, drz = d(pb.s0), d(pb.z0), d(rx), d(rz)
+lx, lz = torch.zeros(pb.n, dtype=torch.float64, device=dev), torch.zeros(pb.m, dtype=torch.float64, device=dev)
+seen = []
+for attempt in range(4):
+    assert ks.kktsolver_update_from_sz_dev(ds.data_ptr(), dz.data_ptr())
+    ks.kktsolver_setrhs_dev(drx.data_ptr(), drz.data_ptr())
+    assert ks.kktsolver_solve_dev(lx.data_ptr(), lz.data_ptr())
+    rc = ks.deferred_status()
+    seen.append(rc)
+    if rc == _lib.OK:
+        break
+print("seen", seen, "fallbacks", ks.fallbacks)
+assert seen[-1] == _lib.OK and seen[0] == _lib.REFINEMENT_INCOMPLETE, seen
+assert _lib.NUMERIC_FAILURE not in seen, seen
+assert ks.fallbacks == (1, 1), ks.fallbacks
+o = make_oracle(pb, perm=ks.perm())
+assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+o.kktsolver_setrhs(rx, rz)
+ok, xo, zo = o.kktsolver_solve()
+assert ok
+err = max(np.abs(lx.cpu().numpy() - xo).max(), np.abs(lz.cpu().numpy() - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max())
+assert err < 1e-9, err
+print("DEFERRED GIVE-UP OK")
+"""
+    r = subprocess.run([sys.executable, "-c", script.format(root=root)],
+                       env=dict(os.environ, HIPKKT_OV_TEST_LIMIT="0", HIPKKT_TOP_TEST_LIMIT="0"), cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "DEFERRED GIVE-UP OK" in r.stdout
+    assert r.stderr.count("gave up") == 2, r.stderr

@@ -209,3 +209,135 @@ def test_device_kkt_solve_matches_host_algebra(affine):
     assert abs(dkappa - dkappa_h) <= 1e-9 * max(1.0, abs(dkappa_h))
     for a, bb in ((dx, dx_h), (dz, dz_h), (ds, ds_h)):
         assert np.abs(a - bb).max() <= 1e-9 * max(1.0, np.abs(bb).max())
+
+
+# ---- level C through the reference's own two calls (lazy constant-RHS solve) ---------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ALL))
+def test_reference_known_answers_with_lazy_constant_solve(name):
+    """kkt_update! and kkt_solve!(:affine) as the TWO SEPARATE calls solver.jl:278-295 makes, with the handle in lazy
+    mode (hipkkt_kkt_system_set_lazy): kkt_update! leaves the constant-RHS solve to the affine kkt_solve!, which sends
+    both right-hand sides through the sweeps as one 2-column solve.  Same known answers, and the SAME iterates, iteration
+    and refinement-round counts as the one-call form (batch_affine=True), with no fallback taken."""
+    P, q, A, b, cones, exp = ALL[name]()
+    lazy = ipm.HipSystemBackend(P, A, cones, lazy=True)
+    res = ipm.solve(P, q, A, b, cones, lazy)
+    _check(res, exp)
+    ref = ipm.solve(P, q, A, b, cones, ipm.HipSystemBackend(P, A, cones, batch_affine=True))
+    assert res.iterations == ref.iterations and res.kkt_ir_rounds == ref.kkt_ir_rounds
+    np.testing.assert_allclose(res.x, ref.x, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(res.z, ref.z, rtol=1e-13, atol=1e-13)
+    assert lazy.ks.fallbacks == (0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ALL))
+def test_reference_known_answers_from_the_callers_cone_objects(name):
+    """The route of the Julia glue's HipKKTSystem: kkt_update!(kktsystem, data, cones) hands over what the CALLER's
+    cone objects hold (hipkkt_kkt_system_update_cones: get_Hs! blocks, sparse-SOC u / v / eta^2, w, eta, lambda, R,
+    Rinv), lazy mode, host-resident iterates through the *_host entry points."""
+    P, q, A, b, cones, exp = ALL[name]()
+    res = ipm.solve(P, q, A, b, cones, ipm.HipSystemBackend(P, A, cones, lazy=True, host_cones=True))
+    _check(res, exp)
+    ref = ipm.solve(P, q, A, b, cones, OracleBackend(P, A, cones))
+    assert res.iterations == ref.iterations
+    if exp["status"] == "SOLVED":
+        np.testing.assert_allclose(res.x, ref.x, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_lazy_mode_on_sparse_second_order_cones_walks_with_the_eager_calls():
+    """cfg2-shaped problem (every second-order cone sparse-expanded): lazy two-call mode, from the device's own scaling
+    and from the caller's cone objects, against the eager level-C calls -- same path for the first ten iterations."""
+    from cuclarabel_amd import problems
+    pb = problems.config2(n=1000)
+    runs = [ipm.solve(pb.P, pb.q, pb.A, pb.b, pb.cones, ipm.HipSystemBackend(pb.P, pb.A, pb.cones, **kw))
+            for kw in (dict(), dict(lazy=True), dict(lazy=True, host_cones=True), dict(lazy=True, staging="torch"))]
+    k = min(min(len(r.history) for r in runs), 10)
+    assert k == 10
+    for r in runs[1:]:
+        for a, b in zip(r.history[:k], runs[0].history[:k]):
+            assert abs(a["pcost"] - b["pcost"]) < 1e-6 * max(1, abs(b["pcost"]))
+            assert abs(a["mu"] - b["mu"]) < 1e-6 * max(1e-12, abs(b["mu"]))
+
+
+@pytest.mark.gpu
+def test_lazy_constant_solve_failure_and_flush():
+    """(i) A numeric failure in the constant-RHS solve must end the iteration as it does in the reference
+    (kktsystem.jl:62-92 returns false from kkt_update!, solver.jl:279-295 ANDs the two results): in lazy mode kkt_update!
+    has returned true by then, so the failure has to come out of the affine kkt_solve!.  (ii) Any other consumer of
+    (x2, z2) -- a :combined solve arriving first -- makes the pending solve run by itself: same step as the eager calls."""
+    from cuclarabel_amd import problems
+    from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+    pb = problems.small_mixed(seed=43, psds=(2, 3, 6), socs=(3, 4, 6, 15))
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal(pb.n)
+    rhs_x, rhs_s, rhs_z = rng.standard_normal(pb.n), rng.standard_normal(pb.m), rng.standard_normal(pb.m)
+    args = (0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+    # (i) q with a non-finite entry: the constant right-hand side's residual is not finite
+    qbad = pb.q.copy()
+    qbad[0] = np.inf
+    for lazy in (False, True):
+        system = HipKKTSystem(HipKKTSolver(pb.P, pb.A, pb.cones))
+        system.init(qbad, pb.b)
+        system.set_lazy(lazy)
+        ok_update = system.update(pb.s0, pb.z0)
+        assert ok_update == lazy                       # eager: kkt_update! reports it; lazy: not yet
+        if lazy:
+            ok, step = system.solve(rhs_x, pb.s0, rhs_z, *args, True)
+            assert not ok and step is None             # ... the affine kkt_solve! does: `a && b` is false either way
+    # and through the driver: both modes stop with the same status on such data
+    st = [ipm.solve(pb.P, qbad, pb.A, pb.b, pb.cones, ipm.HipSystemBackend(pb.P, pb.A, pb.cones, lazy=lz)).status for lz in (False, True)]
+    assert st[0] == st[1] == ipm.NUMERICAL_ERROR, st
+    # (ii) combined step first
+    out = []
+    for lazy in (False, True):
+        system = HipKKTSystem(HipKKTSolver(pb.P, pb.A, pb.cones))
+        system.init(pb.q, pb.b)
+        system.set_lazy(lazy)
+        assert system.update(pb.s0, pb.z0)
+        ok, step = system.solve(rhs_x, rhs_s, rhs_z, *args, False)
+        assert ok
+        out.append(step)
+    for a, bb in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, bb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("affine", [True, False])
+def test_system_update_cones_equals_the_device_scaling(affine):
+    """hipkkt_kkt_system_update_cones (scaling handed over by the caller) against hipkkt_kkt_system_update (scaling
+    computed on the device from (s, z)): fed with the device's own w, eta, lambda, R, Rinv and Hs blocks (and the
+    oracle's sparse-SOC u, v, eta^2) the step must agree to round-off, on every cone kind."""
+    from cuclarabel_amd import problems
+    from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+    from tests.oracle_bindings import make_oracle
+    pb = problems.small_mixed(seed=43, psds=(2, 3, 6), socs=(3, 4, 6, 15))
+    rng = np.random.default_rng(29)
+    x = rng.standard_normal(pb.n)
+    rhs_x, rhs_z = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    rhs_s = pb.s0.copy() if affine else rng.standard_normal(pb.m)
+    args = (0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+    ka = HipKKTSolver(pb.P, pb.A, pb.cones)
+    sa = HipKKTSystem(ka)
+    sa.init(pb.q, pb.b)
+    assert sa.update(pb.s0, pb.z0)
+    ok, step_a = sa.solve(rhs_x, rhs_s, rhs_z, *args, affine)
+    assert ok
+    lam, psd = ka.scaling()
+    w, eta = ka.scaling_w()
+    o = make_oracle(pb, perm=ka.perm())
+    assert o.update_scaling(pb.s0, pb.z0)
+    u, v, e2, _ = o.soc_sparse()
+    R = np.concatenate([t[0].ravel(order="F") for t in psd]) if psd else np.zeros(0)
+    Ri = np.concatenate([t[1].ravel(order="F") for t in psd]) if psd else np.zeros(0)
+    for lazy in (False, True):
+        kb = HipKKTSolver(pb.P, pb.A, pb.cones)
+        sb = HipKKTSystem(kb)
+        sb.init(pb.q, pb.b)
+        sb.set_lazy(lazy)
+        assert sb.update_cones(ka.get_Hs(), u, v, e2, w, eta, lam, R, Ri)
+        ok, step_b = sb.solve(rhs_x, rhs_s, rhs_z, *args, affine)
+        assert ok
+        for a, bb in zip(step_a, step_b):
+            np.testing.assert_allclose(a, bb, rtol=1e-9, atol=1e-9 * max(1.0, float(np.max(np.abs(a)))))

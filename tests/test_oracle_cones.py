@@ -102,3 +102,34 @@ def test_nn_and_zero_blocks():
     Hs = o.get_Hs()
     np.testing.assert_allclose(Hs, [0, 0, 0.25, 4.0, 9.0], rtol=1e-15)           # w^2 = s/z; zero cone 0
     np.testing.assert_allclose(o.mul_Hs(np.ones(5)), [0, 0, 0.25, 4.0, 9.0], rtol=1e-15)
+
+
+def test_driver_cone_objects_hand_over_what_the_oracle_computes():
+    """cuclarabel_amd.ipm.host_cone_data (what the Julia glue reads from the reference's cone objects for kkt_update!:
+    get_Hs! blocks, sparse second-order (u, v, eta^2), w, eta, lambda, R, Rinv) against the oracle's cones on a problem
+    with every cone kind -- the data hipkkt_kkt_system_update_cones takes."""
+    from cuclarabel_amd import ipm, problems
+    from tests.oracle_bindings import make_oracle
+    pb = problems.small_mixed(seed=43, psds=(2, 3, 6), socs=(3, 4, 6, 15))
+    o = make_oracle(pb)
+    assert o.update_scaling(pb.s0, pb.z0)
+    cones = ipm._make_cones(pb.cones)
+    for c in cones:
+        assert c.update_scaling(pb.s0[c.rng].copy(), pb.z0[c.rng].copy())
+    Hs, u, v, e2, w, eta, lam, R, Ri = ipm.host_cone_data(cones)
+    Hs_o = o.get_Hs()
+    np.testing.assert_allclose(Hs, Hs_o, rtol=1e-11, atol=1e-13 * np.abs(Hs_o).max())
+    uo, vo, e2o, _ = o.soc_sparse()
+    np.testing.assert_allclose(u, uo, rtol=1e-12)
+    np.testing.assert_allclose(v, vo, rtol=1e-12)
+    np.testing.assert_allclose(e2, e2o, rtol=1e-12)
+    lam_o = o.cone_lambda()
+    for c in cones:
+        if isinstance(c, (ipm._NN, ipm._SOC)):
+            np.testing.assert_allclose(lam[c.rng], lam_o[c.rng], rtol=1e-11, atol=1e-13)
+        if isinstance(c, ipm._PSD):
+            np.testing.assert_allclose(lam[c.off:c.off + c.k], lam_o[c.off:c.off + c.k], rtol=1e-11)
+    # y = W'W x through the driver's cones equals the oracle's mul_Hs
+    x = np.random.default_rng(3).standard_normal(pb.m)
+    y = np.concatenate([c.mul_Hs(x[c.rng]) for c in cones])
+    np.testing.assert_allclose(y, o.mul_Hs(x), rtol=0, atol=1e-11 * np.abs(y).max())
