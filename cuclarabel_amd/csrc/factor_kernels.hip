@@ -402,6 +402,8 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     const int f = nc + rs;                                         // rows held here
     const bool first = !SLICED || sl == 0;                         // writes what all slices compute alike
     double* __restrict__ F = A.fronts + fd.front_off;
+    // overlap mode: this workgroup is resident now (FactorArgs::ov_started; the launch's tiles wait for all of them)
+    if (OV && tid == 0) __hip_atomic_fetch_add(A.ov_started + A.ov_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // block data is double-buffered by block parity: wave 0 factors diagonal block k+1 while the other waves
     // still read block k's d, 1/d and d*L
@@ -753,8 +755,11 @@ constexpr int LDA = TS + 16;    // k-rows 80 doubles apart: consecutive k land 3
 // on this front's panel at all) is summed into the tile buffer first; then the product takes the panel's 16-column
 // blocks one by one as the panel kernel publishes them (FactorArgs::ov_prog), so that when the panel's last block
 // arrives only one rank-16 update and the store remain; the tile is stored written-through and counted in ov_done.
+// (The kernel can walk its tiles on a grid smaller than their number -- workgroup b takes tiles b, b + G, ... -- which
+// is how a bounded tile grid was tried for the overlap mode's forward-progress guarantee; measured +0.1 ms on cfg2's
+// factorisation.  The guarantee comes from the gate below instead and the grid is the number of tiles.)
 template <bool OV>
-__global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin)
+__global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin, int ntiles)
 {
     // the operand chunks are dead once the product is done: the tile buffer shares their LDS (33 KB per
     // workgroup instead of 53 KB -> one more workgroup per CU)
@@ -768,7 +773,8 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TreeDev& T = A.T;
-    const int2 tl = tiles[tile_begin + blockIdx.x];
+    for (int tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const int2 tl = tiles[tile_begin + tix];
     const int s = tl.x;
     const int ti = tl.y >> 16, tj = tl.y & 0xffff;
     const int c0 = T.sn_start[s];
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
     const int ml = lane & 15, mk = lane >> 4;
     // the pass-through work list is static data: fetch this wave's range and its first 64 descriptors now -- lane l
     // takes descriptor l, ONE vector load round -- so that after the product only (rel, value) load rounds remain
-    const int64_t* __restrict__ tc = T.tile_cut + 5 * (int64_t)(tile_begin + blockIdx.x);
+    const int64_t* __restrict__ tc = T.tile_cut + 5 * (int64_t)(tile_begin + tix);
     const int64_t i0 = tc[wv], i1 = tc[wv + 1];
     static_assert(sizeof(SubItem) == 16, "SubItem is read as an int4");
     const int4* __restrict__ sit4 = reinterpret_cast<const int4*>(T.sitems);
@@ -924,6 +930,21 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(A.ov_done + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    }   // tiles of this workgroup
+}
+
+// Overlap mode's gate: one wave, no LDS, on the tile stream in front of a launch's tile kernel.  It ends when every panel
+// workgroup of the launch has started, i.e. IS RESIDENT (a workgroup keeps its CU until it ends).  From then on the
+// launch's tiles may fill every other CU: each of them waits only for a panel workgroup that is running, and a running
+// panel workgroup waits only for the previous launch's tiles, which were released the same way -- so every wait ends,
+// whatever the hardware's dispatch order (forward progress by induction over the launches, not by submission order).
+__global__ __launch_bounds__(64) void k_ov_gate(const int* __restrict__ started, int target, int* abort_word, long long limit)
+{
+    if (threadIdx.x == 0) (void)ov_wait_ge(started, target, abort_word, wall_clock64(), limit);
+}
+void launch_ov_gate(const int* started, int target, int* abort_word, long long limit, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, st, started, target, abort_word, limit);
 }
 
 size_t panel_lds_bytes(int fmax, int panel_max)
@@ -984,11 +1005,11 @@ void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, 
     if (a.ov) hipLaunchKernelGGL((k_panel<1024, true, true>), dim3(count), dim3(1024), lds, st, a, begin);
     else hipLaunchKernelGGL((k_panel<1024, true, false>), dim3(count), dim3(1024), lds, st, a, begin);
 }
-void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st)
+void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid)
 {
     if (ntiles <= 0) return;
-    if (a.ov) hipLaunchKernelGGL(k_schur<true>, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin);
-    else hipLaunchKernelGGL(k_schur<false>, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin);
+    if (a.ov) hipLaunchKernelGGL(k_schur<true>, dim3(std::max(1, std::min(ntiles, ov_grid))), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
+    else hipLaunchKernelGGL(k_schur<false>, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
 }
 
 }  // namespace hipkkt

@@ -79,7 +79,8 @@ static constexpr size_t kLdsCap = 160 * 1024 - 512;
 static constexpr int kMaxNR = 4;          // right-hand sides the single-column solve path takes in one sweep (1, 2 or 4)
 static const size_t kWinvTailLaunches = std::getenv("HIPKKT_WINV_TAIL") ? (size_t)std::atoi(std::getenv("HIPKKT_WINV_TAIL")) : 4;
 static const size_t kWinvEarlyLaunches = std::getenv("HIPKKT_WINV_EARLY") ? (size_t)std::atoi(std::getenv("HIPKKT_WINV_EARLY")) : 1;
-static int kSideWinvBlocks = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 96;
+// grid of the side-stream W formation while the tree is still being factorised: 3/8 of the CUs (96 of 256) unless set
+static const int kSideWinvBlocksEnv = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 0;
 
 // The persistent top-of-tree solve kernel needs all its workgroups resident.  Two such kernels running
 // at the same time on one device (two handles on different streams) could each hold part of the CUs while
@@ -128,6 +129,10 @@ public:
                          S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
                          top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, overlap_wanted() ? launches.size() - ov_first : (size_t)0,
                          ov_slices);
+            if (overlap_wanted())
+                for (size_t q = ov_first; q < launches.size(); ++q)
+                    std::fprintf(stderr, "[hipkkt] overlap admission: launch %zu: %d panel workgroups, %d tiles behind a gate, %d CUs\n", q,
+                                 launches[q].count - launches[q].nsliced + launches[q].slice_count, launches[q].ntiles, n_cus);
         }
     }
 
@@ -214,14 +219,15 @@ public:
         launch_permute_out(d_X, ldx, xp_m.p, KP, d_iperm.p, S.N, nrhs, stream);
         HIP_CHECK(hipGetLastError());
     }
-    // the same with ROW-major vectors, N x KP (KP a multiple of 16, padding columns zero); d_X may alias d_B
-    void solve_multi_rm(const double* d_B, double* d_X, int KP)
+    // the same with ROW-major vectors, N x KP (KP a multiple of 16, padding columns zero); d_X may alias d_B;
+    // d_add (nullable, same layout): X = K^{-1} B + add, formed while the solution is permuted back
+    void solve_multi_rm(const double* d_B, double* d_X, int KP, const double* d_add = nullptr)
     {
         if (KP <= 0 || (KP & 15)) throw ArgError("solve_multi_rm: KP must be a positive multiple of 16");
         multi_prepare(KP);
         launch_permute_rows(xp_m.p, d_B, KP, d_iperm.p, S.N, 0, stream);
         multi_sweeps(KP);
-        launch_permute_rows(d_X, xp_m.p, KP, d_iperm.p, S.N, 1, stream);
+        launch_permute_rows(d_X, xp_m.p, KP, d_iperm.p, S.N, 1, stream, d_add);
         HIP_CHECK(hipGetLastError());
     }
 
@@ -336,6 +342,7 @@ private:
             launch_zero_ints(d_ov_prog.p, S.nsuper, st);
             launch_zero_ints(d_ov_done.p, S.nsuper, st);
             if (!slice_list.empty()) launch_zero_ints(d_ov_sprog.p, (int)slice_list.size(), st);
+            launch_zero_ints(d_ov_started.p, (int)launches.size(), st);
         }
         FactorArgs a;
         a.T = tree();
@@ -349,6 +356,7 @@ private:
         a.dyn_delta = dyn_delta;
         a.ov_prog = d_ov_prog.p; a.ov_done = d_ov_done.p; a.ov_ntiles = d_ov_ntiles.p; a.ov = 0;
         a.ov_sprog = d_ov_sprog.p; a.ov_sbase = d_ov_sbase.p;
+        a.ov_started = d_ov_started.p; a.ov_slot = 0;
         static const long long ov_limit = std::getenv("HIPKKT_OV_TEST_LIMIT") ? std::atoll(std::getenv("HIPKKT_OV_TEST_LIMIT")) : 5000000;
         a.ov_limit = ov_limit;
         a.stamps = nullptr;
@@ -360,6 +368,12 @@ private:
         }
         int li = 0;
         bool forked = false;
+#ifdef HIPKKT_EXPERIMENTS
+        // EXPERIMENT (timing only; without the gate the overlap mode's forward progress rests on submission order again)
+        static const bool no_gate = std::getenv("HIPKKT_EXPERIMENT_NO_GATE") != nullptr;
+#else
+        constexpr bool no_gate = false;
+#endif
 #ifdef HIPKKT_EXPERIMENTS
         // EXPERIMENT (timing only, wrong results unless K stays the same between factorisations; compiled in only with
         // -DHIPKKT_EXPERIMENTS, never in the default build): skip W formation after n factorisations
@@ -392,7 +406,7 @@ private:
                 HIP_CHECK(hipEventRecord(ev_fork, st));
                 HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
                 // a bounded grid: the top panels need whole CUs (their LDS), which a full-width launch would hold
-                form_w(d_tinv_list.p + w_done, launches[q].tinv_begin - w_done, tinv_ncmax, cap_side, kSideWinvBlocks);
+                form_w(d_tinv_list.p + w_done, launches[q].tinv_begin - w_done, tinv_ncmax, cap_side, side_winv_blocks);
                 eager_fork = true;
                 w_done = launches[q].tinv_begin;
                 // the fronts below the narrow top are used by the next sweep's first launches: the factorisation ends
@@ -407,14 +421,18 @@ private:
                 // that waits for its panel holds LDS a panel workgroup needs; the first overlapped level therefore
                 // starts its tiles only after its panels have finished.)
                 a.ov = 1;
+                a.ov_slot = (int)q;
                 a.nbk = L.nbk;
                 launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
                 launch_panel_sliced(a, L.slice_begin, L.slice_count, L.lds_sliced, st);
                 if (q == ov_first) {
                     HIP_CHECK(hipEventRecord(ev_ov_fork, st));
                     HIP_CHECK(hipStreamWaitEvent(ov_stream, ev_ov_fork, 0));
+                } else if (L.ntiles > 0 && !no_gate) {
+                    // the gate: this launch's tiles are released once all its panel workgroups are resident (k_ov_gate)
+                    launch_ov_gate(d_ov_started.p + q, L.count - L.nsliced + L.slice_count, flags.p + 2, ov_limit, ov_stream);
                 }
-                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, ov_stream);
+                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, ov_stream, L.ntiles);
                 a.ov = 0;
                 if (q + 1 == nl) {
                     HIP_CHECK(hipEventRecord(ev_ov_join, ov_stream));
@@ -777,7 +795,8 @@ private:
     // overlap mode of the factorisation (factor_kernels.hip): the launches from ov_first on (the narrow top of the tree)
     size_t ov_first = 0;         // == launches.size(): none
     bool ov_disabled = false;
-    DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase;
+    int n_cus = 256, side_winv_blocks = 96;
+    DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
     hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
     size_t nr_cap = 1;           // right-hand sides xp / uvec are sized for
@@ -1002,20 +1021,39 @@ private:
         d_sched.upload(sched);
         d_tiles.upload(tiles);
         {
-            // overlap mode: the longest suffix of block-class launches, none sliced, none with more than kOvMaxFronts fronts
-            // (a panel workgroup holds a whole CU while it waits for its children's tiles: the tiles need CUs of their own)
-            static const int ov_max = std::getenv("HIPKKT_OV_MAX_FRONTS") ? std::atoi(std::getenv("HIPKKT_OV_MAX_FRONTS")) : 120;
+            // Overlap admission.  In overlap mode a level's PANEL workgroups (each needs a CU to itself: ~150 KB of LDS) run
+            // beside the level's TILE workgroups on the overlap stream (53 KB: they fit beside each other, but one of them
+            // on a CU is enough to keep a panel out) and the side stream's W formation.  Tiles wait for their panel's
+            // blocks and panels wait for their children's tiles, so forward progress needs every panel workgroup of a
+            // launch to be RESIDENT before a tile of that launch may wait for it.  That is enforced, not hoped for: the
+            // launch's tile kernel sits behind a gate (k_ov_gate) that opens when all its panel workgroups have started.
+            // Everything else on the device is work that ends by itself (the previous launch's tiles, whose panels are
+            // resident or done; the W formation, which waits for nothing), so the panel workgroups do get their CUs,
+            // provided there are enough CUs for all of them plus the gate's wave at once:
+            //     panel workgroups of the launch + 1 + margin <= CUs.
+            // Below that bound the width is a matter of speed only: wide launches were measured slower in the mode
+            // (panels that wait hold whole CUs the tiles could use), so the default admits launches of up to 120 panel
+            // workgroups; HIPKKT_OV_MAX_FRONTS moves that, never beyond the bound.  (The bounded waits remain for what
+            // this argument cannot see: another process, or another handle's kernels, on the same device.)
+            {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
+                side_winv_blocks = kSideWinvBlocksEnv > 0 ? kSideWinvBlocksEnv : std::max(8, n_cus * 3 / 8);
+            }
+            constexpr int kOvMargin = 8;
+            static const int ov_max_env = std::getenv("HIPKKT_OV_MAX_FRONTS") ? std::atoi(std::getenv("HIPKKT_OV_MAX_FRONTS")) : 120 * n_cus / 256;
+            const int ov_max = std::min(ov_max_env, n_cus - 1 - kOvMargin);
+            auto panel_wgs = [&](const Launch& L) { return L.count - L.nsliced + L.slice_count; };   // whole panels + row slices
             size_t first = launches.size();
             while (first > 0) {
                 const Launch& L = launches[first - 1];
-                // (workgroups of the launch: whole panels plus row slices.  A launch that holds BOTH kinds runs them as two
-                //  kernels one after the other: the level's tiles, submitted behind both, can reach the CUs while the
-                //  first one still runs and leave none for the second -- seen as sporadic give-ups on cfg5; such launches
-                //  stay out of the overlap mode)
-                if (L.small || L.count - L.nsliced + L.slice_count > ov_max || (L.nsliced > 0 && L.nsliced < L.count)) break;
+                if (L.small || panel_wgs(L) > ov_max) break;
                 --first;
             }
             ov_first = (launches.size() - first >= 3) ? first : launches.size();
+            d_ov_started.alloc(std::max<size_t>(launches.size(), 1));
+            HIP_CHECK(hipMemset(d_ov_started.p, 0, std::max<size_t>(launches.size(), 1) * sizeof(int)));
             std::vector<int> nt((size_t)S.nsuper, 0);
             for (size_t q = ov_first; q < launches.size(); ++q) {
                 const Launch& L = launches[q];
@@ -1557,11 +1595,12 @@ struct hipkkt_kkt_s {
     bool deferred = false;           // hipkkt_kkt_set_deferred_status
     // level C (DefaultKKTSystem on the device, kktsystem.jl:21-215)
     DBuf<double> lam;                                        // scaled point, m
-    DBuf<double> sq, snegq, sb, sx1, sz1, sx2, sz2, sworkx, sworkz, sconic, spa, spb;
+    DBuf<double> sq, snegq, sb, sx1, sz1, sx2, sz2, sworkx, sworkz, sconic, spa, spb, spc;
     DBuf<double> sys_partial, sys_dots, sys_cached, sys_in, sys_out;
     bool sys_ready = false;
     bool sys_lazy = false;           // hipkkt_kkt_system_set_lazy: kkt_update! leaves (x2, z2) = K \ (-q, b) to the affine kkt_solve!
     bool sys_const_pending = false;  // ... and that solve is still due
+    bool sys_update_unread = false;  // lazy mode: the last kkt_update!'s status sits in the sticky record, read with the next solve's
     DBuf<double> hst;                // staging of the *_host entry points of level C: 3 x (n + 2 m) doubles (rhs, variables, lhs)
     // solve_multi work space, N x mcap each (grown on demand)
     DBuf<double> mB, mX, mC, mE, mE2, mpartial, mnorms;
@@ -2135,7 +2174,7 @@ int hipkkt_kkt_update_cones(hipkkt_kkt_t h, const double* Hs, const double* soc_
     });
 }
 
-int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double* d_s, const double* d_z)
+static int kkt_update_from_sz_dev_impl(hipkkt_kkt_t h, const double* d_s, const double* d_z, bool deferred)
 {
     return guarded([&]() {
         if (!h || (h->K.m > 0 && (!d_s || !d_z))) throw ArgError("hipkkt_kkt_update_from_sz: bad argument");
@@ -2147,8 +2186,12 @@ int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double* d_s, const doubl
         launch_cone_scaling(h->cone_dev(), h->cone_state(), d_s, d_z, h->K.m, h->stream);
         h->prof.end(pu, h->stream);
         h->scaling_valid = true;
-        return kkt_update_device(h, h->deferred);
+        return kkt_update_device(h, deferred);
     });
+}
+int hipkkt_kkt_update_from_sz_dev(hipkkt_kkt_t h, const double* d_s, const double* d_z)
+{
+    return kkt_update_from_sz_dev_impl(h, d_s, d_z, h && h->deferred);
 }
 
 int hipkkt_kkt_update_from_sz(hipkkt_kkt_t h, const double* s, const double* z)
@@ -2284,10 +2327,10 @@ static void kkt_enqueue_round(hipkkt_kkt_t h, int r, bool first, bool readback, 
 }
 // nr = 1, 2 or 4 right-hand sides (columns of h->b, N apart) share every sweep; each column goes through the
 // reference's loop on its own.  ir_out (nullable, nr entries): rounds per column (-1 in deferred mode).
-static int kkt_solve_core(hipkkt_kkt_t h, bool may_defer = false, int nr = 1, int64_t* ir_out = nullptr)
+static int kkt_solve_core(hipkkt_kkt_t h, bool may_defer = false, int nr = 1, int64_t* ir_out = nullptr, bool force_defer = false)
 {
     const hipkkt_settings& st = h->st;
-    const bool deferred = may_defer && h->deferred;
+    const bool deferred = force_defer || (may_defer && h->deferred);
     h->cur_x = h->x.p;
     h->cur_dx = h->dx.p;
     h->last_ir = 0;
@@ -2365,15 +2408,10 @@ int hipkkt_kkt_set_deferred_status(hipkkt_kkt_t h, int defer)
     });
 }
 
-int hipkkt_kkt_deferred_status(hipkkt_kkt_t h)
+// what the sticky record {bad, more, abort, rounds, #dyn. regularisations, eps, solves, overlap gave up} read back into
+// pinned memory says about everything enqueued since the last query: OK / NUMERIC_FAILURE / REFINEMENT_INCOMPLETE
+static int kkt_eval_sticky(hipkkt_kkt_t h, const double* s)
 {
-    return guarded([&]() {
-        if (!h) throw ArgError("null handle");
-        HIP_CHECK(hipSetDevice(h->device));
-        HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        launch_zero_ints((int*)h->ir_sticky, 16, h->stream);
-        HIP_CHECK(hipStreamSynchronize(h->stream));
-        const double* s = h->pin->h + 40;
         const int max_iter = std::max(h->st.iterative_refinement_max_iter, 0);
         h->prof.acc.ir_iterations += (int64_t)s[3];
         h->prof.acc.dynamic_regularizations += (int64_t)s[4];
@@ -2392,6 +2430,18 @@ int hipkkt_kkt_deferred_status(hipkkt_kkt_t h)
             return HIPKKT_REFINEMENT_INCOMPLETE;
         }
         return HIPKKT_OK;
+}
+
+int hipkkt_kkt_deferred_status(hipkkt_kkt_t h)
+{
+    return guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        launch_zero_ints((int*)h->ir_sticky, 16, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->sys_update_unread = false;
+        return kkt_eval_sticky(h, h->pin->h + 40);
     });
 }
 
@@ -2511,9 +2561,9 @@ static int kkt_solve_multi_core_rm(hipkkt_kkt_t h, int k, int KP, int64_t* ir_ou
     const hipkkt_settings& st = h->st;
     const int N = (int)h->K.N;
     std::vector<int64_t> ir((size_t)k, 0);
-    auto trisolve = [&](const double* rhs, double* out) {
+    auto trisolve = [&](const double* rhs, double* out, const double* add = nullptr) {
         int ps = h->prof.begin(2, h->stream);
-        h->eng->solve_multi_rm(rhs, out, KP);
+        h->eng->solve_multi_rm(rhs, out, KP, add);
         h->prof.end(ps, h->stream);
     };
     trisolve(h->mB.p, h->mX.p);
@@ -2548,8 +2598,7 @@ static int kkt_solve_multi_core_rm(hipkkt_kkt_t h, int k, int KP, int64_t* ir_ou
             any = any || active[j];
         }
         if (!any) break;
-        trisolve(h->mE.p, h->mC.p);                                               // dx_j = K^{-1} e_j
-        launch_axpby_sum(h->mC.p, h->mC.p, h->mX.p, (int64_t)N * KP, h->stream);  // prospective x_j + dx_j
+        trisolve(h->mE.p, h->mC.p, h->mX.p);                                      // prospective x_j + dx_j, dx_j = K^{-1} e_j
         int pr = h->prof.begin(3, h->stream);
         launch_residual_rm(A, h->mB.p, h->mC.p, h->mE2.p, h->mpartial.p, h->mnorms.p, nullptr, KP, h->stream);
         h->prof.end(pr, h->stream);
@@ -2569,6 +2618,15 @@ static int kkt_solve_multi_core_rm(hipkkt_kkt_t h, int k, int KP, int64_t* ir_ou
                 mask[j] = 1;
             }
             if (mask[j]) norme[j] = hn[j];
+        }
+        bool all_accept = true;
+        for (int j = 0; j < k; ++j) all_accept = all_accept && mask[j] != 0;
+        if (all_accept) {
+            // every column takes its candidate (the usual first round): the buffers change roles, nothing is copied
+            // (the padding columns are zero in both)
+            std::swap(h->mX.p, h->mC.p);
+            std::swap(h->mE.p, h->mE2.p);
+            continue;
         }
         HIP_CHECK(hipMemcpyAsync(h->mmask.p, mask.data(), (size_t)KP * sizeof(int), hipMemcpyHostToDevice, h->stream));
         launch_accept_columns_rm(h->mX.p, h->mC.p, h->mE.p, h->mE2.p, h->mmask.p, N, KP, h->stream);
@@ -2729,7 +2787,7 @@ int hipkkt_kkt_system_init(hipkkt_kkt_t h, const double* q, const double* b)
         HIP_CHECK(hipSetDevice(h->device));
         const size_t n = (size_t)h->K.n, m = (size_t)h->K.m;
         h->sq.alloc(n); h->snegq.alloc(n); h->sb.alloc(m);
-        h->sx1.alloc(n); h->sx2.alloc(n); h->sworkx.alloc(n); h->spa.alloc(n); h->spb.alloc(n);
+        h->sx1.alloc(n); h->sx2.alloc(n); h->sworkx.alloc(n); h->spa.alloc(n); h->spb.alloc(n); h->spc.alloc(n);
         h->sz1.alloc(m); h->sz2.alloc(m); h->sworkz.alloc(m); h->sconic.alloc(m);
         h->sys_partial.alloc(8 * 64); h->sys_dots.alloc(8); h->sys_cached.alloc(4); h->sys_in.alloc(4); h->sys_out.alloc(4);
         if (n) HIP_CHECK(hipMemcpyAsync(h->sq.p, q, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -2804,8 +2862,15 @@ int hipkkt_kkt_system_update(hipkkt_kkt_t h, const double* d_s, const double* d_
         g_last_error = "hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)";
         return HIPKKT_ERR_ARG;         // (before anything is enqueued: a deferred factorisation's status would be left unread)
     }
-    int rc = hipkkt_kkt_update_from_sz_dev(h, d_s, d_z);
+    // Lazy mode: the update is only ENQUEUED (its status -- cone points, pivots, the overlap mode's waits -- joins the
+    // sticky record on the device) and is read back together with the affine kkt_solve!'s own result: one host round
+    // trip for kkt_update! + kkt_solve!(:affine) instead of three.  A failed factorisation therefore surfaces at the
+    // affine kkt_solve! -- `is_kkt_solve_success = kkt_update!(...)` and `is_kkt_solve_success && kkt_solve!(...)`
+    // (solver.jl:279-295) reach the same branch either way.
+    const bool enqueue_only = h && h->sys_lazy && h->sys_ready;
+    int rc = kkt_update_from_sz_dev_impl(h, d_s, d_z, enqueue_only);
     if (rc != HIPKKT_OK) return rc;                    // "bail if the factorization has failed" (:71)
+    if (enqueue_only) h->sys_update_unread = true;
     return guarded([&]() { return sys_after_update(h); });
 }
 
@@ -2838,15 +2903,24 @@ int hipkkt_kkt_system_solve_initial_point(hipkkt_kkt_t h, double* d_x, double* d
 }
 
 // the part of kkt_solve! behind the solve for (x1, z1) (kktsystem.jl:175-212): dtau, (dx, dz), ds, dkappa
+// with_const: (x2, z2) is new as well (it came out of the same 2-column solve): its terms of tau_den are formed here too
+// addend: Delta_s constant term (sconic, or variables.s itself for the affine step)
 static void sys_finish_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,
-                            double rhs_tau, double rhs_kappa, const double* d_var_x, double var_tau, double var_kappa)
+                            double rhs_tau, double rhs_kappa, const double* d_var_x, double var_tau, double var_kappa,
+                            bool with_const = false, const double* addend = nullptr)
 {
     const int n = h->K.n, m = h->K.m;
     hipStream_t st = h->stream;
     // P x1 and P (xi - x2), xi = x / tau, in one pass (xi - x2 kept in workx for its dot product)
-    launch_P_spmv2(sys_spmv(h), h->Kval.p, h->sx1.p, d_var_x, h->sx2.p, var_tau, h->spa.p, h->spb.p, h->sworkx.p, n, st);
+    launch_P_spmv2(sys_spmv(h), h->Kval.p, h->sx1.p, d_var_x, h->sx2.p, var_tau, h->spa.p, h->spb.p, h->sworkx.p,
+                   with_const ? h->spc.p : nullptr, n, st);
     DotPairs P{};
-    P.npairs = 4;
+    P.npairs = with_const ? 7 : 4;
+    if (with_const) {
+        P.a[4] = h->sq.p; P.b[4] = h->sx2.p; P.len[4] = n;
+        P.a[5] = h->sb.p; P.b[5] = h->sz2.p; P.len[5] = m;
+        P.a[6] = h->sx2.p; P.b[6] = h->spc.p; P.len[6] = n;
+    }
     P.a[0] = h->sq.p; P.b[0] = h->sx1.p; P.len[0] = n;
     P.a[1] = h->sb.p; P.b[1] = h->sz1.p; P.len[1] = m;
     P.a[2] = d_var_x; P.b[2] = h->spa.p; P.len[2] = n;
@@ -2855,12 +2929,25 @@ static void sys_finish_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, do
     // (dx, dz) = (x1, z1) + dtau (x2, z2)                                 (:200-203)
     launch_sys_step(d_lhs_x, d_lhs_z, h->sx1.p, h->sz1.p, h->sx2.p, h->sz2.p, h->sys_out.p, n, m, st);
     // ds = -(Hs dz + const)                                               (:206-212)
-    launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st, h->sconic.p);
+    launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st, addend ? addend : h->sconic.p);
+    if (!lhs_tau_kappa) return;                      // (the caller reads sys_out back with its own status record)
     // (dtau, dkappa) through the handle's pinned block: a copy into pageable memory would be staged
     HIP_CHECK(hipMemcpyAsync(h->pin->h + 48, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     lhs_tau_kappa[0] = h->pin->h[48];
     lhs_tau_kappa[1] = h->pin->h[49];
+}
+// an enqueued-only kkt_update! whose status nobody has read yet (lazy mode), before a call that reads back on its own
+static int sys_flush_update_status(hipkkt_kkt_t h)
+{
+    if (!h->sys_update_unread) return HIPKKT_OK;
+    h->sys_update_unread = false;
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    launch_zero_ints((int*)h->ir_sticky, 16, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    int rc = kkt_eval_sticky(h, h->pin->h + 40);
+    if (rc == HIPKKT_REFINEMENT_INCOMPLETE) rc = kkt_update_device(h);      // a bounded wait gave up: level by level, synchronously
+    return rc;
 }
 // the x2-only terms of tau_den (kktsystem.jl:194-196) are the same for both solves of the iteration
 static void sys_cache_constant_terms(hipkkt_kkt_t h)
@@ -2896,32 +2983,67 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
     if (h->sys_const_pending && !pair) {
         // (x2, z2) is due and cannot ride with this solve: by itself first, as kkt_update! would have done it
         h->sys_const_pending = false;
-        int rc = sys_constant_rhs(h);
+        int rc = sys_flush_update_status(h);
+        if (rc == HIPKKT_OK) rc = sys_constant_rhs(h);
         if (rc != HIPKKT_OK) return rc;
     }
-    // Delta_s constant term and the z part of the right-hand side (kktsystem.jl:150-166)
-    if (!launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, affine ? d_var_s : d_rhs_s,
-                           d_var_z, d_rhs_z, m, affine, st))
-        throw ArgError("hipkkt_kkt_system_solve: unsupported cone kind");
-    if (pair) {
-        // _kkt_solve_constant_rhs! (:80-92) and this solve (:170-173) as ONE 2-column solve: column 0 = (-q, b),
-        // column 1 = (rhs.x, s - rhs.z); each column is refined by the reference's rule on its own
-        h->sys_const_pending = false;
-        const size_t N = (size_t)h->K.N;
-        launch_pack_rhs(h->b.p, h->snegq.p, h->sb.p, n, m, h->K.p, st);
-        launch_pack_rhs(h->b.p + N, d_rhs_x, h->sworkz.p, n, m, h->K.p, st);
-        int rc = kkt_solve_core(h, false, 2, nullptr);
+    h->sys_const_pending = false;
+    const size_t N = (size_t)h->K.N;
+    // everything of this call, enqueued; `defer`: the solve's refinement decisions stay on the device, nothing is read back here
+    auto run = [&](bool defer) -> int {
+        // Delta_s constant term and the z part of the right-hand side (kktsystem.jl:150-166).  Affine step: the constant
+        // term is variables.s itself (:157-158), so the right-hand side is packed straight from (rhs.x, s - rhs.z)
+        if (!affine && !launch_sys_offset(h->cone_dev(), h->cone_state(), h->sconic.p, h->sworkz.p, d_rhs_s, d_var_z, d_rhs_z,
+                                          m, false, st))
+            throw ArgError("hipkkt_kkt_system_solve: unsupported cone kind");
+        if (pair) {
+            // _kkt_solve_constant_rhs! (:80-92) and this solve (:170-173) as ONE 2-column solve: column 0 = (-q, b),
+            // column 1 = (rhs.x, s - rhs.z); each column is refined by the reference's rule on its own
+            launch_pack_rhs_affine(h->b.p, h->snegq.p, h->sb.p, d_rhs_x, d_var_s, d_rhs_z, n, m, h->K.p, 2, st);
+            int rc = kkt_solve_core(h, false, 2, nullptr, defer);
+            if (rc != HIPKKT_OK) return rc;
+            launch_unpack_lhs2(h->sx2.p, h->sz2.p, h->sx1.p, h->sz1.p, h->x.p, n, m, (int64_t)N, st);
+        } else {
+            // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
+            if (affine) launch_pack_rhs_affine(h->b.p, nullptr, nullptr, d_rhs_x, d_var_s, d_rhs_z, n, m, h->K.p, 1, st);
+            else launch_pack_rhs(h->b.p, d_rhs_x, h->sworkz.p, n, m, h->K.p, st);
+            int rc = kkt_solve_core(h, false, 1, nullptr, defer);
+            if (rc != HIPKKT_OK) return rc;
+            launch_unpack_lhs(h->sx1.p, h->sz1.p, h->x.p, n, m, st);
+        }
+        sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, defer ? nullptr : lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa,
+                        pair, affine ? d_var_s : nullptr);
+        return HIPKKT_OK;
+    };
+    if (h->sys_lazy && h->st.iterative_refinement_enable) {
+        // Lazy mode: ONE read-back per call -- the sticky status record (this call's solve, and the kkt_update! before it
+        // if that was enqueued only) together with (dtau, dkappa).  If the record says that the reference's refinement loop
+        // would have gone on, or that a bounded wait gave up, the call is repeated with the synchronous sequence.
+        const bool update_unread = h->sys_update_unread;
+        h->sys_update_unread = false;
+        int rc = run(true);
         if (rc != HIPKKT_OK) return rc;
-        launch_unpack_lhs(h->sx2.p, h->sz2.p, h->x.p, n, m, st);
-        launch_unpack_lhs(h->sx1.p, h->sz1.p, h->x.p + N, n, m, st);
-        sys_cache_constant_terms(h);
+        HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(h->pin->h + 48, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        launch_zero_ints((int*)h->ir_sticky, 16, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        rc = kkt_eval_sticky(h, h->pin->h + 40);
+        h->last_ir = (int64_t)h->pin->h[43];           // this call's refinement rounds, summed over its columns (as the synchronous path reports)
+        if (rc == HIPKKT_OK) {
+            lhs_tau_kappa[0] = h->pin->h[48];
+            lhs_tau_kappa[1] = h->pin->h[49];
+            return HIPKKT_OK;
+        }
+        if (rc != HIPKKT_REFINEMENT_INCOMPLETE) return rc;
+        if (update_unread) {                           // (the factorisation itself may be void: a wait of the overlap mode gave up)
+            rc = kkt_update_device(h);
+            if (rc != HIPKKT_OK) return rc;
+        }
     } else {
-        // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
-        int rc = sys_solve_into(h, d_rhs_x, h->sworkz.p, h->sx1.p, h->sz1.p);
+        int rc = sys_flush_update_status(h);
         if (rc != HIPKKT_OK) return rc;
     }
-    sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa);
-    return HIPKKT_OK;
+    return run(false);
 }
 
 int hipkkt_kkt_system_solve(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,

@@ -305,6 +305,46 @@ void launch_pack_rhs(double* b, const double* rx, const double* rz, int n, int m
 {
     hipLaunchKernelGGL(k_pack_rhs, dim3(grid_for(n + m + p, 256), nrhs), dim3(256), 0, st, b, rx, rz, n, m, p);
 }
+// level C, affine kkt_solve! with the constant right-hand side riding along (kktsystem.jl:87-88, :157-173): column 0 =
+// (-q, b), column 1 = (rhs.x, s - rhs.z) -- the affine step's Delta_s constant term is variables.s itself, so the
+// right-hand side needs no separate offset pass; ncol = 1: column 1's content alone, in column 0
+__global__ void k_pack_rhs_affine(double* __restrict__ b, const double* __restrict__ negq, const double* __restrict__ bb,
+                                  const double* __restrict__ rhs_x, const double* __restrict__ s,
+                                  const double* __restrict__ rhs_z, int n, int m, int p, int ncol)
+{
+    const int N = n + m + p;
+    const bool aff = ncol == 1 || blockIdx.y == 1;
+    b += (int64_t)blockIdx.y * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (i < n) v = aff ? rhs_x[i] : negq[i];
+        else if (i < n + m) v = aff ? s[i - n] - rhs_z[i - n] : bb[i - n];
+        b[i] = v;
+    }
+}
+void launch_pack_rhs_affine(double* b, const double* negq, const double* bb, const double* rhs_x, const double* s,
+                            const double* rhs_z, int n, int m, int p, int ncol, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pack_rhs_affine, dim3(grid_for(n + m + p, 256), ncol), dim3(256), 0, st, b, negq, bb, rhs_x, s, rhs_z,
+                       n, m, p, ncol);
+}
+// getlhs! for two columns at once: (x2, z2) <- column 0, (x1, z1) <- column 1
+__global__ void k_unpack_lhs2(double* __restrict__ x2, double* __restrict__ z2, double* __restrict__ x1,
+                              double* __restrict__ z1, const double* __restrict__ x, int n, int m, int64_t N)
+{
+    const double* __restrict__ src = x + (int64_t)blockIdx.y * N;
+    double* __restrict__ ox = blockIdx.y == 0 ? x2 : x1;
+    double* __restrict__ oz = blockIdx.y == 0 ? z2 : z1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x) {
+        if (i < n) ox[i] = src[i];
+        else oz[i - n] = src[i];
+    }
+}
+void launch_unpack_lhs2(double* x2, double* z2, double* x1, double* z1, const double* x, int n, int m, int64_t N, hipStream_t st)
+{
+    if (n + m <= 0) return;
+    hipLaunchKernelGGL(k_unpack_lhs2, dim3(grid_for(n + m, 256), 2), dim3(256), 0, st, x2, z2, x1, z1, x, n, m, N);
+}
 __global__ void k_accept_columns(double* __restrict__ x, const double* __restrict__ cand, double* __restrict__ e,
                                  const double* __restrict__ e2, const int* __restrict__ mask, int N)
 {
@@ -1067,35 +1107,39 @@ void launch_P_spmv(const SpmvDev& A, const double* Kval, const double* x, double
 __global__ __launch_bounds__(256) void k_P_spmv2(SpmvDev A, const double* __restrict__ K, const double* __restrict__ x1,
                                                  const double* __restrict__ x, const double* __restrict__ x2, double tau,
                                                  double* __restrict__ pa, double* __restrict__ pb,
-                                                 double* __restrict__ xm_out, int n)
+                                                 double* __restrict__ xm_out, double* __restrict__ pc, int n)
 {
+    // pc (nullable): P x2 as well -- the x2-only terms of tau_den, needed once per kkt_update! (kktsystem.jl:194-196)
     const int sub = threadIdx.x & 7;
     for (int row = blockIdx.x * 32 + (threadIdx.x >> 3); row < n; row += gridDim.x * 32) {
-        double a1 = 0.0, a2 = 0.0;
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
         for (int64_t q = A.ptr[row] + sub; q < A.ptr[row + 1]; q += 8) {
             const int c = A.col[q];
             if (c < n) {
                 const double v = A.val ? A.val[q] : K[A.vmap[q]];
+                const double x2c = x2[c];
                 a1 = fma(v, x1[c], a1);
-                a2 = fma(v, x[c] / tau - x2[c], a2);
+                a2 = fma(v, x[c] / tau - x2c, a2);
+                a3 = fma(v, x2c, a3);
             }
         }
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 8); a2 += __shfl_down(a2, o, 8); }
+        for (int o = 4; o > 0; o >>= 1) { a1 += __shfl_down(a1, o, 8); a2 += __shfl_down(a2, o, 8); a3 += __shfl_down(a3, o, 8); }
         if (sub == 0) {
             pa[row] = a1;
             pb[row] = a2;
+            if (pc) pc[row] = a3;
             xm_out[row] = x[row] / tau - x2[row];
         }
     }
 }
 void launch_P_spmv2(const SpmvDev& A, const double* Kval, const double* x1, const double* x, const double* x2, double tau,
-                    double* pa, double* pb, double* xm_out, int n, hipStream_t st)
+                    double* pa, double* pb, double* xm_out, double* pc, int n, hipStream_t st)
 {
     if (n <= 0) return;
     int g = (n + 31) / 32;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_P_spmv2, dim3(g), dim3(256), 0, st, A, Kval, x1, x, x2, tau, pa, pb, xm_out, n);
+    hipLaunchKernelGGL(k_P_spmv2, dim3(g), dim3(256), 0, st, A, Kval, x1, x, x2, tau, pa, pb, xm_out, pc, n);
 }
 
 __global__ void k_sys_axpby(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ alpha,
@@ -1172,19 +1216,22 @@ void launch_sys_scalars(const double* dots, const double* cached, const double* 
 }
 // the second stage of the four dot products and the scalars of kkt_solve! in one single-workgroup kernel; the
 // caller's scalars come by value (a 32-byte copy from pageable host memory would drain the stream first)
-__global__ __launch_bounds__(64) void k_dots_finish_scalars(const double* __restrict__ partial, const double* __restrict__ cached,
+__global__ __launch_bounds__(64) void k_dots_finish_scalars(const double* __restrict__ partial, double* __restrict__ cached,
                                                             double rhs_tau, double rhs_kappa, double tau, double kappa,
-                                                            double* __restrict__ out)
+                                                            double* __restrict__ out, int npairs)
 {
-    __shared__ double d[4];
+    // npairs = 7: pairs 4..6 are the x2-only terms {q.x2, b.z2, x2.(P x2)}; they are stored to `cached` for the
+    // iteration's later solves (what sys_cache_constant_terms does as a pass of its own)
+    __shared__ double d[8];
     const int p = threadIdx.x;
-    if (p < 4) {
+    if (p < npairs) {
         double acc = 0.0;
         for (int i = 0; i < kDotBlocks; ++i) acc += partial[p * kDotBlocks + i];      // (the order of k_dots_finish)
         d[p] = acc;
     }
     __syncthreads();
     if (p != 0) return;
+    if (npairs == 7) { cached[0] = d[4]; cached[1] = d[5]; cached[2] = d[6]; }
     const double tau_num = rhs_tau - rhs_kappa / tau + d[0] + d[1] + 2.0 * (d[2] / tau);
     double tau_den = kappa / tau - cached[0] - cached[1];
     tau_den += d[3] - cached[2];
@@ -1194,11 +1241,11 @@ __global__ __launch_bounds__(64) void k_dots_finish_scalars(const double* __rest
     out[2] = tau_num;
     out[3] = tau_den;
 }
-void launch_dots4_scalars(const DotPairs& P, double* partial, const double* cached, double rhs_tau, double rhs_kappa, double tau,
+void launch_dots4_scalars(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
                           double kappa, double* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_dots, dim3(kDotBlocks, 4), dim3(256), 0, st, P, partial);
-    hipLaunchKernelGGL(k_dots_finish_scalars, dim3(1), dim3(64), 0, st, partial, cached, rhs_tau, rhs_kappa, tau, kappa, out);
+    hipLaunchKernelGGL(k_dots, dim3(kDotBlocks, P.npairs), dim3(256), 0, st, P, partial);
+    hipLaunchKernelGGL(k_dots_finish_scalars, dim3(1), dim3(64), 0, st, partial, cached, rhs_tau, rhs_kappa, tau, kappa, out, P.npairs);
 }
 // (dx, dz) = (x1, z1) + dtau (x2, z2) in one launch (kktsystem.jl:200-203); dtau = scal[0] on the device
 __global__ void k_sys_step(double* __restrict__ dx, double* __restrict__ dz, const double* __restrict__ x1,
@@ -1509,18 +1556,28 @@ __global__ __launch_bounds__(256) void k_residual_rm(SpmvDev A, const double* __
         if (bpartial) bpartial[(int64_t)blockIdx.x * KP + cb0 + c] = w;
     }
 }
-__global__ void k_finish_norm_rm(const double* __restrict__ partial, const double* __restrict__ bpartial, int nblocks, int KP,
-                                 double* __restrict__ out, double* __restrict__ bout)
+// one workgroup per 64 columns, 16 threads per column over the partial rows (the maximum is order-independent); a single
+// thread per column walking all 512 partial rows took 140-230 us of pure latency per residual
+__global__ __launch_bounds__(1024) void k_finish_norm_rm(const double* __restrict__ partial, const double* __restrict__ bpartial,
+                                                         int nblocks, int KP, double* __restrict__ out, double* __restrict__ bout)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= KP) return;
+    __shared__ double sh[2][16][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double v = 0.0, w = 0.0;
-    for (int i = 0; i < nblocks; ++i) {
-        v = fmax(v, partial[(int64_t)i * KP + c]);
-        if (bpartial) w = fmax(w, bpartial[(int64_t)i * KP + c]);
+    if (c < KP)
+        for (int i = part; i < nblocks; i += 16) {
+            v = fmax(v, partial[(int64_t)i * KP + c]);
+            if (bpartial) w = fmax(w, bpartial[(int64_t)i * KP + c]);
+        }
+    sh[0][part][cl] = v;
+    sh[1][part][cl] = w;
+    __syncthreads();
+    if (part == 0 && c < KP) {
+        for (int k = 1; k < 16; ++k) { v = fmax(v, sh[0][k][cl]); w = fmax(w, sh[1][k][cl]); }
+        out[c] = v;
+        if (bpartial) bout[c] = w;
     }
-    out[c] = v;
-    if (bpartial) bout[c] = w;
 }
 void launch_residual_rm(const SpmvDev& A, const double* B, const double* X, double* E, double* partial, double* norm_out,
                         double* normb_out, int KP, hipStream_t st)
@@ -1530,7 +1587,7 @@ void launch_residual_rm(const SpmvDev& A, const double* B, const double* X, doub
     if (g < 1) g = 1;
     double* bpartial = normb_out ? partial + (size_t)kRmBlocks * KP : nullptr;
     hipLaunchKernelGGL(k_residual_rm, dim3(g, KP / 16), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
-    hipLaunchKernelGGL(k_finish_norm_rm, dim3((KP + 63) / 64), dim3(64), 0, st, (const double*)partial, (const double*)bpartial, g,
+    hipLaunchKernelGGL(k_finish_norm_rm, dim3((KP + 63) / 64), dim3(1024), 0, st, (const double*)partial, (const double*)bpartial, g,
                        KP, norm_out, normb_out);
 }
 __global__ void k_accept_columns_rm(double* __restrict__ X, const double* __restrict__ cand, double* __restrict__ E,

@@ -148,6 +148,11 @@ struct FactorArgs {
     //   ov_sbase[s]   first slice of supernode s in sdesc (-1: s is factorised whole)
     int* ov_sprog;
     const int* ov_sbase;
+    //   ov_started[q] panel workgroups (whole panels and row slices) of launch q that have begun to run this
+    //                 factorisation: the launch's tile kernel is released by a gate (k_ov_gate) once ALL of them are
+    //                 resident -- a tile workgroup that waits for its panel then never keeps that panel off a CU
+    int* ov_started;
+    int ov_slot;                 // this launch's index q
     int ov;                      // this launch runs in overlap mode
     long long ov_limit;          // bound of every overlap-mode wait in 100 MHz ticks (50 ms; the tests set it to 0 to
                                  // force the give-up-and-repeat path: HIPKKT_OV_TEST_LIMIT)
@@ -215,7 +220,10 @@ void launch_front_tiny(const FactorArgs& a, int begin, int count, hipStream_t st
 void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st);
 // row slices of the panels too tall for one CU (TreeDev::sdesc[begin ..]), one 1024-thread workgroup each
 void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, hipStream_t st);
-void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st);
+// ov_grid: overlap mode only -- the number of tile workgroups that may exist at a time (they walk the launch's tiles)
+void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid = 0);
+// overlap mode: returns (the stream goes on) once *started >= target, i.e. every panel workgroup of the launch is resident
+void launch_ov_gate(const int* started, int target, int* abort_word, long long limit, hipStream_t st);
 size_t panel_lds_bytes(int fmax, int panel_max);
 // nr = 1, 2 or 4 right-hand sides per launch (column strides in SolveArgs::ld_*); lds = bytes per right-hand side
 void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);
@@ -231,7 +239,7 @@ void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int 
 // iperm[caller's index] = permuted index
 void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
 // row-major source / destination (N x KP): rows move, columns stay; dir 0: Xp[iperm[o]] = B[o], 1: X[o] = Xp[iperm[o]]
-void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st);
+void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st, const double* add = nullptr);
 void launch_permute_out(double* X, int64_t ldx, const double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
 void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
@@ -377,10 +385,14 @@ void launch_dots(const DotPairs& P, double* partial, double* out, hipStream_t st
 void launch_sys_scalars(const double* dots, const double* cached, const double* scal_in, double* out, hipStream_t st);
 void launch_neg_sum(double* y, const double* a, const double* b, int n, hipStream_t st);      // y = -(a + b)
 // fused forms of the above for kkt_solve!'s step recovery (fewer dependent launches, scalars by value)
+// (pc nullable: P x2 too; P.npairs = 4, or 7 with the x2-only pairs {q.x2, b.z2, x2.(P x2)} behind them, which are then stored to `cached`)
 void launch_P_spmv2(const SpmvDev& A, const double* Kval, const double* x1, const double* x, const double* x2, double tau,
-                    double* pa, double* pb, double* xm_out, int n, hipStream_t st);
-void launch_dots4_scalars(const DotPairs& P, double* partial, const double* cached, double rhs_tau, double rhs_kappa, double tau,
+                    double* pa, double* pb, double* xm_out, double* pc, int n, hipStream_t st);
+void launch_dots4_scalars(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
                           double kappa, double* out, hipStream_t st);
+void launch_pack_rhs_affine(double* b, const double* negq, const double* bb, const double* rhs_x, const double* s,
+                            const double* rhs_z, int n, int m, int p, int ncol, hipStream_t st);
+void launch_unpack_lhs2(double* x2, double* z2, double* x1, double* z1, const double* x, int n, int m, int64_t N, hipStream_t st);
 void launch_sys_step(double* dx, double* dz, const double* x1, const double* z1, const double* x2, const double* z2,
                      const double* scal, int n, int m, hipStream_t st);
 void launch_neg_copy(double* y, const double* a, int n, hipStream_t st);                    // y = -a

@@ -1913,13 +1913,15 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 15, mk = lane >> 4;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    // (grid.x = column block, grid.y = front: the workgroups that share a front's W are dispatched together, so W comes
+    //  from HBM once per XCD instead of once per column block)
+    const FrontDesc fd = T.desc[begin + blockIdx.y];
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ W = A.tinv + fd.w_off;                  // f x nc, ld f
-    double* __restrict__ xp = A.xp + blockIdx.y * kMultiCB;
-    double* __restrict__ uvec = A.uvec + blockIdx.y * kMultiCB;
+    double* __restrict__ xp = A.xp + blockIdx.x * kMultiCB;
+    double* __restrict__ uvec = A.uvec + blockIdx.x * kMultiCB;
     const int ncp = (nc + 3) & ~3;
     double* Ys = smem;                       // ncp x 16 row-major
 
@@ -2043,12 +2045,12 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 15, mk = lane >> 4;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const FrontDesc fd = T.desc[begin + blockIdx.y];
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;       // W'(j, r) at j + r*nc
-    double* __restrict__ xp = A.xp + blockIdx.y * kMultiCB;
+    double* __restrict__ xp = A.xp + blockIdx.x * kMultiCB;
     const int nt = (nc + 15) >> 4;
     constexpr int NW = BS / 64;
     const int ns = bwd_multi_slices(nt, f, NW);
@@ -2101,8 +2103,9 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
     }
 }
 
+// add (nullable, dir = 1 only): dst[o] = src[iperm[o]] + add[o] -- the refinement step's x + dx formed on the way out
 __global__ __launch_bounds__(256) void k_permute_rows(double* __restrict__ dst, const double* __restrict__ src, int KP,
-                                                      const int* __restrict__ iperm, int N, int dir)
+                                                      const int* __restrict__ iperm, int N, int dir, const double* __restrict__ add)
 {
     const int groups = KP >> 3;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < (int64_t)N * groups;
@@ -2114,15 +2117,20 @@ __global__ __launch_bounds__(256) void k_permute_rows(double* __restrict__ dst, 
         double2 v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = s2[c];
+        if (add) {
+            const double2* a2 = reinterpret_cast<const double2*>(add + (int64_t)o * KP + 8 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const double2 t = a2[c]; v[c].x += t.x; v[c].y += t.y; }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) d2[c] = v[c];
     }
 }
-void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st)
+void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st, const double* add)
 {
     const int64_t work = (int64_t)N * (KP >> 3);
     int g = (int)std::min<int64_t>((work + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_permute_rows, dim3(g < 1 ? 1 : g), dim3(256), 0, st, dst, src, KP, iperm, N, dir);
+    hipLaunchKernelGGL(k_permute_rows, dim3(g < 1 ? 1 : g), dim3(256), 0, st, dst, src, KP, iperm, N, dir, dir ? add : nullptr);
 }
 void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st)
 {
@@ -2145,8 +2153,8 @@ void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     }
     const size_t lds = (size_t)((ncmax + 3) & ~3) * 16 * sizeof(double);
     // many column blocks: smaller workgroups, more fronts in flight (measured: 256 columns 21.4 vs 23.4 ms)
-    if (KP >= 128) hipLaunchKernelGGL(k_fwd_block_m<256>, dim3(count, KP / kMultiCB), dim3(256), lds, st, a, begin, KP);
-    else hipLaunchKernelGGL(k_fwd_block_m<512>, dim3(count, KP / kMultiCB), dim3(512), lds, st, a, begin, KP);
+    if (KP >= 128) hipLaunchKernelGGL(k_fwd_block_m<256>, dim3(KP / kMultiCB, count), dim3(256), lds, st, a, begin, KP);
+    else hipLaunchKernelGGL(k_fwd_block_m<512>, dim3(KP / kMultiCB, count), dim3(512), lds, st, a, begin, KP);
 }
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st)
 {
@@ -2158,8 +2166,8 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     // at most max(8, nt) partial tiles of 16 x 16
     const int nt = (ncmax + 15) >> 4;
     const size_t lds = (size_t)std::max(8, nt) * 256 * sizeof(double);
-    if (KP >= 128) hipLaunchKernelGGL(k_bwd_block_m<256>, dim3(count, KP / kMultiCB), dim3(256), lds, st, a, begin, KP);
-    else hipLaunchKernelGGL(k_bwd_block_m<512>, dim3(count, KP / kMultiCB), dim3(512), lds, st, a, begin, KP);
+    if (KP >= 128) hipLaunchKernelGGL(k_bwd_block_m<256>, dim3(KP / kMultiCB, count), dim3(256), lds, st, a, begin, KP);
+    else hipLaunchKernelGGL(k_bwd_block_m<512>, dim3(KP / kMultiCB, count), dim3(512), lds, st, a, begin, KP);
 }
 
 // resident workgroups the device guarantees for the persistent kernel with `lds` bytes of dynamic LDS (the 1024-thread

