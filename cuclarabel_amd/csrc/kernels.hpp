@@ -321,6 +321,13 @@ void launch_fold_update_status(double* sticky, const double* st4, hipStream_t st
 void launch_fold_flag(double* sticky, const int* flag, hipStream_t st);
 // p[0..n) = 0 with a kernel: a small hipMemsetAsync stalls the stream for ~40 us on this stack
 void launch_zero_ints(int* p, int n, hipStream_t st);
+struct ZeroList {
+    int* p[8];
+    int n[8];
+    int count = 0;
+    void add(int* ptr, int len) { if (ptr && len > 0 && count < 8) { p[count] = ptr; n[count] = len; ++count; } }
+};
+void launch_zero_ints_multi(const ZeroList& Z, hipStream_t st);      // up to eight arrays in one launch
 // dst[0..4] = {eps[0], conefail[0], flags[0], flags[1], flags[2]} (null pointers read as 0)
 void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st);
 

@@ -296,6 +296,28 @@ class HipKKTSystem:
             0 if affine else 1), "hipkkt_kkt_system_solve")
         return ok, tk[0], tk[1]
 
+    def prepared(self, d_lhs, d_rhs, rhs_tau, rhs_kappa, d_var, var_tau, var_kappa):
+        """(update, solve_affine, solve_combined) closures over pre-converted ctypes arguments for a caller that issues the
+        same three calls on the same resident buffers every iteration (bench.py): the per-call argument marshalling of
+        `update_dev` / `solve_dev` is host time during which the GPU idles.  d_rhs = (affine (x, s, z), combined (x, s, z))."""
+        L = _lib.lib()
+        h = self.ks._h
+        tk = np.zeros(2)
+        P = lambda v: C.c_void_p(v)
+        upd_args = (h, P(d_var[1]), P(d_var[2]))
+        sol_args = [(h, P(d_lhs[0]), P(d_lhs[1]), P(d_lhs[2]), ptr(tk), P(r[0]), P(r[1]), P(r[2]), C.c_double(rhs_tau),
+                     C.c_double(rhs_kappa), P(d_var[0]), P(d_var[1]), P(d_var[2]), C.c_double(var_tau), C.c_double(var_kappa),
+                     C.c_int(st)) for r, st in ((d_rhs[0], 0), (d_rhs[1], 1))]
+        fu, fs = L.hipkkt_kkt_system_update, L.hipkkt_kkt_system_solve
+
+        def update():
+            return check(fu(*upd_args), "hipkkt_kkt_system_update")
+
+        def solve(i):
+            ok = check(fs(*sol_args[i]), "hipkkt_kkt_system_solve")
+            return ok, tk[0], tk[1]
+        return update, (lambda: solve(0)), (lambda: solve(1))
+
     # ---- lazy constant-RHS solve (hipkkt_kkt_system_set_lazy): kkt_update! + kkt_solve!(:affine) as two SEPARATE calls
     #      whose two solves still share one 2-column sweep
     def set_lazy(self, on=True):
