@@ -922,10 +922,15 @@ private:
                 int64_t smax = 0;
                 L.nsliced = 0;
                 L.slice_begin = (int)slice_list.size();
+                // A launch that holds row-sliced fronts runs ALL its fronts through the sliced panel kernel, a whole front
+                // as a front of one slice: two panel kernels one after the other (whole, then sliced) cost a level of
+                // cfg5 30-57 us for the one to four whole fronts that sit beside its hundreds of slices.
+                bool all_sliced = false;
+                if (cls == 0) for (int s : v) all_sliced = all_sliced || slices_of(s) > 1;
                 for (int s : v) {
                     const int r = cls == 0 ? slices_of(s) : 1;
                     const int nc = ncols(s), nb = front_size(s) - nc;
-                    if (r == 1) {
+                    if (r == 1 && !all_sliced) {
                         pmax = std::max(pmax, front_size(s) * nc - nc * (nc - 1) / 2);
                     } else {
                         ++L.nsliced;
@@ -1076,7 +1081,7 @@ private:
             {
                 // the trailing launches whose panels share one kernel: whole panels only, at most ov_merge_max of them in all
                 // (HIPKKT_OV_MERGE, 0 = off), and never the first overlapped launch (its tiles are released by an event)
-                static const int ov_merge_max = std::getenv("HIPKKT_OV_MERGE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE")) : 64;
+                static const int ov_merge_max = std::getenv("HIPKKT_OV_MERGE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE")) : 100;
                 ov_merge_first = ~(size_t)0;
                 ov_merge_count = 0;
                 ov_merge_lds = 0;
