@@ -440,7 +440,8 @@ private:
                     launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
                     launch_panel_sliced(a, L.slice_begin, L.slice_count, L.lds_sliced, st);
                 } else if (q == ov_merge_first) {
-                    launch_panel(a, L.begin, ov_merge_count, 1024, ov_merge_lds, st);
+                    if (ov_merge_sliced) launch_panel_sliced(a, L.slice_begin, ov_merge_count, ov_merge_lds, st);
+                    else launch_panel(a, L.begin, ov_merge_count, 1024, ov_merge_lds, st);
                 }
                 if (q == ov_first) {
                     HIP_CHECK(hipEventRecord(ev_ov_fork, st));
@@ -815,8 +816,9 @@ private:
     bool ov_disabled = false;
     int n_cus = 256, side_winv_blocks = 96;
     size_t ov_merge_first = ~(size_t)0;   // overlap mode: launches from here on share one panel kernel (none: beyond the last)
-    int ov_merge_count = 0;
+    int ov_merge_count = 0;          // panel workgroups of that kernel (whole fronts, or row slices: ov_merge_sliced)
     size_t ov_merge_lds = 0;
+    bool ov_merge_sliced = false;
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
     hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
@@ -1079,7 +1081,8 @@ private:
             }
             ov_first = (launches.size() - first >= 3) ? first : launches.size();
             {
-                // the trailing launches whose panels share one kernel: whole panels only, at most ov_merge_max of them in all
+                // the trailing launches whose panels share one kernel: all of one kind (whole panels, or row slices -- a
+                // launch with sliced fronts runs all its fronts as slices), at most ov_merge_max workgroups in all
                 // (HIPKKT_OV_MERGE, 0 = off), and never the first overlapped launch (its tiles are released by an event)
                 static const int ov_merge_max = std::getenv("HIPKKT_OV_MERGE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE")) : 100;
                 ov_merge_first = ~(size_t)0;
@@ -1087,10 +1090,12 @@ private:
                 ov_merge_lds = 0;
                 size_t m = launches.size();
                 int cnt = 0;
-                while (m > ov_first + 1 && launches[m - 1].nsliced == 0 && !launches[m - 1].small &&
-                       cnt + launches[m - 1].count <= std::min(ov_merge_max, ov_max)) {
-                    cnt += launches[m - 1].count;
-                    ov_merge_lds = std::max(ov_merge_lds, launches[m - 1].lds_panel);
+                ov_merge_sliced = !launches.empty() && launches.back().nsliced > 0;
+                while (m > ov_first + 1 && !launches[m - 1].small &&
+                       (ov_merge_sliced ? launches[m - 1].nsliced == launches[m - 1].count : launches[m - 1].nsliced == 0) &&
+                       cnt + panel_wgs(launches[m - 1]) <= std::min(ov_merge_max, ov_max)) {
+                    cnt += panel_wgs(launches[m - 1]);
+                    ov_merge_lds = std::max(ov_merge_lds, ov_merge_sliced ? launches[m - 1].lds_sliced : launches[m - 1].lds_panel);
                     --m;
                 }
                 if (launches.size() - m >= 2) { ov_merge_first = m; ov_merge_count = cnt; }
@@ -1603,8 +1608,9 @@ struct hipkkt_kkt_s {
     // residual SpMV
     DBuf<int64_t> fptr;
     DBuf<int> fcol, fmap;
-    DBuf<double> fval;               // K values in the CSR image's order, refreshed after every value change
-    bool fval_dirty = true;
+    DBuf<double> fval;               // K values in the CSR image's order: gathered whole after P / A changed (fval_dirty), kept
+    bool fval_dirty = true;          //   current by write-through from the cone update otherwise (kpos: two slots per K entry)
+    DBuf<int> kpos;
     // long rows of the image (kernels.hpp, SpmvDev)
     DBuf<int> long_rows;
     DBuf<int64_t> long_chunk_ptr, chunk_q;
@@ -2034,6 +2040,14 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
             h->fmap.upload(vmap);
             h->fval.alloc(vmap.size());
             {
+                std::vector<int> kp((size_t)2 * K.nnzK, -1);
+                for (size_t q = 0; q < vmap.size(); ++q) {
+                    const size_t e = (size_t)vmap[q];
+                    if (kp[2 * e] < 0) kp[2 * e] = (int)q; else kp[2 * e + 1] = (int)q;
+                }
+                h->kpos.upload(kp);
+            }
+            {
                 std::vector<int> lrows;
                 std::vector<int64_t> lptr{0}, cq;
                 for (int i = 0; i < N; ++i) {
@@ -2068,7 +2082,7 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
         h->cur_dx = h->dx.p;
         h->rx.alloc((size_t)K.n); h->rz.alloc((size_t)K.m);
         h->sbuf.alloc((size_t)K.m); h->zbuf.alloc((size_t)K.m); h->ybuf.alloc((size_t)K.m);
-        h->partial.alloc((size_t)std::max(2, kMaxNR) * (kNormParts + 1) + 8);
+        h->partial.alloc((size_t)std::max(2, kMaxNR) * (2 * kNormParts + 1) + 8);
         h->scal.alloc(16);               // [0] eps, [1] norme, [2] normb, [3] abort, [4] speculative norme, [8..11] update status
         HIP_CHECK(hipMemset(h->scal.p, 0, 16 * sizeof(double)));
         h->pin.reset(new PinnedScalars);
@@ -2159,11 +2173,12 @@ int hipkkt_kkt_info(hipkkt_kkt_t h, hipkkt_info* info)
 static int kkt_update_device(hipkkt_kkt_t h, bool deferred = false)
 {
     KKTAssembly& K = h->K;
-    h->fval_dirty = true;
     int pu = h->prof.begin(0, h->stream);
-    launch_scatter(h->Kval.p, h->mapHs.p, h->Hs.p, K.nHs, -1.0, h->stream);       // :225-228
-    launch_soc_columns(h->Kval.p, h->mapU.p, h->mapV.p, h->mapD.p, h->soc_u.p, h->soc_v.p, h->soc_eta2.p,
-                       h->soc_of_entry.p, K.sparse_len, K.nsparse, h->stream);     // :235-241
+    // -Hs (:225-228) and the sparse cones' columns (:235-241) in one launch, written through to the residual's copy of K
+    // when that copy is current (otherwise it is gathered whole before the next residual: kkt_spmv)
+    launch_update_values(h->Kval.p, h->mapHs.p, h->Hs.p, (int)K.nHs, h->mapU.p, h->mapV.p, h->mapD.p, h->soc_u.p, h->soc_v.p,
+                         h->soc_eta2.p, h->soc_of_entry.p, K.sparse_len, K.nsparse, h->fval_dirty ? nullptr : h->fval.p,
+                         h->kpos.p, h->stream);
     const double* eps_ptr = nullptr;
     if (h->st.static_regularization_enable) {                                      // :259-279
         launch_regularizer(h->Kval.p, h->mapDiag.p, K.N, h->st.static_regularization_constant,
@@ -2177,11 +2192,9 @@ static int kkt_update_device(hipkkt_kkt_t h, bool deferred = false)
     // read back: flags, eps, cone failure
     // (one small kernel gathers the four words, one copy into pinned memory brings them over: three separate
     // copies, two of them into pageable memory, cost ~60 us of idle GPU per update)
-    launch_collect_status(h->scal.p + 8, h->scal.p, h->fail.p, h->eng->flags_ptr(), h->stream);
-    if (deferred) {                  // no read-back: the status joins the sticky record (hipkkt_kkt_deferred_status)
-        launch_fold_update_status(h->ir_sticky, h->scal.p + 8, h->stream);
-        return HIPKKT_OK;
-    }
+    // (deferred: no read-back, the status joins the sticky record in the same launch -- hipkkt_kkt_deferred_status)
+    launch_collect_status(h->scal.p + 8, h->scal.p, h->fail.p, h->eng->flags_ptr(), h->stream, deferred ? h->ir_sticky : nullptr);
+    if (deferred) return HIPKKT_OK;
     HIP_CHECK(hipMemcpyAsync(h->pin->h + 8, h->scal.p + 8, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (h->pin->h[12] != 0.0) {                      // never expected; see LDLEngine::ov_gave_up: repeat level by level

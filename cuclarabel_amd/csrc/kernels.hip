@@ -28,6 +28,50 @@ void launch_scatter(double* K, const int* idx, const double* v, int64_t n, doubl
     if (n <= 0) return;
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(n, 256)), dim3(256), 0, st, K, idx, v, n, scale);
 }
+// The cone update of an iteration in ONE launch: -Hs into K (kktsolver_directldl.jl:225-228) and the sparse second-order
+// cones' columns u, v and D (:235-241), each value also written THROUGH to its one or two slots of the residual's
+// CSR-ordered copy (kpos: two slots per K entry, -1 = none) -- the copy used to be re-gathered whole (2.5 M entries,
+// 13 us) after every update although only these entries change.
+__device__ __forceinline__ void put_k(double* __restrict__ K, double* __restrict__ fval, const int* __restrict__ kpos, int e, double v)
+{
+    K[e] = v;
+    if (fval) {
+        const int p0 = kpos[2 * e], p1 = kpos[2 * e + 1];
+        if (p0 >= 0) fval[p0] = v;
+        if (p1 >= 0) fval[p1] = v;
+    }
+}
+__global__ void k_update_values(double* __restrict__ K, const int* __restrict__ mapHs, const double* __restrict__ Hs, int nHs,
+                                const int* __restrict__ mapU, const int* __restrict__ mapV, const int* __restrict__ mapD,
+                                const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ eta2,
+                                const int* __restrict__ soc_of_entry, int sparse_len, int nsparse,
+                                double* __restrict__ fval, const int* __restrict__ kpos)
+{
+    const int total = nHs + sparse_len + nsparse;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < nHs) {
+            put_k(K, fval, kpos, mapHs[i], -Hs[i]);
+        } else if (i < nHs + sparse_len) {
+            const int j = i - nHs;
+            const double e2 = eta2[soc_of_entry[j]];
+            put_k(K, fval, kpos, mapU[j], u[j] * (-e2));
+            put_k(K, fval, kpos, mapV[j], v[j] * (-e2));
+        } else {
+            const int j = i - nHs - sparse_len;
+            put_k(K, fval, kpos, mapD[2 * j], -eta2[j]);
+            put_k(K, fval, kpos, mapD[2 * j + 1], eta2[j]);
+        }
+    }
+}
+void launch_update_values(double* K, const int* mapHs, const double* Hs, int nHs, const int* mapU, const int* mapV,
+                          const int* mapD, const double* u, const double* v, const double* eta2, const int* soc_of_entry,
+                          int sparse_len, int nsparse, double* fval, const int* kpos, hipStream_t st)
+{
+    const int total = nHs + sparse_len + nsparse;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_update_values, dim3(grid_for(total, 256)), dim3(256), 0, st, K, mapHs, Hs, nHs, mapU, mapV, mapD, u, v,
+                       eta2, soc_of_entry, sparse_len, nsparse, fval, kpos);
+}
 __global__ void k_scale(double* __restrict__ K, const int* __restrict__ idx, double scale, int64_t n)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -127,7 +171,8 @@ __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __res
     partial += blockIdx.y * (gridDim.x + 1);
     const int sub = threadIdx.x % G;
     const int rows_per_block = 256 / G;
-    double vmax = 0.0, bmax = 0.0;           // bmax: ||b||_inf rides along when bpartial is given (one column only)
+    if (bpartial) bpartial += blockIdx.y * gridDim.x;
+    double vmax = 0.0, bmax = 0.0;           // bmax: ||b||_inf rides along when bpartial is given
     bool bad = false;
     for (int row = blockIdx.x * rows_per_block + threadIdx.x / G; row < A.N; row += gridDim.x * rows_per_block) {
         const int64_t q0 = A.ptr[row], q1 = A.ptr[row + 1];
@@ -217,12 +262,12 @@ __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, do
     // norm(e, Inf) of a vector holding Inf or NaN is not finite either way; the caller only
     // tests isfinite() (kktsolver_directldl.jl:411,429)
     if (threadIdx.x == 0) out[0] = v;
-    if (bpartial && blockIdx.x == 0) {
+    if (bpartial) {                          // (column blockIdx.x's ||b||: its partials sit nbparts apart)
         __syncthreads();
         double w = 0.0;
-        for (int i = threadIdx.x; i < nbparts; i += blockDim.x) w = fmax(w, bpartial[i]);
+        for (int i = threadIdx.x; i < nbparts; i += blockDim.x) w = fmax(w, bpartial[blockIdx.x * nbparts + i]);
         w = block_max_256(w, sh);
-        if (threadIdx.x == 0) bout[0] = w;
+        if (threadIdx.x == 0) bout[blockIdx.x] = w;
     }
 }
 void launch_residual(const SpmvDev& A, const double* K, const double* b, const double* x, double* e,
@@ -233,8 +278,9 @@ void launch_residual(const SpmvDev& A, const double* K, const double* b, const d
     int g = (A.N + rows_per_block - 1) / rows_per_block;
     if (g > kNormParts) g = kNormParts;
     if (g < 1) g = 1;
-    // ||b||_inf in the same pass (one column, no long rows: every row's b is read here anyway)
-    double* bpartial = (normb_out && nrhs == 1 && A.nlong == 0) ? partial + (g + 1) : nullptr;
+    // ||b||_inf in the same pass (no long rows: every row's b is read here anyway); partial then holds nrhs * (g + 1)
+    // residual partials followed by nrhs * g partials of b, at most kResidualPartial(nrhs) doubles
+    double* bpartial = (normb_out && nrhs <= kMaxNormbCols && A.nlong == 0) ? partial + (size_t)nrhs * (g + 1) : nullptr;
     if (A.lanes_per_row == 8)
         hipLaunchKernelGGL(k_residual<8>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
     else
@@ -394,19 +440,27 @@ void launch_zero_ints_multi(const ZeroList& Z, hipStream_t st)
 }
 // the value update's status words in one place, so that ONE small copy brings them to the host
 __global__ void k_collect_status(double* __restrict__ dst, const double* __restrict__ eps, const int* __restrict__ conefail,
-                                 const int* __restrict__ flags)
+                                 const int* __restrict__ flags, double* __restrict__ sticky)
 {
     if (threadIdx.x == 0) {
-        dst[0] = eps ? eps[0] : 0.0;
-        dst[1] = conefail ? (double)conefail[0] : 0.0;
-        dst[2] = (double)flags[0];
-        dst[3] = (double)flags[1];
-        dst[4] = (double)flags[2];       // an overlap-mode wait of the factorisation gave up
+        const double e = eps ? eps[0] : 0.0, cf = conefail ? (double)conefail[0] : 0.0;
+        const double f0 = (double)flags[0], f1 = (double)flags[1], f2 = (double)flags[2];
+        dst[0] = e;
+        dst[1] = cf;
+        dst[2] = f0;
+        dst[3] = f1;
+        dst[4] = f2;                     // an overlap-mode wait of the factorisation gave up
+        if (sticky) {                    // deferred status: folded into the sticky record here (k_fold_update_status's rule)
+            if (cf != 0.0 || f1 != 0.0) sticky[0] = 1.0;
+            if (f2 != 0.0) sticky[7] = 1.0;
+            sticky[4] += f0;
+            sticky[5] = e;
+        }
     }
 }
-void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st)
+void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st, double* sticky)
 {
-    hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(64), 0, st, dst, eps, conefail, flags);
+    hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(64), 0, st, dst, eps, conefail, flags, sticky);
 }
 // ---- the refinement loop's decisions on the device (kktsolver_directldl.jl:389-449).  State after round r
 // (slot r of `state`, 4 doubles): {active: the reference's loop would go on, rounds done, bad: a residual norm was not

@@ -276,6 +276,11 @@ constexpr int kLongChunk = 2048;
 // norm_out[j] = ||e_j||_inf (not finite if any entry is non-finite).  nrhs > 1: column j of b, x, e
 // at stride ld; `partial` then needs nrhs * (kNormParts + 1) doubles
 constexpr int kNormParts = 2048;   // partial needs nrhs * (kNormParts + 1) doubles
+constexpr int kMaxNormbCols = 4;   // ||b|| rides along in the residual pass for up to this many columns: partial then needs
+                                   // nrhs * (2 kNormParts + 1) doubles
+void launch_update_values(double* K, const int* mapHs, const double* Hs, int nHs, const int* mapU, const int* mapV,
+                          const int* mapD, const double* u, const double* v, const double* eta2, const int* soc_of_entry,
+                          int sparse_len, int nsparse, double* fval, const int* kpos, hipStream_t st);
 // flag_in/flag_out (nullable): *flag_out = (*flag_in != 0) as a double, so that a device status word rides along
 // with the norm read-back
 void launch_residual(const SpmvDev& A, const double* Kval, const double* b, const double* x, double* e,
@@ -329,7 +334,8 @@ struct ZeroList {
 };
 void launch_zero_ints_multi(const ZeroList& Z, hipStream_t st);      // up to eight arrays in one launch
 // dst[0..4] = {eps[0], conefail[0], flags[0], flags[1], flags[2]} (null pointers read as 0)
-void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st);
+// sticky (nullable): also fold the words into the deferred-status record (what launch_fold_update_status does)
+void launch_collect_status(double* dst, const double* eps, const int* conefail, const int* flags, hipStream_t st, double* sticky = nullptr);
 
 // ---- cone scalings on the device (update_scaling! + get_Hs!, src/cones/coneops_*.jl)
 struct ConeDev {
