@@ -645,7 +645,9 @@ def main():
     level_b = {}
     system.set_lazy(not args.sequential_solves)
     ks.set_deferred_status(not args.sync_status)
-    for name, batched in (("batched_2col", True), ("three_single_solves", False)):
+    # (--sequential-solves is the profiling configuration -- scripts/profile_bench.sh: every sweep of the run single-column,
+    #  so that traffic per sweep pair is well defined -- and leaves the level-B passes out)
+    for name, batched in (() if args.sequential_solves else (("batched_2col", True), ("three_single_solves", False))):
         unit(ks, st, batched, may_repeat=True)
         barrier()
         t0 = time.perf_counter()
@@ -742,6 +744,8 @@ def main():
                        "mode), combined alone (3 solves per step); ms_per_step_sequential_solves is the same step with "
                        "kkt_update! solving the constant right-hand side itself (three single-column solves)"),
             "fallbacks": {"overlap": fb2[0], "top": fb2[1], "in_timed_region": 0},
+            # value updates (= factorisations) this process has run, for per-launch averages of profiler counters
+            "updates_in_run": args.warmup + 3 * args.steps + 1 + (0 if args.sequential_solves else 2 * (args.steps + 1)),
             # rounds 1-2 quoted this: level B alone (no right-hand-side construction / step recovery), deferred status
             "level_B_ms_per_step": level_b,
             "ms_per_step_instrumented": elapsed_profiled / args.steps * 1e3,

@@ -61,8 +61,9 @@ if not have_bench:
               open(os.path.join(dst, f"{tag}_traffic_summary.json"), "w"), indent=1)
     sys.exit(0)
 bench = json.loads(open(os.path.join(src, "bench.json")).read())
-# bench.py runs the steps three times (timed, un-instrumented sequential, instrumented sequential) after the warm-up
-steps = 3 * bench["steps"] + bench["warmup"]
+# bench.py runs the steps three times (timed, un-instrumented sequential, instrumented sequential) after the warm-up;
+# from round 3 on its line says how many value updates (factorisations) the process ran
+steps = bench.get("updates_in_run", 3 * bench["steps"] + bench["warmup"])
 TRI = ("k_fwd", "k_bwd", "k_top_solve")
 FAC = ("k_panel", "k_schur", "k_front", "k_subtree", "k_tinv", "k_winv")
 
