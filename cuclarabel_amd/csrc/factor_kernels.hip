@@ -47,13 +47,16 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 // wall clock; on expiry flags[2] is set, everyone leaves, and the host repeats the factorisation level by level.
 #define OV_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define OV_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-__device__ inline bool ov_wait_ge(const int* counter, int target, int* abort_word, long long t0, long long limit)
+// (who / info: which wait expired first -- 1 a panel for a child's tiles, 2 a tile for its panel's blocks, 3 the gate -- and
+//  the supernode or launch it waited for: abort_word[1..4], printed with the fall-back message)
+__device__ inline bool ov_wait_ge(const int* counter, int target, int* abort_word, long long t0, long long limit, int who = 0, int info = 0)
 {
     for (;;) {
-        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        const int seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= target) return true;
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         if (wall_clock64() - t0 > limit) {            // (50 ms at 100 MHz: far beyond any real factorisation step)
-            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (atomicCAS(abort_word, 0, 1) == 0) { abort_word[1] = who; abort_word[2] = info; abort_word[3] = seen; abort_word[4] = target; }
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
             for (int e = T.child_ptr[s] + lane; e < T.child_ptr[s + 1]; e += 64) {
                 const int c = T.child_idx[e];
                 const int need = A.ov_ntiles[c];
-                if (need > 0) ok = ov_wait_ge(A.ov_done + c, need, A.flags + 2, tw, A.ov_limit) && ok;
+                if (need > 0) ok = ov_wait_ge(A.ov_done + c, need, A.flags + 2, tw, A.ov_limit, 1, c) && ok;
             }
             if (!ok) sh_ov_ok = 0;
         }
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
                 bool ok = true;
                 const int sb = A.ov_sbase[s];
                 if (sb < 0) {
-                    ok = ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw, A.ov_limit);
+                    ok = ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw, A.ov_limit, 2, s);
                 } else {
                     // a front factorised in row slices: the slices that hold this tile's two strips, and the first one
                     // (it publishes the top block, whose diagonal the product scales with)
@@ -940,11 +943,35 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
 // whatever the hardware's dispatch order (forward progress by induction over the launches, not by submission order).
 __global__ __launch_bounds__(64) void k_ov_gate(const int* __restrict__ started, int target, int* abort_word, long long limit)
 {
-    if (threadIdx.x == 0) (void)ov_wait_ge(started, target, abort_word, wall_clock64(), limit);
+    if (threadIdx.x == 0) (void)ov_wait_ge(started, target, abort_word, wall_clock64(), limit, 3, target);
 }
 void launch_ov_gate(const int* started, int target, int* abort_word, long long limit, hipStream_t st)
 {
     hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, st, started, target, abort_word, limit);
+}
+
+// Do two streams really run side by side?  HIP multiplexes a process's streams onto a few hardware queues; two streams
+// that share one execute their kernels in submission order.  k_probe_wait (first stream) spins until k_probe_set (second
+// stream, submitted AFTER it) has stored the word, or a bound of ~2 ms passes: word[1] = 1 if it saw the store.
+__global__ __launch_bounds__(64) void k_probe_wait(int* word)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    int seen = 0;
+    while (wall_clock64() - t0 < 200000) {               // 2 ms at 100 MHz
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    word[1] = seen;
+}
+__global__ __launch_bounds__(64) void k_probe_set(int* word)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_concurrency_probe(int* word2, hipStream_t first, hipStream_t second)
+{
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, first, word2);
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(64), 0, second, word2);
 }
 
 size_t panel_lds_bytes(int fmax, int panel_max)

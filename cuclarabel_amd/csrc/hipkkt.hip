@@ -341,6 +341,28 @@ private:
             }
         }
         const bool ov_on = use_ov && !ov_disabled;
+        if (ov_on && ov_probed_stream != st) {
+            // The merged panel kernel of the narrow top (below) waits for tile kernels that are submitted BEHIND it: that
+            // needs the two streams on different hardware queues.  HIP multiplexes streams onto a few queues (a process
+            // with many handles has more streams than queues), and streams that share one run in submission order -- the
+            // merged kernel would then wait for its 50 ms bound (seen with eight handles in one process: two of them).
+            // Asked once per (handle, stream): a kernel on the main stream waits up to 2 ms for a kernel submitted after
+            // it on the tile stream.  Without concurrency every level keeps its own panel kernel, whose waits only ever
+            // look at work submitted earlier (panel L, tiles L, panel L + 1, ...: correct on one queue as well).
+            int* w = flags.p + 8;
+            launch_zero_ints(w, 2, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+            launch_concurrency_probe(w, st, ov_stream);
+            int seen[2] = {0, 0};
+            HIP_CHECK(hipMemcpyAsync(seen, w, sizeof(seen), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            HIP_CHECK(hipStreamSynchronize(ov_stream));
+            ov_concurrent = seen[1] != 0;
+            ov_probed_stream = st;
+            if (!ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
+                std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
+        }
+        const size_t merge_from = ov_concurrent ? ov_merge_first : ~(size_t)0;
         if (ov_on) {
             zl.add(d_ov_prog.p, S.nsuper);
             zl.add(d_ov_done.p, S.nsuper);
@@ -406,7 +428,7 @@ private:
             // which the next sweep's bottom levels hide
             // (with the top launches' panels merged into one kernel, the last fork sits in front of that kernel: an event
             //  behind it would wait for the whole top of the tree)
-            const size_t tail_fork = (ov_on && ov_merge_first < nl) ? ov_merge_first : (nl >= kWinvTailLaunches ? nl - kWinvTailLaunches : 0);
+            const size_t tail_fork = (ov_on && merge_from < nl) ? merge_from : (nl >= kWinvTailLaunches ? nl - kWinvTailLaunches : 0);
             if (first_top < nl && (q + kWinvEarlyLaunches == first_top || q == first_top ||
                                    (q > first_top && q == tail_fork)) && launches[q].tinv_begin > w_done) {
                 ensure_capture_streams();
@@ -434,7 +456,7 @@ private:
                 // children are still being factorised, and then waits for its children's tiles -- a level of the narrow
                 // top costs its critical path (children's assembly, block loop, tiles) without a kernel boundary and
                 // launch ramp in between.  Workgroups are dispatched in schedule order, i.e. lower levels first.
-                const bool merged = q >= ov_merge_first;
+                const bool merged = q >= merge_from;
                 a.ov_slot = merged ? (int)ov_merge_first : (int)q;
                 if (!merged) {
                     launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
@@ -759,6 +781,53 @@ public:
     {
         ov_disabled = true;
         ++n_ov_fallbacks;
+        if (std::getenv("HIPKKT_VERBOSE")) {            // which wait expired first (factor_kernels.hip, ov_wait_ge)
+            int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpy(w, flags.p, sizeof(w), hipMemcpyDeviceToHost);
+            const int sn = w[4];
+            std::fprintf(stderr, "[hipkkt] expired wait: kind %d (1 panel for a child's tiles, 2 tile for its panel, 3 gate), waited for %d "
+                         "(saw %d of %d)", w[3], sn, w[5], w[6]);
+            if ((w[3] == 1 || w[3] == 2) && sn >= 0 && sn < S.nsuper) {
+                int q = -1;
+                for (size_t k = 0; k < sched.size(); ++k) if (sched[k] == sn) q = (int)k;
+                size_t lq = 0;
+                while (lq < launches.size() && !(q >= launches[lq].begin && q < launches[lq].begin + launches[lq].count)) ++lq;
+                std::fprintf(stderr, "; supernode %d is in launch %zu of %zu (overlap from %zu, merged from %zu), level %d, parent %d", sn, lq,
+                             launches.size(), ov_first, ov_merge_first, lq < launches.size() ? launches[lq].level : -1, S.sn_parent[sn]);
+            }
+            std::fprintf(stderr, "\n");
+            // the lowest overlapped launch with unfinished fronts: progress of its panels and tiles as the abort left them
+            std::vector<int> prog((size_t)S.nsuper), done((size_t)S.nsuper), nt((size_t)S.nsuper), started(launches.size());
+            (void)hipMemcpy(prog.data(), d_ov_prog.p, prog.size() * sizeof(int), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(done.data(), d_ov_done.p, done.size() * sizeof(int), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(nt.data(), d_ov_ntiles.p, nt.size() * sizeof(int), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(started.data(), d_ov_started.p, started.size() * sizeof(int), hipMemcpyDeviceToHost);
+            int shown = 0;
+            for (size_t q = ov_first; q < launches.size() && shown < 12; ++q) {
+                const Launch& L = launches[q];
+                int unfinished = 0;
+                for (int t = L.begin; t < L.begin + L.count; ++t) {
+                    const int s2 = sched[(size_t)t];
+                    const int ncs = S.sn_start[s2 + 1] - S.sn_start[s2];
+                    if (prog[(size_t)s2] < ncs || done[(size_t)s2] < nt[(size_t)s2]) {
+                        if (shown < 12) {
+                            std::fprintf(stderr, "[hipkkt]   launch %zu (started %d) position %d supernode %d: %d of %d columns published, %d of %d tiles done, "
+                                         "%d children:", q, started[q], t - L.begin, s2, prog[(size_t)s2], ncs, done[(size_t)s2], nt[(size_t)s2],
+                                         S.child_ptr[s2 + 1] - S.child_ptr[s2]);
+                            for (int e = S.child_ptr[s2]; e < S.child_ptr[s2 + 1]; ++e) {
+                                const int c = S.child_idx[e];
+                                if (nt[(size_t)c] > 0) std::fprintf(stderr, " %d(%d/%d)", c, done[(size_t)c], nt[(size_t)c]);
+                            }
+                            std::fprintf(stderr, " | merged kernel: %d of %d workgroups started", ov_merge_first < launches.size() ? started[ov_merge_first] : -1, ov_merge_count);
+                            std::fprintf(stderr, "\n");
+                            ++shown;
+                        }
+                        ++unfinished;
+                    }
+                }
+                if (unfinished) std::fprintf(stderr, "[hipkkt]   launch %zu: %d of %d fronts unfinished, %d tiles\n", q, unfinished, L.count, L.ntiles);
+            }
+        }
         std::fprintf(stderr, "[hipkkt] factorisation overlap gave up waiting; falling back to one level after the other\n");
     }
     static bool overlap_wanted()
@@ -819,6 +888,8 @@ private:
     int ov_merge_count = 0;          // panel workgroups of that kernel (whole fronts, or row slices: ov_merge_sliced)
     size_t ov_merge_lds = 0;
     bool ov_merge_sliced = false;
+    bool ov_concurrent = false;          // the main and the tile stream run side by side (asked once per stream: enqueue_factor)
+    hipStream_t ov_probed_stream = (hipStream_t)(-1);
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
     hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
@@ -1494,10 +1565,10 @@ private:
         Dinv.alloc((size_t)S.N);
         xp.alloc((size_t)S.N);
         uvec.alloc(S.rows.size());
-        flags.alloc(4);
+        flags.alloc(12);      // [0..2] status words, [3..6] which wait expired (diagnostic), [8..9] concurrency probe
         HIP_CHECK(hipMemset(fronts.p, 0, std::max<size_t>(fronts.n, 1) * sizeof(double)));
         HIP_CHECK(hipMemset(Dinv.p, 0, std::max<size_t>(Dinv.n, 1) * sizeof(double)));
-        HIP_CHECK(hipMemset(flags.p, 0, 4 * sizeof(int)));
+        HIP_CHECK(hipMemset(flags.p, 0, 12 * sizeof(int)));
     }
 };
 

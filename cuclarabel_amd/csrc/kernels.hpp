@@ -224,6 +224,9 @@ void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, 
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid = 0);
 // overlap mode: returns (the stream goes on) once *started >= target, i.e. every panel workgroup of the launch is resident
 void launch_ov_gate(const int* started, int target, int* abort_word, long long limit, hipStream_t st);
+// word2[0] must be 0; afterwards word2[1] = 1 iff a kernel on `second`, submitted behind a waiting kernel on `first`, ran
+// while that one waited -- i.e. the two streams do not share a hardware queue
+void launch_concurrency_probe(int* word2, hipStream_t first, hipStream_t second);
 size_t panel_lds_bytes(int fmax, int panel_max);
 // nr = 1, 2 or 4 right-hand sides per launch (column strides in SolveArgs::ld_*); lds = bytes per right-hand side
 void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);

@@ -1215,3 +1215,51 @@ def test_overlap_admission_and_gate(maker, env):
     assert m and len(rows) == int(m.group(1)), r.stderr
     for _, panels, ntiles, cus in rows:
         assert int(panels) + 1 + 8 <= int(cus), (rows, env)
+
+
+def test_many_handles_in_one_process():
+    """A process with many handles has more HIP streams than hardware queues, and streams that share a queue run their
+    kernels in submission order.  The overlap mode's per-level kernels only ever wait for work submitted earlier, but the
+    merged panel kernel of the narrow top waits for tile kernels submitted BEHIND it: with eight handles in one process two
+    of them used to give up (50 ms each) until the library started to ask, per handle, whether its two streams really run
+    side by side (enqueue_factor's probe).  Twelve handles, factorised and solved in turn, twice: no fallback on any of
+    them, every solution matches the oracle's, same refinement rounds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver
+from tests.oracle_bindings import make_oracle
+pbs = [problems.config2(seed=2000 + j, n=20000) for j in range(12)]
+hs = [HipKKTSolver(pb.P, pb.A, pb.cones) for pb in pbs]
+rng = np.random.default_rng(4)
+rhs = [(rng.standard_normal(pb.n), rng.standard_normal(pb.m)) for pb in pbs]
+sols = []
+for rep in range(2):
+    for ks, pb, (rx, rz) in zip(hs, pbs, rhs):
+        assert ks.kktsolver_update_from_sz(pb.s0 * (1.0 + 0.1 * rep), pb.z0)
+        ks.kktsolver_setrhs(rx, rz)
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        if rep == 1:
+            sols.append((x, z, ks.last_ir_iterations))
+assert all(ks.fallbacks == (0, 0) for ks in hs), [ks.fallbacks for ks in hs]
+for j in (0, 5, 11):
+    pb, (rx, rz), (x, z, ir) = pbs[j], rhs[j], sols[j]
+    o = make_oracle(pb, perm=hs[j].perm())
+    assert o.update_scaling(pb.s0 * 1.1, pb.z0) and o.kktsolver_update()
+    o.kktsolver_setrhs(rx, rz)
+    ok, xo, zo = o.kktsolver_solve()
+    assert ok and ir == o.last_ir_iters, (j, ir, o.last_ir_iters)
+    assert max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()) < 1e-9
+print("MANY HANDLES OK")
+"""
+    r = subprocess.run([sys.executable, "-c", script.format(root=root)], env=dict(os.environ, HIPKKT_VERBOSE="1"), cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MANY HANDLES OK" in r.stdout and "gave up" not in r.stderr, r.stderr
