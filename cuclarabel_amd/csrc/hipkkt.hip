@@ -1118,7 +1118,7 @@ private:
             d_ksrc.upload(ks_all);
         }
         d_sched.upload(sched);
-        d_tiles.upload(tiles);
+        // (d_tiles is uploaded with the tile work lists below: the launch order of a level's tiles may be permuted there)
         {
             // Overlap admission.  In overlap mode a level's PANEL workgroups (each needs a CU to itself: ~150 KB of LDS) run
             // beside the level's TILE workgroups on the overlap stream (53 KB: they fit beside each other, but one of them
@@ -1546,6 +1546,52 @@ private:
                 }
                 tcut[t * 5 + 4] = I1;
             }
+            {
+                // XCD-aware launch order of a wide level's tiles (HIPKKT_TILE_XCD=n: launches with at least n fronts;
+                // 0 = off): workgroup i of a launch runs on XCD i mod 8, each XCD has its own L2, and every tile of a front
+                // reads that front's L21 strips -- a front's tiles are dealt to ONE residue class (eight fronts interleaved,
+                // fronts in work order so that a group's fronts have similar tile counts), so its strips come from HBM
+                // once instead of once per XCD that happens to hold one of its tiles.
+                // Measured on cfg2 (rocprofv3 --pmc FETCH_SIZE, r03): k_schur's reads 838 -> 525 MB per factorisation with the
+                // wide levels (>= 150 fronts) permuted, factorisation 1.754 / 1.760 -> 1.743 / 1.751 ms; permuting the narrow
+                // levels as well costs time (>= 32: 1.766 / 1.770 -- a handful of fronts' tiles then crowd one XCD).
+                static const int tile_xcd = std::getenv("HIPKKT_TILE_XCD") ? std::atoi(std::getenv("HIPKKT_TILE_XCD")) : 150;
+                if (tile_xcd > 0) {
+                    std::vector<int64_t> nt2(tiles.size()), nc2(tcut.size(), 0);
+                    nt2 = tiles;
+                    nc2 = tcut;
+                    for (const Launch& L : launches) {
+                        if (L.small || L.count < tile_xcd || L.ntiles <= 0) continue;
+                        // the launch's fronts and their (contiguous) logical tile ranges
+                        std::vector<std::pair<int64_t, int64_t>> rng;       // [first, last) per front, launch order
+                        for (int t = L.begin; t < L.begin + L.count; ++t) {
+                            const int sn = sched[(size_t)t];
+                            if (tile_base[sn] < 0) continue;
+                            const int nb = front_size(sn) - (S.sn_start[sn + 1] - S.sn_start[sn]);
+                            const int k = (nb + 63) / 64;
+                            if (k > 0) rng.push_back({tile_base[sn], tile_base[sn] + (int64_t)k * (k + 1) / 2});
+                        }
+                        int64_t pos = L.tile_begin;
+                        for (size_t g0 = 0; g0 < rng.size(); g0 += 8) {
+                            const size_t g1 = std::min(rng.size(), g0 + 8);
+                            int64_t longest = 0;
+                            for (size_t x = g0; x < g1; ++x) longest = std::max(longest, rng[x].second - rng[x].first);
+                            for (int64_t j = 0; j < longest; ++j)
+                                for (size_t x = g0; x < g1; ++x)
+                                    if (rng[x].first + j < rng[x].second) {
+                                        const int64_t from = rng[x].first + j;
+                                        nt2[(size_t)pos] = tiles[(size_t)from];
+                                        for (int w = 0; w < 5; ++w) nc2[(size_t)pos * 5 + w] = tcut[(size_t)from * 5 + w];
+                                        ++pos;
+                                    }
+                        }
+                        if (pos != (int64_t)L.tile_begin + L.ntiles) throw std::runtime_error("tile permutation lost a tile");
+                    }
+                    tiles.swap(nt2);
+                    tcut.swap(nc2);
+                }
+            }
+            d_tiles.upload(tiles);
             std::vector<int64_t> raw2(sit.size() * 2);
             std::memcpy(raw2.data(), sit.data(), sit.size() * sizeof(SubItem));
             d_sitems.upload(raw2);
