@@ -238,6 +238,11 @@ private:
     {
         const int KP = (nrhs + 15) & ~15;
         if (KP / 8 > 65535) throw ArgError("solve_multi: too many right-hand sides per call");
+        {   // the block kernels' grid.y is (fronts of a launch / 8) x (column blocks of 16)
+            int64_t widest = 0;
+            for (const Launch& L : launches) if (!L.small) widest = std::max<int64_t>(widest, (L.count + 7) / 8);
+            if (widest * (KP / 16) > 65535) throw ArgError("solve_multi: too many right-hand sides per call for this structure (split the call)");
+        }
         wait_w(stream);
         if ((size_t)KP > multi_cap) {
             xp_m.alloc((size_t)S.N * KP);

@@ -1906,22 +1906,26 @@ __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int 
 // out = W Ys on the matrix cores; rows below the diagonal block gather their children's contributions
 // in the epilogue (they are only needed there).
 template <int BS>
-__global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int KP)
+__global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int count, int KP)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 15, mk = lane >> 4;
     const TreeDev& T = A.T;
-    // (grid.x = column block, grid.y = front: the workgroups that share a front's W are dispatched together, so W comes
-    //  from HBM once per XCD instead of once per column block)
-    const FrontDesc fd = T.desc[begin + blockIdx.y];
+    // Grid (8, ceil(count / 8) * column blocks): workgroup (x, y) takes front 8 (y / ncb) + x and column block y % ncb.  A
+    // launch's workgroups go to the XCDs round-robin by linear index, i.e. by x here: all column blocks of a front run on
+    // ONE XCD and share its L2, so the front's W comes from HBM once instead of once per XCD (or per column block).
+    const int ncb = KP / kMultiCB;
+    const int fi = 8 * ((int)blockIdx.y / ncb) + (int)blockIdx.x, cbk = (int)blockIdx.y % ncb;
+    if (fi >= count) return;
+    const FrontDesc fd = T.desc[begin + fi];
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ W = A.tinv + fd.w_off;                  // f x nc, ld f
-    double* __restrict__ xp = A.xp + blockIdx.x * kMultiCB;
-    double* __restrict__ uvec = A.uvec + blockIdx.x * kMultiCB;
+    double* __restrict__ xp = A.xp + cbk * kMultiCB;
+    double* __restrict__ uvec = A.uvec + cbk * kMultiCB;
     const int ncp = (nc + 3) & ~3;
     double* Ys = smem;                       // ncp x 16 row-major
 
@@ -2040,19 +2044,22 @@ __device__ inline int bwd_multi_slices(int nt, int f, int nwaves)
     return ns < 1 ? 1 : ns;
 }
 template <int BS>
-__global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int KP)
+__global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int count, int KP)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 15, mk = lane >> 4;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.y];
+    const int ncb = KP / kMultiCB;                    // (grid as in k_fwd_block_m: a front's column blocks on one XCD)
+    const int fi = 8 * ((int)blockIdx.y / ncb) + (int)blockIdx.x, cbk = (int)blockIdx.y % ncb;
+    if (fi >= count) return;
+    const FrontDesc fd = T.desc[begin + fi];
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;       // W'(j, r) at j + r*nc
-    double* __restrict__ xp = A.xp + blockIdx.x * kMultiCB;
+    double* __restrict__ xp = A.xp + cbk * kMultiCB;
     const int nt = (nc + 15) >> 4;
     constexpr int NW = BS / 64;
     const int ns = bwd_multi_slices(nt, f, NW);
@@ -2155,8 +2162,9 @@ void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     }
     const size_t lds = (size_t)((ncmax + 3) & ~3) * 16 * sizeof(double);
     // many column blocks: smaller workgroups, more fronts in flight (measured: 256 columns 21.4 vs 23.4 ms)
-    if (KP >= 128) hipLaunchKernelGGL(k_fwd_block_m<256>, dim3(KP / kMultiCB, count), dim3(256), lds, st, a, begin, KP);
-    else hipLaunchKernelGGL(k_fwd_block_m<512>, dim3(KP / kMultiCB, count), dim3(512), lds, st, a, begin, KP);
+    const dim3 grid(8, ((count + 7) / 8) * (KP / kMultiCB));
+    if (KP >= 128) hipLaunchKernelGGL(k_fwd_block_m<256>, grid, dim3(256), lds, st, a, begin, count, KP);
+    else hipLaunchKernelGGL(k_fwd_block_m<512>, grid, dim3(512), lds, st, a, begin, count, KP);
 }
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st)
 {
@@ -2168,8 +2176,9 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     // at most max(8, nt) partial tiles of 16 x 16
     const int nt = (ncmax + 15) >> 4;
     const size_t lds = (size_t)std::max(8, nt) * 256 * sizeof(double);
-    if (KP >= 128) hipLaunchKernelGGL(k_bwd_block_m<256>, dim3(KP / kMultiCB, count), dim3(256), lds, st, a, begin, KP);
-    else hipLaunchKernelGGL(k_bwd_block_m<512>, dim3(KP / kMultiCB, count), dim3(512), lds, st, a, begin, KP);
+    const dim3 grid(8, ((count + 7) / 8) * (KP / kMultiCB));
+    if (KP >= 128) hipLaunchKernelGGL(k_bwd_block_m<256>, grid, dim3(256), lds, st, a, begin, count, KP);
+    else hipLaunchKernelGGL(k_bwd_block_m<512>, grid, dim3(512), lds, st, a, begin, count, KP);
 }
 
 // resident workgroups the device guarantees for the persistent kernel with `lds` bytes of dynamic LDS (the 1024-thread
