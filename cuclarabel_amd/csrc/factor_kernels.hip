@@ -484,6 +484,32 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
         __syncthreads();
         if (!sh_ov_ok) return;
     }
+    // ---- 3a. the dense child, if any (TreeDev::dense_off): entry (r, j) of its update block is entry (r, j) of this
+    //          front -- column by column, coalesced, eight loads per thread in flight; every thread owns its entries, the
+    //          barrier separates them from the waves' item adds below
+    {
+        const int64_t doff = T.dense_off[s];
+        if (doff >= 0) {
+            const double* __restrict__ Uc = A.upd + doff;
+            const int total = f * nc;                                  // (rectangle walked, entries above the diagonal skipped)
+            for (int base = 0; base < total; base += 8 * BS) {
+                double v[8];
+                int tg[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int idx = base + q * BS + tid;
+                    const int j = idx / f, rl = idx - j * f;
+                    const int r = (!SLICED || rl < nc) ? rl : r_lo + (rl - nc);       // row of the whole front
+                    const bool ok = idx < total && rl >= j;
+                    tg[q] = ok ? rl + pcol(j, f) : -1;
+                    v[q] = ok ? (OV ? OV_LD(Uc + r + (int64_t)j * ff) : Uc[r + (int64_t)j * ff]) : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (tg[q] >= 0) P[tg[q]] += v[q];
+            }
+            __syncthreads();
+        }
+    }
     // ---- 3. children: each wave applies its slice of whole columns' items
     if (A.stamps && blockIdx.x == 0 && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -762,7 +788,7 @@ constexpr int LDA = TS + 16;    // k-rows 80 doubles apart: consecutive k land 3
 // is how a bounded tile grid was tried for the overlap mode's forward-progress guarantee; measured +0.1 ms on cfg2's
 // factorisation.  The guarantee comes from the gate below instead and the grid is the number of tiles.)
 template <bool OV>
-__global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin, int ntiles)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OV ? 3 : 4))) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin, int ntiles)
 {
     // the operand chunks are dead once the product is done: the tile buffer shares their LDS (33 KB per
     // workgroup instead of 53 KB -> one more workgroup per CU)
@@ -835,8 +861,21 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
             }
         }
     };
+    // the dense child (TreeDev::dense_off): entry (i, j) of this front's update block receives entry (nc + i, nc + j)
+    // of the child's (leading dimension f) -- a plain block copy, no lists
+    auto dense_ptr = [&]() -> const double* {
+        const int64_t doff = T.dense_off[s];
+        return doff >= 0 ? A.upd + doff + (int64_t)(nc + r0) + (int64_t)(nc + q0) * f : nullptr;
+    };
     if (OV) {
-        for (int idx = tid; idx < TS * (TS + 1); idx += 256) (&Ct[0][0])[idx] = 0.0;
+        const double* __restrict__ Ud = dense_ptr();
+        auto dense_at = [&](int a, int b) -> double {
+            return (Ud && a < nr && b < nq && (r0 + a) >= (q0 + b)) ? Ud[a + (int64_t)b * f] : 0.0;
+        };
+        for (int idx = tid; idx < TS * (TS + 1); idx += 256) {
+            const int b = idx / (TS + 1), a = idx - b * (TS + 1);
+            (&Ct[0][0])[idx] = dense_at(a < TS ? a : nr, b);
+        }
         if (tid == 0) *sh_ok = 1;
         __syncthreads();
         pass_through();
@@ -921,11 +960,32 @@ __global__ __launch_bounds__(256) void k_schur(FactorArgs A, const int2* __restr
     if (!OV) pass_through();
     __syncthreads();
     // store the lower part of the tile
-    for (int idx = tid; idx < TS * TS; idx += 256) {
-        const int b = idx >> 6, a = idx & 63;
-        if (a < nr && b < nq && (r0 + a) >= (q0 + b)) {
-            if (OV) OV_ST(U + (r0 + a) + (int64_t)(q0 + b) * nb, Ct[b][a]);
-            else U[(r0 + a) + (int64_t)(q0 + b) * nb] = Ct[b][a];
+    const double* __restrict__ Ud = OV ? nullptr : dense_ptr();
+    if (!OV && Ud) {
+        auto dense_at = [&](int a, int b) -> double {
+            return (a < nr && b < nq && (r0 + a) >= (q0 + b)) ? Ud[a + (int64_t)b * f] : 0.0;
+        };
+        // (non-overlap launches add the dense child's entries here, four loads per thread in flight: fetched earlier
+        // and held across the product or the lists they cost the kernel a quarter of its occupancy)
+#pragma unroll 1
+        for (int base = 0; base < TS * TS; base += 4 * 256) {
+            double dv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int idx = base + q * 256 + tid; dv[q] = dense_at(idx & 63, idx >> 6); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = base + q * 256 + tid;
+                const int b = idx >> 6, a = idx & 63;
+                if (a < nr && b < nq && (r0 + a) >= (q0 + b)) U[(r0 + a) + (int64_t)(q0 + b) * nb] = Ct[b][a] + dv[q];
+            }
+        }
+    } else {
+        for (int idx = tid; idx < TS * TS; idx += 256) {
+            const int b = idx >> 6, a = idx & 63;
+            if (a < nr && b < nq && (r0 + a) >= (q0 + b)) {
+                if (OV) OV_ST(U + (r0 + a) + (int64_t)(q0 + b) * nb, Ct[b][a]);
+                else U[(r0 + a) + (int64_t)(q0 + b) * nb] = Ct[b][a];
+            }
         }
     }
     if (OV) {

@@ -868,6 +868,7 @@ private:
     DBuf<int> d_cuts;            // first child-row index reaching each 64-row tile boundary of the parent's U
     DBuf<int64_t> d_item_ptr;
     DBuf<int64_t> d_items;       // ExtItem = 4 x int64
+    DBuf<int64_t> d_dense_off;   // per supernode: offset of its dense child's update block (-1: none)
     DBuf<int64_t> d_wave_cut;
     DBuf<int64_t> d_sitems;      // SubItem = 2 x int64
     DBuf<int64_t> d_tile_cut;
@@ -916,7 +917,7 @@ private:
         t.ncolpar = d_ncolpar.p; t.front_off = d_front_off.p; t.upd_off = d_upd_off.p;
         t.child_ptr = d_child_ptr.p; t.child_idx = d_child_idx.p; t.kptr = d_kptr.p;
         t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
-        t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p; t.udst = d_udst.p;
+        t.dense_off = d_dense_off.p; t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p; t.udst = d_udst.p;
         t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
         t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p; t.desc = (const FrontDesc*)d_desc.p; t.sdesc = (const FrontDesc*)d_sdesc.p;
         t.spos = d_spos.p; t.sn_parent = d_sn_parent.p;
@@ -1394,10 +1395,36 @@ private:
             // column it lands in, children in fixed order -- a wave handles eight pieces at a time, all of them
             // a single load round, however long the child's column is
             static_assert(sizeof(ExtItem) == 32, "ExtItem layout");
+            // DENSE CHILD: a child whose update block IS its parent's whole front (same rows in the same order: the
+            // previous panel of a supernode that was cut into panels, the lower front of a chain) needs no work lists at
+            // all -- parent entry (r, j) receives child entry (r, j).  The panel kernel and the Schur tiles add it as a
+            // dense block (coalesced loads, no descriptors, no row lookups); its pieces stay out of both lists.
+            std::vector<int> dense_child((size_t)S.nsuper, -1);
+            std::vector<int64_t> dense_off((size_t)S.nsuper, -1);
+            static const bool dense_on = !(std::getenv("HIPKKT_DENSE_CHILD") && std::atoi(std::getenv("HIPKKT_DENSE_CHILD")) == 0);
+            int64_t n_dense = 0;
+            for (int p = 0; dense_on && p < S.nsuper; ++p) {
+                if (tile_base[p] < 0) continue;                              // block-class parents only
+                const int fp = front_size(p);
+                for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {
+                    const int c = S.child_idx[e];
+                    const int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
+                    if (nbc != fp) continue;
+                    bool ident = true;
+                    for (int q = 0; ident && q < nbc; ++q) ident = S.rel[S.rowptr[c] + q] == q;
+                    if (!ident) continue;
+                    dense_child[(size_t)p] = c;
+                    dense_off[(size_t)p] = S.upd_off[c];
+                    ++n_dense;
+                    break;
+                }
+            }
+            d_dense_off.upload(dense_off);
+            if (std::getenv("HIPKKT_VERBOSE")) std::fprintf(stderr, "[hipkkt] dense children: %lld\n", (long long)n_dense);
             std::vector<int64_t> pptr((size_t)S.N + 1, 0);
             for (int c = 0; c < S.nsuper; ++c) {
                 int p = S.sn_parent[c];
-                if (p < 0) continue;
+                if (p < 0 || dense_child[(size_t)p] == c) continue;
                 const int pnc = S.sn_start[p + 1] - S.sn_start[p];
                 const int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
                 for (int b = 0; b < nbc; ++b) {
@@ -1414,6 +1441,7 @@ private:
                     const int pnc = S.sn_start[p + 1] - S.sn_start[p];
                     for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {
                         int c = S.child_idx[e];
+                        if (dense_child[(size_t)p] == c) continue;
                         int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
                         for (int b = 0; b < nbc; ++b) {
                             int64_t q = S.rowptr[c] + b;
@@ -1506,6 +1534,7 @@ private:
                     const int pnc = S.sn_start[p + 1] - S.sn_start[p];
                     for (int e = S.child_ptr[p]; e < S.child_ptr[p + 1]; ++e) {
                         const int c = S.child_idx[e];
+                        if (dense_child[(size_t)p] == c) continue;
                         const int nbc = (int)(S.rowptr[c + 1] - S.rowptr[c]);
                         const int* rl = S.rel.data() + S.rowptr[c];
                         for (int b = 0; b < nbc; ++b) {

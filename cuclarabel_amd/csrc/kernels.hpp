@@ -108,6 +108,9 @@ struct TreeDev {                 // device copies of the symbolic structure
     // (used by the gather lists below).
     const int64_t* item_ptr;     // = gl_ptr
     const ExtItem* items;
+    // dense child (hipkkt.hip, upload): offset in upd of the child whose update block is this front's whole front
+    // (entry (r, j) -> entry (r, j), leading dimension = this front's size), or -1; block-class fronts only
+    const int64_t* dense_off;
     // forward-solve gather lists: local row r of front s (same indexing) receives
     // uvec[gl_src[q]] for q in gl_ptr[lc] .. gl_ptr[lc+1]
     const int64_t* gl_ptr;
