@@ -133,7 +133,7 @@ public:
             if (overlap_wanted())
                 for (size_t q = ov_first; q < launches.size(); ++q)
                     std::fprintf(stderr, "[hipkkt] overlap admission: launch %zu: %d panel workgroups, %d tiles behind a gate, %d CUs\n", q,
-                                 q >= ov_merge_first ? ov_merge_count : launches[q].count - launches[q].nsliced + launches[q].slice_count,
+                                 ov_group_of[q] >= 0 ? ov_groups[(size_t)ov_group_of[q]].count : launches[q].count - launches[q].nsliced + launches[q].slice_count,
                                  launches[q].ntiles, n_cus);
         }
     }
@@ -367,7 +367,11 @@ private:
             if (!ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
                 std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
         }
-        const size_t merge_from = ov_concurrent ? ov_merge_first : ~(size_t)0;
+        // (the merged kernels only where the two streams run side by side)
+        auto group_of = [&](size_t q) -> const MergeGroup* {
+            return (ov_concurrent && q < ov_group_of.size() && ov_group_of[q] >= 0) ? &ov_groups[(size_t)ov_group_of[q]] : nullptr;
+        };
+        const size_t merge_from = (ov_concurrent && !ov_groups.empty()) ? ov_groups.back().first : ~(size_t)0;
         if (ov_on) {
             zl.add(d_ov_prog.p, S.nsuper);
             zl.add(d_ov_done.p, S.nsuper);
@@ -434,8 +438,16 @@ private:
             // (with the top launches' panels merged into one kernel, the last fork sits in front of that kernel: an event
             //  behind it would wait for the whole top of the tree)
             const size_t tail_fork = (ov_on && merge_from < nl) ? merge_from : (nl >= kWinvTailLaunches ? nl - kWinvTailLaunches : 0);
-            if (first_top < nl && (q + kWinvEarlyLaunches == first_top || q == first_top ||
-                                   (q > first_top && q == tail_fork)) && launches[q].tinv_begin > w_done) {
+            // (a fork point inside a merged run moves to the run's first launch: an event recorded behind the run's kernel
+            //  would wait for the whole run)
+            auto fork_at = [&](size_t want) {
+                if (want >= nl) return want;
+                const MergeGroup* g = ov_on ? group_of(want) : nullptr;
+                return g ? g->first : want;
+            };
+            const bool fork_here = first_top < nl && (q == fork_at(first_top >= kWinvEarlyLaunches ? first_top - kWinvEarlyLaunches : nl) ||
+                                                      q == fork_at(first_top) || (q > first_top && q == fork_at(tail_fork)));
+            if (fork_here && launches[q].tinv_begin > w_done) {
                 ensure_capture_streams();
                 HIP_CHECK(hipEventRecord(ev_fork, st));
                 HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
@@ -456,26 +468,27 @@ private:
                 // starts its tiles only after its panels have finished.)
                 a.ov = 1;
                 a.nbk = L.nbk;
-                // The last launches' panels go out as ONE kernel (ov_merge_first .. end: a few dozen fronts): every one of
+                // The panels of a run of narrow launches go out as ONE kernel (ov_groups: a few dozen workgroups): every one of
                 // them is resident from the start, zeroes its panel, scatters K and fetches its item lists while its
                 // children are still being factorised, and then waits for its children's tiles -- a level of the narrow
                 // top costs its critical path (children's assembly, block loop, tiles) without a kernel boundary and
                 // launch ramp in between.  Workgroups are dispatched in schedule order, i.e. lower levels first.
-                const bool merged = q >= merge_from;
-                a.ov_slot = merged ? (int)ov_merge_first : (int)q;
+                const MergeGroup* g = group_of(q);
+                const bool merged = g != nullptr;
+                a.ov_slot = merged ? (int)g->first : (int)q;
                 if (!merged) {
                     launch_panel(a, L.begin, L.count - L.nsliced, L.bs_panel, L.lds_panel, st);
                     launch_panel_sliced(a, L.slice_begin, L.slice_count, L.lds_sliced, st);
-                } else if (q == ov_merge_first) {
-                    if (ov_merge_sliced) launch_panel_sliced(a, L.slice_begin, ov_merge_count, ov_merge_lds, st);
-                    else launch_panel(a, L.begin, ov_merge_count, 1024, ov_merge_lds, st);
+                } else if (q == g->first) {
+                    if (g->sliced) launch_panel_sliced(a, L.slice_begin, g->count, g->lds, st);
+                    else launch_panel(a, L.begin, g->count, 1024, g->lds, st);
                 }
                 if (q == ov_first) {
                     HIP_CHECK(hipEventRecord(ev_ov_fork, st));
                     HIP_CHECK(hipStreamWaitEvent(ov_stream, ev_ov_fork, 0));
                 } else if (L.ntiles > 0 && !no_gate) {
                     // the gate: this launch's tiles are released once all its panel workgroups are resident (k_ov_gate)
-                    if (merged) launch_ov_gate(d_ov_started.p + ov_merge_first, ov_merge_count, flags.p + 2, ov_limit, ov_stream);
+                    if (merged) launch_ov_gate(d_ov_started.p + g->first, g->count, flags.p + 2, ov_limit, ov_stream);
                     else launch_ov_gate(d_ov_started.p + q, L.count - L.nsliced + L.slice_count, flags.p + 2, ov_limit, ov_stream);
                 }
                 launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, ov_stream, L.ntiles);
@@ -797,8 +810,8 @@ public:
                 for (size_t k = 0; k < sched.size(); ++k) if (sched[k] == sn) q = (int)k;
                 size_t lq = 0;
                 while (lq < launches.size() && !(q >= launches[lq].begin && q < launches[lq].begin + launches[lq].count)) ++lq;
-                std::fprintf(stderr, "; supernode %d is in launch %zu of %zu (overlap from %zu, merged from %zu), level %d, parent %d", sn, lq,
-                             launches.size(), ov_first, ov_merge_first, lq < launches.size() ? launches[lq].level : -1, S.sn_parent[sn]);
+                std::fprintf(stderr, "; supernode %d is in launch %zu of %zu (overlap from %zu, %zu merged runs, the first from %zu), level %d, parent %d", sn, lq,
+                             launches.size(), ov_first, ov_groups.size(), ov_groups.empty() ? launches.size() : ov_groups.front().first, lq < launches.size() ? launches[lq].level : -1, S.sn_parent[sn]);
             }
             std::fprintf(stderr, "\n");
             // the lowest overlapped launch with unfinished fronts: progress of its panels and tiles as the abort left them
@@ -823,7 +836,10 @@ public:
                                 const int c = S.child_idx[e];
                                 if (nt[(size_t)c] > 0) std::fprintf(stderr, " %d(%d/%d)", c, done[(size_t)c], nt[(size_t)c]);
                             }
-                            std::fprintf(stderr, " | merged kernel: %d of %d workgroups started", ov_merge_first < launches.size() ? started[ov_merge_first] : -1, ov_merge_count);
+                            if (ov_group_of[q] >= 0) {
+                                const MergeGroup& g = ov_groups[(size_t)ov_group_of[q]];
+                                std::fprintf(stderr, " | merged kernel of launches %zu..%zu: %d of %d workgroups started", g.first, g.end - 1, started[g.first], g.count);
+                            }
                             std::fprintf(stderr, "\n");
                             ++shown;
                         }
@@ -890,10 +906,15 @@ private:
     size_t ov_first = 0;         // == launches.size(): none
     bool ov_disabled = false;
     int n_cus = 256, side_winv_blocks = 96;
-    size_t ov_merge_first = ~(size_t)0;   // overlap mode: launches from here on share one panel kernel (none: beyond the last)
-    int ov_merge_count = 0;          // panel workgroups of that kernel (whole fronts, or row slices: ov_merge_sliced)
-    size_t ov_merge_lds = 0;
-    bool ov_merge_sliced = false;
+    // overlap mode: runs of consecutive launches whose panels go out as ONE kernel each (upload: overlap admission)
+    struct MergeGroup {
+        size_t first, end;           // launches [first, end)
+        int count;                   // panel workgroups of the kernel (whole fronts, or row slices: sliced)
+        size_t lds;
+        bool sliced;
+    };
+    std::vector<MergeGroup> ov_groups;        // in launch order
+    std::vector<int> ov_group_of;             // per launch: index into ov_groups, -1 = a kernel of its own
     bool ov_concurrent = false;          // the main and the tile stream run side by side (asked once per stream: enqueue_factor)
     hipStream_t ov_probed_stream = (hipStream_t)(-1);
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
@@ -1158,24 +1179,37 @@ private:
             }
             ov_first = (launches.size() - first >= 3) ? first : launches.size();
             {
-                // the trailing launches whose panels share one kernel: all of one kind (whole panels, or row slices -- a
-                // launch with sliced fronts runs all its fronts as slices), at most ov_merge_max workgroups in all
-                // (HIPKKT_OV_MERGE, 0 = off), and never the first overlapped launch (its tiles are released by an event)
+                // Runs of narrow launches whose panels share one kernel, found from the root downwards: all launches of a run
+                // are of one kind (whole panels, or row slices -- a launch with sliced fronts runs all its fronts as slices),
+                // a run has at most ov_merge_max workgroups in all (HIPKKT_OV_MERGE, 0 = off) and at least two launches, a
+                // launch in a run has at most ov_merge_wide workgroups (HIPKKT_OV_MERGE_WIDE: the workgroups of a run hold
+                // their CUs from the start of the run, which the tiles of a WIDE level below them would miss), and the first
+                // overlapped launch is in none (its tiles are released by an event).
                 static const int ov_merge_max = std::getenv("HIPKKT_OV_MERGE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE")) : 100;
-                ov_merge_first = ~(size_t)0;
-                ov_merge_count = 0;
-                ov_merge_lds = 0;
+                static const int ov_merge_wide = std::getenv("HIPKKT_OV_MERGE_WIDE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE_WIDE")) : 24;
+                static const int ov_merge_groups = std::getenv("HIPKKT_OV_MERGE_GROUPS") ? std::atoi(std::getenv("HIPKKT_OV_MERGE_GROUPS")) : 8;
+                ov_groups.clear();
+                ov_group_of.assign(launches.size(), -1);
                 size_t m = launches.size();
-                int cnt = 0;
-                ov_merge_sliced = !launches.empty() && launches.back().nsliced > 0;
-                while (m > ov_first + 1 && !launches[m - 1].small &&
-                       (ov_merge_sliced ? launches[m - 1].nsliced == launches[m - 1].count : launches[m - 1].nsliced == 0) &&
-                       cnt + panel_wgs(launches[m - 1]) <= std::min(ov_merge_max, ov_max)) {
-                    cnt += panel_wgs(launches[m - 1]);
-                    ov_merge_lds = std::max(ov_merge_lds, ov_merge_sliced ? launches[m - 1].lds_sliced : launches[m - 1].lds_panel);
-                    --m;
+                const int cap = std::min(ov_merge_max, ov_max);
+                while (m > ov_first + 1 && (int)ov_groups.size() < ov_merge_groups) {
+                    MergeGroup g{m, m, 0, 0, launches[m - 1].nsliced > 0};
+                    // (the root's run takes launches of any width, as it always did; the runs below it narrow ones only)
+                    const int wide = ov_groups.empty() ? cap : ov_merge_wide;
+                    while (g.first > ov_first + 1 && !launches[g.first - 1].small &&
+                           (g.sliced ? launches[g.first - 1].nsliced == launches[g.first - 1].count : launches[g.first - 1].nsliced == 0) &&
+                           panel_wgs(launches[g.first - 1]) <= wide && g.count + panel_wgs(launches[g.first - 1]) <= cap) {
+                        const Launch& L = launches[g.first - 1];
+                        g.count += panel_wgs(L);
+                        g.lds = std::max(g.lds, g.sliced ? L.lds_sliced : L.lds_panel);
+                        --g.first;
+                    }
+                    if (g.end - g.first < 2) break;
+                    ov_groups.insert(ov_groups.begin(), g);
+                    m = g.first;
                 }
-                if (launches.size() - m >= 2) { ov_merge_first = m; ov_merge_count = cnt; }
+                for (size_t k = 0; k < ov_groups.size(); ++k)
+                    for (size_t q = ov_groups[k].first; q < ov_groups[k].end; ++q) ov_group_of[q] = (int)k;
             }
             d_ov_started.alloc(std::max<size_t>(launches.size(), 1));
             HIP_CHECK(hipMemset(d_ov_started.p, 0, std::max<size_t>(launches.size(), 1) * sizeof(int)));
