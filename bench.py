@@ -133,7 +133,9 @@ def cpu_baseline(pb, n_units):
 
 def run_configs(args):
     """All BASELINE.json configurations at full size on one MI355X (results table of BASELINE.md section 3), one JSON
-    line each: the unit of work of SURVEY.md 8(d) timed on the GPU through the C ABI, the last solve compared with
+    line each: the unit of work of SURVEY.md 8(d) timed on the GPU through the C ABI -- `gpu_ms_per_unit`: level B, update +
+    three single solves on given right-hand sides (the figure of rounds 1-2); `system_ms_per_unit`: the same unit through
+    the reduced-system layer in lazy mode, i.e. the way the headline issues it --, the last solve compared with
     the CPU oracle on the same K, b, and -- this is bench.py's cpu_baseline leg for the other configurations -- the
     oracle timed on this box's host (1 thread, AMD ordering) on a bounded sample.  cfg4 is the per-GPU share of the
     batch: 8 problems back to back on one stream ("4"), or stacked block-diagonally on one handle ("4b")."""
@@ -206,11 +208,45 @@ def run_configs(args):
         dt = (time.perf_counter() - t0) / (args.steps * len(sol))
         prof = sol[0].profile()
         info = sol[0].info
+        # The same unit through the reduced-system layer the way the headline issues it (level C, lazy: kkt_update!, then
+        # kkt_solve!(:affine) -- the constant and the affine right-hand side as one 2-column solve where the structure's
+        # sweeps take two columns --, then kkt_solve!(:combined); three separate calls with one status read-back each)
+        from cuclarabel_amd.kktsolver import HipKKTSystem
+        systems = []
+        for pb, ks in zip(pbs, sol):
+            ks.profile_enable(False)
+            system = HipKKTSystem(ks)
+            system.init(pb.q, pb.b)
+            system.set_lazy(True)
+            dd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            var = [dd(rng.standard_normal(pb.n)), dd(pb.s0), dd(pb.z0)]
+            rhs2 = [[dd(rng.standard_normal(k)) for k in (pb.n, pb.m, pb.m)] for _ in range(2)]
+            lhs = [torch.zeros(k, dtype=torch.float64, device=dev) for k in (pb.n, pb.m, pb.m)]
+            P = lambda ts: [t.data_ptr() for t in ts]
+            calls = system.prepared(P(lhs), [P(rhs2[0]), P(rhs2[1])], 0.3, -0.1, P(var), 1.1, 0.9)
+            systems.append((system, calls, (var, rhs2, lhs)))
+
+        def unit_sys(calls):
+            update, solve_affine, solve_combined = calls
+            assert update()
+            assert solve_affine()[0] and solve_combined()[0]
+
+        for _, calls, _ in systems:
+            unit_sys(calls)
+            unit_sys(calls)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for _, calls, _ in systems:
+                unit_sys(calls)
+        torch.cuda.synchronize(dev)
+        dt_sys = (time.perf_counter() - t0) / (args.steps * len(sol))
         fallbacks = [sum(k.fallbacks[i] for k in sol) for i in (0, 1)]       # (overlap mode, persistent sweep kernel): the ABI's counters
         row = dict(config=c, problems_on_gpu=len(sol), N=info["N"], nnzK=info["nnzK"], nnzL=info["nnzL"],
                    nnzL_stored=info["nnzL_stored"], levels=info["nlevels"], max_front=info["max_front"],
                    factor_gflop=info["factor_flops"] / 1e9, setup_s=setup_s / len(sol),
                    gpu_ms_per_unit=dt * 1e3 / per_unit, gpu_units_per_s=per_unit / dt, problems_per_handle=per_unit,
+                   system_ms_per_unit=dt_sys * 1e3 / per_unit, system_units_per_s=per_unit / dt_sys,
                    factor_ms=prof["factor_ms"] / max(prof["n_factor"], 1),
                    trisolve_ms=prof["trisolve_ms"] / max(prof["n_trisolve"], 1),
                    update_ms=prof["update_ms"] / max(prof["n_update"], 1),
@@ -253,6 +289,7 @@ def run_configs(args):
         # the NEXT configuration once read 10.6 instead of 5.6 ms): release this configuration's arrays now, well before
         # the next timed region.
         o = xo = zo = x = z = None
+        systems = None
         del sol, state, pbs, o, xo, zo, x, z
         import gc
         gc.collect()

@@ -130,6 +130,20 @@ public:
                          S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
                          top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, overlap_wanted() ? launches.size() - ov_first : (size_t)0,
                          ov_slices);
+            if (std::atoi(std::getenv("HIPKKT_VERBOSE")) >= 2)
+                for (size_t q = 0; q < launches.size(); ++q) {
+                    const Launch& L = launches[q];
+                    int fmin = 1 << 30, ncmin = 1 << 30;
+                    double flops = 0;
+                    for (int t = L.begin; t < L.begin + L.count; ++t) {
+                        const int sn = sched[(size_t)t], nc = S.sn_start[sn + 1] - S.sn_start[sn], f = front_size(sn);
+                        fmin = std::min(fmin, f); ncmin = std::min(ncmin, nc);
+                        flops += (double)nc * (f - nc) * (f - nc) + (double)nc * nc * (f - nc) + (double)nc * nc * nc / 3;
+                    }
+                    std::fprintf(stderr, "[hipkkt] launch %zu level %d: %d fronts (%s), f %d..%d, nc %d..%d, %d sliced into %d, %d tiles, %.3f GF\n",
+                                 q, L.level, L.count, L.small ? "one wave" : "block", fmin, L.fmax, ncmin, L.ncmax, L.nsliced, L.slice_count,
+                                 L.ntiles, flops * 1e-9);
+                }
             if (overlap_wanted())
                 for (size_t q = ov_first; q < launches.size(); ++q)
                     std::fprintf(stderr, "[hipkkt] overlap admission: launch %zu: %d panel workgroups, %d tiles behind a gate, %d CUs\n", q,
@@ -305,6 +319,86 @@ private:
         HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
     }
 
+    // Do two streams really run side by side?  HIP deals a process's streams to a few hardware queues, and two streams on
+    // one queue execute in submission order: the side stream's W formation would then sit in the middle of the
+    // factorisation (seen: cfg2's 1.75 ms became 2.69 in a process that had created a few streams before), the tile
+    // stream's kernels would not overlap their panels.  A kernel on `a` waits up to 2 ms for a kernel submitted AFTER it
+    // on `b` (factor_kernels.hip, launch_concurrency_probe).
+    bool streams_concurrent(hipStream_t a, hipStream_t b)
+    {
+        int* w = flags.p + 8;
+        launch_zero_ints(w, 2, a);
+        HIP_CHECK(hipStreamSynchronize(a));
+        HIP_CHECK(hipStreamSynchronize(b));
+        launch_concurrency_probe(w, a, b);
+        int seen[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(seen, w, sizeof(seen), hipMemcpyDeviceToHost, a));
+        HIP_CHECK(hipStreamSynchronize(a));
+        HIP_CHECK(hipStreamSynchronize(b));
+        return seen[1] != 0;
+    }
+    // A stream that runs beside every stream of `beside`: `have` if it does (or nullptr: create one), else new streams are
+    // tried -- up to six, the rejected ones held until the search ends so that the next creation lands on another queue.
+    // *ok says whether the search succeeded; without success the last candidate is returned (everything still works
+    // on a shared queue, in submission order).
+    template <typename Create>
+    hipStream_t stream_beside(hipStream_t have, const std::vector<hipStream_t>& beside, Create&& create, bool* ok)
+    {
+        std::vector<hipStream_t> rejected;
+        hipStream_t cand = have;
+        *ok = false;
+        for (int attempt = 0; attempt < 6; ++attempt) {
+            if (!cand && create(&cand) != hipSuccess) { (void)hipGetLastError(); cand = nullptr; break; }
+            bool good = true;
+            for (hipStream_t o : beside) good = good && streams_concurrent(o, cand);
+            if (good) { *ok = true; break; }
+            if (attempt == 5) break;
+            rejected.push_back(cand);
+            cand = nullptr;
+        }
+        if (!cand && !rejected.empty()) { cand = rejected.back(); rejected.pop_back(); }
+        for (hipStream_t r : rejected) { (void)hipStreamSynchronize(r); (void)hipStreamDestroy(r); }
+        return cand;
+    }
+    hipStream_t sides_for = (hipStream_t)(-1);     // the main stream the side / tile streams were chosen for
+    bool side_concurrent = false;
+    // (eager path only) the W-formation stream and the tile stream, each beside the main stream and beside each other
+    void choose_side_streams(hipStream_t st, bool want_tiles)
+    {
+        if (sides_for == st && (!want_tiles || ov_stream || ov_disabled)) return;
+        ensure_capture_streams();
+        wait_w(st);
+        auto plain = [](hipStream_t* out) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); };
+        if (sides_for != st) {
+            cap_side = stream_beside(cap_side, {st}, plain, &side_concurrent);
+            if (!side_concurrent && std::getenv("HIPKKT_VERBOSE"))
+                std::fprintf(stderr, "[hipkkt] no stream beside the main stream for the W formation: it will run in submission order\n");
+        }
+        if (want_tiles && !ov_disabled) {
+            // (HIPKKT_OV_CU_MASK=1 confines the tile stream to every other CU.  Measured: on this stack a CU-masked
+            // stream slows EVERY stream of the process down as if all of them were masked -- residual 0.032 -> 0.054 ms,
+            // sweep 0.29 -> 0.37 ms -- so the default is a plain stream.)
+            static const bool cu_mask = std::getenv("HIPKKT_OV_CU_MASK") != nullptr;
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+            std::vector<uint32_t> mask((size_t)std::max((prop.multiProcessorCount + 31) / 32, 1), 0x55555555u);
+            auto masked = [&](hipStream_t* out) { return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()); };
+            const bool had = ov_stream != nullptr;
+            if (cu_mask) ov_stream = stream_beside(ov_stream, {st, cap_side}, masked, &ov_concurrent);
+            else ov_stream = stream_beside(ov_stream, {st, cap_side}, plain, &ov_concurrent);
+            if (!ov_stream) {
+                ov_disabled = true;
+                std::fprintf(stderr, "[hipkkt] no stream for the Schur tiles: factorisation overlap off\n");
+            } else if (!had) {
+                HIP_CHECK(hipEventCreateWithFlags(&ev_ov_fork, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&ev_ov_join, hipEventDisableTiming));
+            }
+            if (ov_stream && !ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
+                std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
+        }
+        sides_for = st;
+    }
+
     // side != nullptr: put the T = L11^{-1} kernels on that stream, forked after each level's panels
     void enqueue_factor(const double* d_Kval, const double* d_eps, hipStream_t st, hipStream_t side, bool want_stamps)
     {
@@ -319,54 +413,14 @@ private:
         // much as the factorisation ended earlier).
         const bool want_ov = overlap_wanted();
         const bool use_ov = want_ov && !side && !want_stamps && !ov_disabled && ov_first < launches.size();
-        if (use_ov) {
-            if (!ov_stream) {
-                // A panel workgroup needs a whole CU's LDS: tiles that reached the device first, spread one per CU and
-                // waiting for their panel, would leave no CU for it.  The submission order below makes the panels ready
-                // before their tiles; the bounded waits are the safety net.
-                hipDeviceProp_t prop;
-                HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
-                const int words = (prop.multiProcessorCount + 31) / 32;
-                std::vector<uint32_t> mask((size_t)std::max(words, 1), 0x55555555u);
-                // (HIPKKT_OV_CU_MASK=1 confines the tile stream to every other CU.  Measured: on this stack a CU-masked
-                // stream slows EVERY stream of the process down as if all of them were masked -- residual 0.032 -> 0.054 ms,
-                // sweep 0.29 -> 0.37 ms -- so the default is a plain stream and the submission order described below.)
-                static const bool cu_mask = std::getenv("HIPKKT_OV_CU_MASK") != nullptr;
-                const hipError_t ce = !cu_mask ? hipStreamCreateWithFlags(&ov_stream, hipStreamNonBlocking)
-                                               : hipExtStreamCreateWithCUMask(&ov_stream, (uint32_t)mask.size(), mask.data());
-                if (ce != hipSuccess) {
-                    (void)hipGetLastError();
-                    ov_stream = nullptr;
-                    ov_disabled = true;
-                    std::fprintf(stderr, "[hipkkt] no stream for the Schur tiles: factorisation overlap off\n");
-                } else {
-                    HIP_CHECK(hipEventCreateWithFlags(&ev_ov_fork, hipEventDisableTiming));
-                    HIP_CHECK(hipEventCreateWithFlags(&ev_ov_join, hipEventDisableTiming));
-                }
-            }
-        }
-        const bool ov_on = use_ov && !ov_disabled;
-        if (ov_on && ov_probed_stream != st) {
-            // The merged panel kernel of the narrow top (below) waits for tile kernels that are submitted BEHIND it: that
-            // needs the two streams on different hardware queues.  HIP multiplexes streams onto a few queues (a process
-            // with many handles has more streams than queues), and streams that share one run in submission order -- the
-            // merged kernel would then wait for its 50 ms bound (seen with eight handles in one process: two of them).
-            // Asked once per (handle, stream): a kernel on the main stream waits up to 2 ms for a kernel submitted after
-            // it on the tile stream.  Without concurrency every level keeps its own panel kernel, whose waits only ever
-            // look at work submitted earlier (panel L, tiles L, panel L + 1, ...: correct on one queue as well).
-            int* w = flags.p + 8;
-            launch_zero_ints(w, 2, st);
-            HIP_CHECK(hipStreamSynchronize(st));
-            launch_concurrency_probe(w, st, ov_stream);
-            int seen[2] = {0, 0};
-            HIP_CHECK(hipMemcpyAsync(seen, w, sizeof(seen), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            HIP_CHECK(hipStreamSynchronize(ov_stream));
-            ov_concurrent = seen[1] != 0;
-            ov_probed_stream = st;
-            if (!ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
-                std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
-        }
+        // the side streams (W formation, Schur tiles) are chosen once per main stream, each probed to run BESIDE it
+        if (!side && !want_stamps) choose_side_streams(st, use_ov);
+        const bool ov_on = use_ov && !ov_disabled && ov_stream != nullptr;
+        // The merged panel kernels of the narrow top (below) wait for tile kernels that are submitted BEHIND them: that
+        // needs the two streams on different hardware queues (ov_concurrent: choose_side_streams' probe; seen without it,
+        // eight handles in one process: two of them waited for their 50 ms bound).  Without concurrency every level keeps
+        // its own panel kernel, whose waits only ever look at work submitted earlier (panel L, tiles L, panel L + 1, ...:
+        // correct on one queue as well).
         // (the merged kernels only where the two streams run side by side)
         auto group_of = [&](size_t q) -> const MergeGroup* {
             return (ov_concurrent && q < ov_group_of.size() && ov_group_of[q] >= 0) ? &ov_groups[(size_t)ov_group_of[q]] : nullptr;
@@ -915,8 +969,7 @@ private:
     };
     std::vector<MergeGroup> ov_groups;        // in launch order
     std::vector<int> ov_group_of;             // per launch: index into ov_groups, -1 = a kernel of its own
-    bool ov_concurrent = false;          // the main and the tile stream run side by side (asked once per stream: enqueue_factor)
-    hipStream_t ov_probed_stream = (hipStream_t)(-1);
+    bool ov_concurrent = false;          // the main and the tile stream run side by side (choose_side_streams)
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
     hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;

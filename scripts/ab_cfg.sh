@@ -10,7 +10,7 @@ for line in sys.stdin:
     line=line.strip()
     if not line.startswith('{'): continue
     d=json.loads(line)
-    print('cfg%-3s %-28s' % (d['config'], '$e'), 'unit %.3f ms  factor %.3f  trisolve %.3f  TF %.2f  fallbacks %s' % (d['gpu_ms_per_unit'], d['factor_ms'], d['trisolve_ms'], d['factor_TFLOPs'], d.get('fallbacks')))
+    print('cfg%-3s %-28s' % (d['config'], '$e'), 'unit %.3f ms (level C %.3f)  factor %.3f  trisolve %.3f  TF %.2f  fallbacks %s' % (d['gpu_ms_per_unit'], d.get('system_ms_per_unit', 0), d['factor_ms'], d['trisolve_ms'], d['factor_TFLOPs'], d.get('fallbacks')))
 " || exit 1
   done
 done
