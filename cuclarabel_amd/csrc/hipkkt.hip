@@ -210,14 +210,19 @@ public:
         HIP_CHECK(hipGraphLaunch(it->second, stream));
     }
     // The single-column kernels' NR-column instances keep NR times the vectors in LDS: possible when every level's
-    // share still fits a CU, and when the top of the tree does not need the (front, slice) kernel (single column only).
+    // share still fits a CU (the (front, slice) kernel of sets with very tall fronts: two columns at most).
     bool supports_nr(int nr) const
     {
         if (nr == 1) return true;
         if (nr != 2 && nr != 4) return false;
-        if (top_ntask > 0) return false;
-        for (const Launch& L : launches)
-            if (!L.small && L.lds_solve * (size_t)nr > kLdsCap) return false;
+        // A set with very tall fronts ((front, slice) kernel): two columns at most, and only the launches BELOW the set
+        // have to fit -- the set's own fronts (1531 x 96: one column's vectors fill a CU's LDS in the per-level kernels)
+        // go through the persistent kernel, or, where that is not available (no claim, given up), column by column
+        // (enqueue_solve).
+        if (top_ntask > 0 && (nr != 2 || top_sgrid2 <= 0)) return false;
+        const size_t below = top_ntask > 0 ? launches.size() - top_launches : launches.size();
+        for (size_t q = 0; q < below; ++q)
+            if (!launches[q].small && launches[q].lds_solve * (size_t)nr > kLdsCap) return false;
         return true;
     }
 
@@ -623,6 +628,7 @@ private:
     int top_grid_for(int nr)
     {
         if (nr == 1) return top_grid;
+        if (top_ntask > 0) return nr == 2 ? top_sgrid2 : 0;
         int& g = top_grid_nr[nr == 2 ? 0 : 1];
         if (g < 0) g = std::min(top_grid, top_solve_capacity_nr(top_lds * (size_t)nr, nr));
         return g;
@@ -649,6 +655,12 @@ private:
         a.ld_b = ldb; a.ld_out = ldx; a.ld_xp = S.N; a.ld_uvec = (int64_t)std::max<size_t>(S.rows.size(), 1);
         a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
+        if (nr > 1 && top_ntask > 0 && (no_top || !use_top || top_disabled || top_sgrid2 <= 0)) {
+            // two columns through a set with very tall fronts need its persistent kernel (supports_nr): without it, one
+            // column after the other
+            for (int c = 0; c < nr; ++c) enqueue_solve(d_b + (int64_t)c * ldb, d_x + (int64_t)c * ldx, st, use_top, 1, 0, 0);
+            return;
+        }
         const size_t nl = launches.size();
         // the persistent kernel covers the last ntl launches.  Right after a factorisation the W of the narrow top is
         // still being formed on the side stream: that sweep keeps the per-level launches for the levels below the
@@ -656,7 +668,9 @@ private:
         const int tgrid = (no_top || !use_top || top_disabled) ? 0 : top_grid_for(nr);
         size_t ntl = tgrid > 0 ? top_launches : 0;
         int ncount = top_count;
-        if (ntl > 0 && w_pending && late_launches > 0 && late_launches < ntl) { ntl = late_launches; ncount = late_count; }
+        // (two columns through a set with very tall fronts: the whole set or nothing -- its lower levels do not fit the
+        //  per-level kernels with two columns; the sweep then waits for W at the set's first level)
+        if (ntl > 0 && w_pending && late_launches > 0 && late_launches < ntl && !(nr > 1 && top_ntask > 0)) { ntl = late_launches; ncount = late_count; }
         const size_t first_w = nl - std::min(nl, late_launches);    // fronts from here on get their W late (w_pending)
         // a level's block-class launch and the one-wave launch behind it (sched order) go out as one launch
         static const bool no_merge = std::getenv("HIPKKT_NO_LEVEL_MERGE") != nullptr;
@@ -693,8 +707,8 @@ private:
                     a.top_stamps = (long long*)top_stamps.p;
                     sl_stamp = true;
                 }
-                launch_top_solve_sliced(a, Lfull.begin, pos0, task0, top_ntask, top_sgrid, top_slds, top_flags.p,
-                                        top_nflag, ++top_epoch, st);
+                launch_top_solve_sliced(a, Lfull.begin, pos0, task0, top_ntask, nr == 2 ? top_sgrid2 : top_sgrid, top_slds, top_flags.p,
+                                        top_nflag, ++top_epoch, st, nr);
                 a.top_stamps = nullptr;
                 if (sl_stamp) {
                     // (front, slice) tasks: per direction the mean time from a task's start to its flags seen, from there
@@ -953,7 +967,7 @@ private:
     DBuf<int> d_tk_pos, d_tk_sl, d_tbase;      // tasks of k_top_solve_sliced (SolveArgs::tk_*); empty unless the set has tall fronts
     DBuf<double> xf;
     std::vector<int> h_tbase;
-    int top_ntask = 0, top_nflag = 0, top_sgrid = 0;
+    int top_ntask = 0, top_nflag = 0, top_sgrid = 0, top_sgrid2 = 0;
     size_t top_slds = 0;
     size_t top_launches = 0, late_launches = 0, top_lds = 0;
     // overlap mode of the factorisation (factor_kernels.hip): the launches from ov_first on (the narrow top of the tree)
@@ -1402,8 +1416,11 @@ private:
                     top_nflag = top_ntask;
                     top_slds = slds;
                     top_sgrid = std::min(top_solve_sliced_capacity(slds), top_ntask);
+                    // (two right-hand sides per sweep: twice the LDS, the same grid or none)
+                    top_sgrid2 = slds * 2 <= 150 * 1024 ? std::min(top_solve_sliced_capacity(slds * 2, 2), top_ntask) : 0;
+                    if (top_sgrid2 < top_sgrid) top_sgrid2 = 0;
                     d_tk_pos.upload(tp); d_tk_sl.upload(ts); d_tbase.upload(h_tbase);
-                    xf.alloc((size_t)S.N);
+                    xf.alloc((size_t)S.N * 2);
                     if (top_sgrid <= 0) top_ntask = 0;
                 }
             }

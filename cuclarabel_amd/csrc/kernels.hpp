@@ -207,9 +207,9 @@ int top_solve_capacity_nr(size_t lds_total, int nr);     // the same for the 102
 // nr right-hand sides (1, 2 or 4); lds = bytes per right-hand side
 void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t lds, int* flags, int nflag, int epoch,
                       hipStream_t st, bool tall, int nr = 1);
-int top_solve_sliced_capacity(size_t lds);
+int top_solve_sliced_capacity(size_t lds, int nr = 1);
 void launch_top_solve_sliced(const SolveArgs& a, int begin, int pos0, int task0, int task1, int grid, size_t lds, int* flags, int nflag,
-                             int epoch, hipStream_t st);
+                             int epoch, hipStream_t st, int nr = 1);
 // max_blocks > 0: at most that many workgroups (each walks several supernodes)
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks = 0);

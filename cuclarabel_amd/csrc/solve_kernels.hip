@@ -1001,7 +1001,31 @@ __device__ inline bool wait_parent_tasks(const TreeDev& T, const int* __restrict
     return ok;
 }
 
-template <int BS>
+// gather_rest for NR interleaved columns (entry e of column c at e * NR + c): GPB sources per pair of load rounds,
+// every column's values in flight together, sums in list order
+template <int GPB, int NR>
+__device__ inline void gather_rest_nr(const TreeDev& T, const double* uvec, int64_t g, int64_t g1, double (&v)[NR])
+{
+    for (; g < g1; g += GPB) {
+        int src[GPB];
+        double u[NR][GPB];
+#pragma unroll
+        for (int q = 0; q < GPB; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
+#pragma unroll
+        for (int q = 0; q < GPB; ++q)
+#pragma unroll
+            for (int c = 0; c < NR; ++c) u[c][q] = src[q] >= 0 ? LD_AGENT_F64(uvec + (int64_t)src[q] * NR + c) : 0.0;
+#pragma unroll
+        for (int c = 0; c < NR; ++c)
+#pragma unroll
+            for (int q = 0; q < GPB; ++q) if (src[q] >= 0) v[c] += u[c][q];
+    }
+}
+
+// NR = 1 or 2 right-hand sides per sweep (column c of the work vectors interleaved: entry i at i * NR + c, as in
+// k_top_solve): the parked matrix entries, gather indices and row indices serve both columns; column c's LDS vectors
+// sit one column stride behind column c - 1's.
+template <int BS, int NR>
 __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int begin, int pos0, int task0, int task1, int* flags,
                                                              int epoch, int nflag)
 {
@@ -1034,10 +1058,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             const int f = nc + nb;
             const double* __restrict__ W = A.tinv + fd.w_off;
             const int fpad = (f + 3) & ~3;
-            double* y = smem;
-            double* part = smem + fpad;
             // ---- preload
             const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6, nitF = nrb * nks;
+            const int cst = (1 + nks) * fpad;
+            double* y = smem;
+            double* part = smem + fpad;
             ItemRegs rf[4];
     #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -1048,19 +1073,25 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
     #pragma unroll
                 for (int q = 0; q < 8; ++q) rf[p].m[q] = (live && r < f && k0 + q < nc) ? W[r + (int64_t)(k0 + q) * f] : 0.0;
             }
-            constexpr int GP = 12;             // gather sources per row whose indices are fetched before the wait: the
-            int gsrc[GP];                      // separator rows near the top collect a dozen small children each
+            constexpr int GP = NR == 1 ? 12 : 8;   // gather sources per row whose indices are fetched before the wait: the
+            int gsrc[GP];                          // separator rows near the top collect a dozen small children each
     #pragma unroll
             for (int q = 0; q < GP; ++q) gsrc[q] = -1;
             int64_t g0 = 0, g1 = 0;
-            double bmine = 0.0;
+            double bmine[NR];
+    #pragma unroll
+            for (int c = 0; c < NR; ++c) bmine[c] = 0.0;
             if (tid < f) {
                 const int64_t lc = (int64_t)c0 + rp + tid;
                 g0 = T.gl_ptr[lc];
                 g1 = T.gl_ptr[lc + 1];
     #pragma unroll
                 for (int q = 0; q < GP; ++q) gsrc[q] = (g0 + q < g1) ? T.gl_src[g0 + q] : -1;
-                if (tid < nc) bmine = A.b[T.perm[c0 + tid]];
+                if (tid < nc) {
+                    const int pi = T.perm[c0 + tid];
+    #pragma unroll
+                    for (int c = 0; c < NR; ++c) bmine[c] = A.b[c * A.ld_b + pi];
+                }
             }
             if (tid == 0) sh_ok = 1;
             __syncthreads();
@@ -1073,26 +1104,40 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             SL_STAMP(0, 2);
             // ---- gather (only the handed-over values are loaded now)
             if (tid < f) {
-                double u[GP];
+                double u[NR][GP];
     #pragma unroll
-                for (int q = 0; q < GP; ++q) u[q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + gsrc[q]) : 0.0;
-                double v = bmine;
+                for (int q = 0; q < GP; ++q)
     #pragma unroll
-                for (int q = 0; q < GP; ++q) v += u[q];
-                v = gather_rest<8>(T, A.uvec, g0 + GP, g1, v);
-                y[tid] = v;
+                    for (int c = 0; c < NR; ++c) u[c][q] = gsrc[q] >= 0 ? LD_AGENT_F64(A.uvec + (int64_t)gsrc[q] * NR + c) : 0.0;
+    #pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    double v = bmine[c];
+    #pragma unroll
+                    for (int q = 0; q < GP; ++q) v += u[c][q];
+                    bmine[c] = v;
+                }
+                if (NR == 1) bmine[0] = gather_rest<8>(T, A.uvec, g0 + GP, g1, bmine[0]);
+                else gather_rest_nr<8, NR>(T, A.uvec, g0 + GP, g1, bmine);
+    #pragma unroll
+                for (int c = 0; c < NR; ++c) y[c * cst + tid] = bmine[c];
             }
             for (int i = tid + BS; i < f; i += BS) {          // fronts taller than the workgroup (rare)
-                double v = (i < nc) ? A.b[T.perm[c0 + i]] : 0.0;
                 const int64_t lc = (int64_t)c0 + rp + i;
-                for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
-                y[i] = v;
+    #pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    double v = (i < nc) ? A.b[c * A.ld_b + T.perm[c0 + i]] : 0.0;
+                    for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + (int64_t)T.gl_src[g] * NR + c);
+                    y[c * cst + i] = v;
+                }
             }
             __syncthreads();
     #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int it = wv + p * NW;
-                if (it < nitF) item_apply(rf[p], y, f, nc, part, fpad, it, nrb, lane);
+                if (it < nitF) {
+    #pragma unroll
+                    for (int c = 0; c < NR; ++c) item_apply(rf[p], y + c * cst, f, nc, part + c * cst, fpad, it, nrb, lane);
+                }
             }
             // (tall fronts: the items beyond the parked ones, three at a time -- 24 loads per lane in flight)
             for (int it0 = wv + 4 * NW; it0 < nitF; it0 += 3 * NW) {
@@ -1108,19 +1153,25 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
                 }
     #pragma unroll
                 for (int u = 0; u < 3; ++u)
-                    if (it0 + u * NW < nitF) item_apply(rr[u], y, f, nc, part, fpad, it0 + u * NW, nrb, lane);
+                    if (it0 + u * NW < nitF) {
+    #pragma unroll
+                        for (int c = 0; c < NR; ++c) item_apply(rr[u], y + c * cst, f, nc, part + c * cst, fpad, it0 + u * NW, nrb, lane);
+                    }
             }
             __syncthreads();
             for (int i = tid; i < f; i += BS) {
-                const double v = lds_sum_strided(part + i, nks, fpad);
-                if (i < nc) ST_AGENT_F64(A.xp + c0 + i, v);
-                else ST_AGENT_F64(A.uvec + rp + i - nc, y[i] - v);
+    #pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    const double v = lds_sum_strided(part + c * cst + i, nks, fpad);
+                    if (i < nc) ST_AGENT_F64(A.xp + (int64_t)(c0 + i) * NR + c, v);
+                    else ST_AGENT_F64(A.uvec + (int64_t)(rp + i - nc) * NR + c, y[c * cst + i] - v);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
             __syncthreads();
             SL_STAMP(0, 5);
             if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    
+
             continue;
         }
         const FrontDesc fd = T.desc[begin + pos];
@@ -1133,11 +1184,12 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         const int rs = max(0, min(rsz, f - r_lo));
         const int R0 = sl == 0 ? 0 : r_lo, R1 = r_lo + rs;          // this slice's rows of W
         const int nloc = R1 - R0, nlocp = (nloc + 3) & ~3, ncp = (nc + 3) & ~3;
+        const int nks = (nc + 7) >> 3, nrb = (nloc + 63) >> 6, nit = nrb * nks;
+        const int cst = ncp + nlocp + nks * nlocp;                   // one column's LDS vectors
         double* ytop = smem;                                         // y of the top nc rows
         double* yloc = smem + ncp;                                   // y of the slice's rows (slice 0: starts with the top ones)
         double* part = yloc + nlocp;
         // ---- parked: matrix items
-        const int nks = (nc + 7) >> 3, nrb = (nloc + 63) >> 6, nit = nrb * nks;
         ItemRegs rf[kSlPF];
 #pragma unroll
         for (int p = 0; p < kSlPF; ++p) {
@@ -1152,11 +1204,13 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         // slices, of the top rows (threads 0 .. nc-1)
         int gs[2][kSlGP];
         int64_t g0[2] = {0, 0}, g1[2] = {0, 0};
-        double bm[2] = {0.0, 0.0};
+        double bm[2][NR];
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
 #pragma unroll
             for (int q = 0; q < kSlGP; ++q) gs[x][q] = -1;
+#pragma unroll
+            for (int c = 0; c < NR; ++c) bm[x][c] = 0.0;
             const int lr = tid + x * BS;
             if (lr < nloc) {
                 const int row = R0 + lr;
@@ -1165,12 +1219,18 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
                 g1[x] = T.gl_ptr[lc + 1];
 #pragma unroll
                 for (int q = 0; q < kSlGP; ++q) gs[x][q] = (g0[x] + q < g1[x]) ? T.gl_src[g0[x] + q] : -1;
-                if (row < nc) bm[x] = A.b[T.perm[c0 + row]];
+                if (row < nc) {
+                    const int pi = T.perm[c0 + row];
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) bm[x][c] = A.b[c * A.ld_b + pi];
+                }
             }
         }
         int gt[kSlGP];
         int64_t gt0 = 0, gt1 = 0;
-        double bt = 0.0;
+        double bt[NR];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) bt[c] = 0.0;
 #pragma unroll
         for (int q = 0; q < kSlGP; ++q) gt[q] = -1;
         if (sl != 0 && tid < nc) {
@@ -1179,7 +1239,9 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             gt1 = T.gl_ptr[lc + 1];
 #pragma unroll
             for (int q = 0; q < kSlGP; ++q) gt[q] = (gt0 + q < gt1) ? T.gl_src[gt0 + q] : -1;
-            bt = A.b[T.perm[c0 + tid]];
+            const int pi = T.perm[c0 + tid];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) bt[c] = A.b[c * A.ld_b + pi];
         }
         if (tid == 0) sh_ok = 1;
         __syncthreads();
@@ -1194,34 +1256,55 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         for (int x = 0; x < 2; ++x) {
             const int lr = tid + x * BS;
             if (lr < nloc) {
-                double u[kSlGP];
+                double u[NR][kSlGP];
 #pragma unroll
-                for (int q = 0; q < kSlGP; ++q) u[q] = gs[x][q] >= 0 ? LD_AGENT_F64(A.uvec + gs[x][q]) : 0.0;
-                double v = bm[x];
+                for (int q = 0; q < kSlGP; ++q)
 #pragma unroll
-                for (int q = 0; q < kSlGP; ++q) v += u[q];
-                v = gather_rest<8>(T, A.uvec, g0[x] + kSlGP, g1[x], v);
-                yloc[lr] = v;
-                if (sl == 0 && lr < nc) ytop[lr] = v;
+                    for (int c = 0; c < NR; ++c) u[c][q] = gs[x][q] >= 0 ? LD_AGENT_F64(A.uvec + (int64_t)gs[x][q] * NR + c) : 0.0;
+                double v[NR];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    v[c] = bm[x][c];
+#pragma unroll
+                    for (int q = 0; q < kSlGP; ++q) v[c] += u[c][q];
+                }
+                if (NR == 1) v[0] = gather_rest<8>(T, A.uvec, g0[x] + kSlGP, g1[x], v[0]);
+                else gather_rest_nr<8, NR>(T, A.uvec, g0[x] + kSlGP, g1[x], v);
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    yloc[c * cst + lr] = v[c];
+                    if (sl == 0 && lr < nc) ytop[c * cst + lr] = v[c];
+                }
             }
         }
         for (int lr = tid + 2 * BS; lr < nloc; lr += BS) {              // (slices taller than 2 x BS rows: none with R <= 8)
             const int row = R0 + lr;
-            double v = (row < nc) ? A.b[T.perm[c0 + row]] : 0.0;
             const int64_t lc = (int64_t)c0 + rp + row;
-            for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + T.gl_src[g]);
-            yloc[lr] = v;
-            if (sl == 0 && lr < nc) ytop[lr] = v;
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                double v = (row < nc) ? A.b[c * A.ld_b + T.perm[c0 + row]] : 0.0;
+                for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += LD_AGENT_F64(A.uvec + (int64_t)T.gl_src[g] * NR + c);
+                yloc[c * cst + lr] = v;
+                if (sl == 0 && lr < nc) ytop[c * cst + lr] = v;
+            }
         }
         if (sl != 0 && tid < nc) {
-            double u[kSlGP];
+            double u[NR][kSlGP];
 #pragma unroll
-            for (int q = 0; q < kSlGP; ++q) u[q] = gt[q] >= 0 ? LD_AGENT_F64(A.uvec + gt[q]) : 0.0;
-            double v = bt;
+            for (int q = 0; q < kSlGP; ++q)
 #pragma unroll
-            for (int q = 0; q < kSlGP; ++q) v += u[q];
-            v = gather_rest<8>(T, A.uvec, gt0 + kSlGP, gt1, v);
-            ytop[tid] = v;
+                for (int c = 0; c < NR; ++c) u[c][q] = gt[q] >= 0 ? LD_AGENT_F64(A.uvec + (int64_t)gt[q] * NR + c) : 0.0;
+            double v[NR];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                v[c] = bt[c];
+#pragma unroll
+                for (int q = 0; q < kSlGP; ++q) v[c] += u[c][q];
+            }
+            if (NR == 1) v[0] = gather_rest<8>(T, A.uvec, gt0 + kSlGP, gt1, v[0]);
+            else gather_rest_nr<8, NR>(T, A.uvec, gt0 + kSlGP, gt1, v);
+#pragma unroll
+            for (int c = 0; c < NR; ++c) ytop[c * cst + tid] = v[c];
         }
         __syncthreads();
 #pragma unroll
@@ -1230,10 +1313,13 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             if (it < nit) {
                 const int ks = it / nrb, rb = it - ks * nrb;
                 const int lr = rb * 64 + lane, k0 = 8 * ks;
-                double acc = 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc = fma(rf[p].m[q], (k0 + q < nc) ? ytop[k0 + q] : 0.0, acc);
-                if (lr < nloc) part[ks * nlocp + lr] = acc;
+                for (int c = 0; c < NR; ++c) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = fma(rf[p].m[q], (k0 + q < nc) ? ytop[c * cst + k0 + q] : 0.0, acc);
+                    if (lr < nloc) part[c * cst + ks * nlocp + lr] = acc;
+                }
             }
         }
         for (int it0 = wv + kSlPF * NW; it0 < nit; it0 += 3 * NW) {
@@ -1253,19 +1339,29 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
                 if (it < nit) {
                     const int ks = it / nrb, rb = it - ks * nrb;
                     const int lr = rb * 64 + lane, k0 = 8 * ks;
-                    double acc = 0.0;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (k0 + q < nc) ? ytop[k0 + q] : 0.0, acc);
-                    if (lr < nloc) part[ks * nlocp + lr] = acc;
+                    for (int c = 0; c < NR; ++c) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (k0 + q < nc) ? ytop[c * cst + k0 + q] : 0.0, acc);
+                        if (lr < nloc) part[c * cst + ks * nlocp + lr] = acc;
+                    }
                 }
             }
         }
         __syncthreads();
         for (int lr = tid; lr < nloc; lr += BS) {
-            const double v = lds_sum_strided(part + lr, nks, nlocp);
             const int row = R0 + lr;
-            if (row < nc) { ST_AGENT_F64(A.xp + c0 + row, v); ST_AGENT_F64(A.xf + c0 + row, v); }
-            else ST_AGENT_F64(A.uvec + rp + row - nc, yloc[lr] - v);
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                const double v = lds_sum_strided(part + c * cst + lr, nks, nlocp);
+                if (row < nc) {
+                    ST_AGENT_F64(A.xp + (int64_t)(c0 + row) * NR + c, v);
+                    ST_AGENT_F64(A.xf + (int64_t)(c0 + row) * NR + c, v);
+                } else {
+                    ST_AGENT_F64(A.uvec + (int64_t)(rp + row - nc) * NR + c, yloc[c * cst + lr] - v);
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1288,10 +1384,11 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             const int f = nc + nb;
             const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;
             const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
-            double* z = smem;
-            double* part = smem + fpad;
             // ---- preload
             const int ncb = (nc + 63) >> 6, nrs = (f + 7) >> 3, nitB = ncb * nrs;
+            const int cst = fpad + nrs * ncpad;
+            double* z = smem;
+            double* part = smem + fpad;
             ItemRegs rbk[4];
     #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -1314,10 +1411,21 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             __syncthreads();
             if (!sh_ok) return;
             SL_STAMP(1, 2);
-            if (tid < nc) z[tid] = LD_AGENT_F64(A.xp + c0 + tid) * dinv;
-            else if (tid < f) z[tid] = -LD_AGENT_F64(A.xp + ridx);
-            for (int i = tid + BS; i < f; i += BS)
-                z[i] = (i < nc) ? LD_AGENT_F64(A.xp + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
+            {
+                double zv[NR];                 // every column's value in flight before the first use
+    #pragma unroll
+                for (int c = 0; c < NR; ++c)
+                    zv[c] = (tid < nc) ? LD_AGENT_F64(A.xp + (int64_t)(c0 + tid) * NR + c)
+                                       : (tid < f ? LD_AGENT_F64(A.xp + (int64_t)ridx * NR + c) : 0.0);
+    #pragma unroll
+                for (int c = 0; c < NR; ++c)
+                    if (tid < f) z[c * cst + tid] = (tid < nc) ? zv[c] * dinv : -zv[c];
+            }
+    #pragma unroll
+            for (int c = 0; c < NR; ++c)
+                for (int i = tid + BS; i < f; i += BS)
+                    z[c * cst + i] = (i < nc) ? LD_AGENT_F64(A.xp + (int64_t)(c0 + i) * NR + c) * A.Dinv[c0 + i]
+                                              : -LD_AGENT_F64(A.xp + (int64_t)T.rows[rp + i - nc] * NR + c);
             __syncthreads();
     #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -1325,10 +1433,13 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
                 if (it < nitB) {
                     const int rs = it / ncb, cb = it - rs * ncb;
                     const int j = cb * 64 + lane, r0 = 8 * rs;
-                    double acc = 0.0;
     #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-                    if (j < nc) part[rs * ncpad + j] = acc;
+                    for (int c = 0; c < NR; ++c) {
+                        double acc = 0.0;
+    #pragma unroll
+                        for (int q = 0; q < 8; ++q) acc = fma(rbk[p].m[q], (r0 + q < f) ? z[c * cst + r0 + q] : 0.0, acc);
+                        if (j < nc) part[c * cst + rs * ncpad + j] = acc;
+                    }
                 }
             }
             for (int it0 = wv + 4 * NW; it0 < nitB; it0 += 3 * NW) {
@@ -1348,24 +1459,31 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
                     if (it < nitB) {
                         const int rs = it / ncb, cb = it - rs * ncb;
                         const int j = cb * 64 + lane, r0 = 8 * rs;
-                        double acc = 0.0;
     #pragma unroll
-                        for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[r0 + q] : 0.0, acc);
-                        if (j < nc) part[rs * ncpad + j] = acc;
+                        for (int c = 0; c < NR; ++c) {
+                            double acc = 0.0;
+    #pragma unroll
+                            for (int q = 0; q < 8; ++q) acc = fma(m[u][q], (r0 + q < f) ? z[c * cst + r0 + q] : 0.0, acc);
+                            if (j < nc) part[c * cst + rs * ncpad + j] = acc;
+                        }
                     }
                 }
             }
             __syncthreads();
             for (int j = tid; j < nc; j += BS) {
-                const double v = lds_sum_strided(part + j, nrs, ncpad);
-                ST_AGENT_F64(A.xp + c0 + j, v);
-                A.out[T.perm[c0 + j]] = v;
+                const int pi = T.perm[c0 + j];
+    #pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    const double v = lds_sum_strided(part + c * cst + j, nrs, ncpad);
+                    ST_AGENT_F64(A.xp + (int64_t)(c0 + j) * NR + c, v);
+                    A.out[c * A.ld_out + pi] = v;
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             SL_STAMP(1, 5);
             if (tid == 0) __hip_atomic_store(flag_b + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    
+
             continue;
         }
         const FrontDesc fd = T.desc[begin + pos];
@@ -1376,6 +1494,7 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         const int csz = (nc + R - 1) / R;
         const int j0 = sl * csz, ncl = max(0, min(csz, nc - j0));      // this slice's columns of x
         const int fpad = (f + 3) & ~3;
+        const int cst = fpad + NW * 16;                                 // one right-hand side's LDS vectors
         double* z = smem;
         double* part = smem + fpad;                                     // NW x 16
         const int nrb = (f + 63) >> 6;
@@ -1403,47 +1522,73 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         __syncthreads();
         if (!sh_ok) return;
         SL_STAMP(1, 2);
+        {
+            double zv[2][NR];              // every value in flight before the first use
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const int i = tid + x * BS;
-            if (i < nc) z[i] = LD_AGENT_F64(A.xf + c0 + i) * dinv[x];
-            else if (i < f) z[i] = -LD_AGENT_F64(A.xp + ridx[x]);
+            for (int x = 0; x < 2; ++x) {
+                const int i = tid + x * BS;
+#pragma unroll
+                for (int c = 0; c < NR; ++c)
+                    zv[x][c] = (i < nc) ? LD_AGENT_F64(A.xf + (int64_t)(c0 + i) * NR + c)
+                                        : (i < f ? LD_AGENT_F64(A.xp + (int64_t)ridx[x] * NR + c) : 0.0);
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int i = tid + x * BS;
+#pragma unroll
+                for (int c = 0; c < NR; ++c)
+                    if (i < f) z[c * cst + i] = (i < nc) ? zv[x][c] * dinv[x] : -zv[x][c];
+            }
         }
-        for (int i = tid + 2 * BS; i < f; i += BS)
-            z[i] = (i < nc) ? LD_AGENT_F64(A.xf + c0 + i) * A.Dinv[c0 + i] : -LD_AGENT_F64(A.xp + T.rows[rp + i - nc]);
+#pragma unroll
+        for (int c = 0; c < NR; ++c)
+            for (int i = tid + 2 * BS; i < f; i += BS)
+                z[c * cst + i] = (i < nc) ? LD_AGENT_F64(A.xf + (int64_t)(c0 + i) * NR + c) * A.Dinv[c0 + i]
+                                          : -LD_AGENT_F64(A.xp + (int64_t)T.rows[rp + i - nc] * NR + c);
         __syncthreads();
         for (int cc = 0; cc < ncl; cc += CW) {
             const int ncc = min(CW, ncl - cc);
-            double acc[CW];
+            double acc[NR][CW];
 #pragma unroll
-            for (int c = 0; c < CW; ++c) acc[c] = 0.0;
+            for (int b = 0; b < NR; ++b)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) acc[b][c] = 0.0;
             int x = 0;
             for (int rb = wv; rb < nrb; rb += NW, ++x) {
                 const int r = rb * 64 + lane;
-                const double zl = r < f ? z[r] : 0.0;
+                double zl[NR];
+#pragma unroll
+                for (int b = 0; b < NR; ++b) zl[b] = r < f ? z[b * cst + r] : 0.0;
                 if (cc == 0 && x == 0) {
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) acc[c] = fma(pm[c], zl, acc[c]);
+                    for (int b = 0; b < NR; ++b)
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) acc[b][c] = fma(pm[c], zl[b], acc[b][c]);
                 } else {
                     double m[CW];
 #pragma unroll
                     for (int c = 0; c < CW; ++c) m[c] = (c < ncc && r < f) ? W[r + (int64_t)(j0 + cc + c) * f] : 0.0;
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) acc[c] = fma(m[c], zl, acc[c]);
+                    for (int b = 0; b < NR; ++b)
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) acc[b][c] = fma(m[c], zl[b], acc[b][c]);
                 }
             }
 #pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                const double sum = wave_reduce_sum(acc[c]);
-                if (lane == 0) part[wv * 16 + c] = sum;
-            }
+            for (int b = 0; b < NR; ++b)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    const double sum = wave_reduce_sum(acc[b][c]);
+                    if (lane == 0) part[b * cst + wv * 16 + c] = sum;
+                }
             __syncthreads();
-            if (tid < ncc) {
+            if (tid < ncc * NR) {
+                const int b = tid / ncc, jj = tid - b * ncc;
                 double v = 0.0;
-                for (int w = 0; w < NW; ++w) v += part[w * 16 + tid];
-                const int j = j0 + cc + tid;
-                ST_AGENT_F64(A.xp + c0 + j, v);
-                A.out[T.perm[c0 + j]] = v;
+                for (int w = 0; w < NW; ++w) v += part[b * cst + w * 16 + jj];
+                const int j = j0 + cc + jj;
+                ST_AGENT_F64(A.xp + (int64_t)(c0 + j) * NR + b, v);
+                A.out[b * A.ld_out + T.perm[c0 + j]] = v;
             }
             __syncthreads();
         }
@@ -1670,7 +1815,8 @@ static void init_solve_lds()
 #undef HIPKKT_SET_NR
         set(k_winv, 160 * 1024);
         set(k_top_solve<512, 7, 7, 1>, 150 * 1024);
-        set(k_top_solve_sliced<1024>, 150 * 1024);
+        set(k_top_solve_sliced<1024, 1>, 150 * 1024);
+        set(k_top_solve_sliced<1024, 2>, 150 * 1024);
         return e;
     });
 }
@@ -2233,24 +2379,31 @@ void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t
     else
         hipLaunchKernelGGL((k_top_solve<512, 7, 7, 1>), dim3(std::min(grid, count)), dim3(512), lds, st, a, begin, flags, epoch, count, nflag);
 }
-int top_solve_sliced_capacity(size_t lds)
+int top_solve_sliced_capacity(size_t lds, int nr)
 {
     init_solve_lds();
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve_sliced<1024>, 1024, lds) != hipSuccess) return 0;
+    const hipError_t e = nr == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve_sliced<1024, 2>, 1024, lds)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_top_solve_sliced<1024, 1>, 1024, lds);
+    if (e != hipSuccess) return 0;
     per_cu = per_cu > 1 ? 1 : per_cu;
     return (int)(per_cu * prop.multiProcessorCount * 0.94);
 }
 void launch_top_solve_sliced(const SolveArgs& a, int begin, int pos0, int task0, int task1, int grid, size_t lds, int* flags, int nflag,
-                             int epoch, hipStream_t st)
+                             int epoch, hipStream_t st, int nr)
 {
     const int ntask = task1 - task0;
     if (ntask <= 0 || grid <= 0 || nflag < task1) return;
     init_solve_lds();
-    hipLaunchKernelGGL(k_top_solve_sliced<1024>, dim3(std::min(grid, ntask)), dim3(1024), lds, st, a, begin, pos0, task0, task1, flags,
-                       epoch, nflag);
+    // (lds: one right-hand side's share)
+    if (nr == 2)
+        hipLaunchKernelGGL((k_top_solve_sliced<1024, 2>), dim3(std::min(grid, ntask)), dim3(1024), lds * 2, st, a, begin, pos0, task0,
+                           task1, flags, epoch, nflag);
+    else
+        hipLaunchKernelGGL((k_top_solve_sliced<1024, 1>), dim3(std::min(grid, ntask)), dim3(1024), lds, st, a, begin, pos0, task0, task1,
+                           flags, epoch, nflag);
 }
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
                  hipStream_t st, int max_blocks)

@@ -818,6 +818,62 @@ def test_sliced_persistent_solve(maker, kb):
     assert sched["top_tasks"] > sched["top_fronts"] > 0, sched       # (front, slice) tasks: k_top_solve_sliced was selected
 
 
+_SLICED_PAIR_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver
+from tests.oracle_bindings import make_oracle
+pb = {maker}
+ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+o = make_oracle(pb, perm=ks.perm())
+assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+rng = np.random.default_rng(77)
+for k in (2, 3):
+    RX, RZ = rng.standard_normal((pb.n, k)), rng.standard_normal((pb.m, k))
+    RX[:, 1] *= 1e4; RZ[:, 1] *= 1e4
+    ok, LX, LZ, ir = ks.kktsolver_solve_multi(RX, RZ)
+    assert ok
+    for j in range(k):
+        ks.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        assert np.array_equal(LX[:, j], x) and np.array_equal(LZ[:, j], z), (k, j)       # same arithmetic per column
+        assert int(ir[j]) == ks.last_ir_iterations
+        o.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        oko, xo, zo = o.kktsolver_solve()
+        assert oko and max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()) < 1e-9
+        assert ks.last_ir_iterations == o.last_ir_iters
+assert ks.fallbacks == (0, 0), ks.fallbacks
+print("SLICED PAIR OK")
+"""
+
+
+@pytest.mark.parametrize("no_top", [False, True])
+@pytest.mark.parametrize("maker,kb", [("problems.config2(n=6000)", 8), ("problems.config3(nblocks=4, blk=150)", 16),
+                                      ("problems.config5(n=120, npsd=6, psd_dim=8, nsoc=4, soc_dim=12)", 4)])
+def test_two_columns_through_the_sliced_persistent_kernel(maker, kb, no_top):
+    """k_top_solve_sliced takes two right-hand sides per sweep (the (constant, affine) pair of the reduced-system layer's
+    lazy mode on cfg5-like structures): every column of a 2- and a 3-column batch must end bit for bit where its own
+    single solve ends, with the oracle's refinement rounds.  With HIPKKT_NO_TOP=1 the persistent kernel is not used and
+    the two columns of such a set go one after the other (its fronts do not fit the per-level kernels twice)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb), HIPKKT_VERBOSE="1")
+    if no_top:
+        env["HIPKKT_NO_TOP"] = "1"
+    r = subprocess.run([sys.executable, "-c", _SLICED_PAIR_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SLICED PAIR OK" in r.stdout and "gave up" not in r.stderr, r.stderr
+    sched = _schedule_line(r.stderr)
+    assert sched["top_tasks"] > sched["top_fronts"] > 0, sched       # (front, slice) tasks: k_top_solve_sliced was selected
+
+
 def test_json_problem_file_drives_the_c_abi(tmp_path):
     """SURVEY.md section 8 f3: a problem saved in the reference's on-disk format (save_to_file, json.jl:118-156;
     round trip test/UnitTests/test_json.jl:14-25) is loaded back and driven through the C ABI on the GPU; the
