@@ -1387,8 +1387,14 @@ private:
             top_nflag = std::max(top_count, 1);
             {
                 // Sets with very tall fronts (solve matrix > 3 x slice_kb: far more than a CU should stream per hop) run the
-                // (front, slice) kernel: such a front is cut into slices of ~slice_kb (at most 8), the others are one task
-                static const int slice_kb = std::getenv("HIPKKT_SOLVE_SLICE_KB") ? std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_KB")) : 120;
+                // (front, slice) kernel: such a front is cut into slices of ~slice_kb (at most slice_max), the others are one task
+                // (r03, cfg5: slices of ~80 KB, at most 16, instead of ~120 KB / 8: sweep pair 0.765 -> 0.729 ms; 60 KB / 16 and
+                //  40 KB / 32: 0.74 -- a hop is mostly its fixed latencies by then.  A front is sliced when its W exceeds
+                //  HIPKKT_SOLVE_SLICE_FROM KB, by default 4.5 slices' worth: cfg3's 395 KB fronts are faster whole)
+                static const int slice_kb = std::getenv("HIPKKT_SOLVE_SLICE_KB") ? std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_KB")) : 80;
+                static const int slice_max = std::getenv("HIPKKT_SOLVE_SLICE_MAX") ? std::max(1, std::min(64, std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_MAX")))) : 16;
+                static const int64_t slice_from = std::getenv("HIPKKT_SOLVE_SLICE_FROM") ? std::atoll(std::getenv("HIPKKT_SOLVE_SLICE_FROM")) * 1024
+                                                                                        : (int64_t)slice_kb * 1024 * 9 / 2;
                 std::vector<int> tp, ts;
                 h_tbase.assign((size_t)top_count + 1, 0);
                 const int b0 = top_launches ? launches[launches.size() - top_launches].begin : 0;
@@ -1399,8 +1405,8 @@ private:
                     const int f = front_size(sn), nc = S.sn_start[sn + 1] - S.sn_start[sn], nb = f - nc;
                     const int64_t wbytes = (int64_t)f * nc * 8;
                     int R = 1;
-                    if (slice_kb > 0 && wbytes > (int64_t)3 * slice_kb * 1024)      // (cfg3's 395 KB fronts are faster whole)
-                        R = (int)std::min<int64_t>(8, (wbytes + (int64_t)slice_kb * 1024 - 1) / ((int64_t)slice_kb * 1024));
+                    if (slice_kb > 0 && wbytes > slice_from)
+                        R = (int)std::min<int64_t>(slice_max, (wbytes + (int64_t)slice_kb * 1024 - 1) / ((int64_t)slice_kb * 1024));
                     R = std::max(1, std::min(R, std::max(1, nb)));
                     any_sliced = any_sliced || R > 1;
                     h_tbase[(size_t)p] = (int)tp.size();

@@ -808,7 +808,7 @@ def test_sliced_persistent_solve(maker, kb):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb), HIPKKT_VERBOSE="1")
+    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb), HIPKKT_SOLVE_SLICE_FROM=str(3 * kb), HIPKKT_VERBOSE="1")
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -863,7 +863,7 @@ def test_two_columns_through_the_sliced_persistent_kernel(maker, kb, no_top):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb), HIPKKT_VERBOSE="1")
+    env = dict(os.environ, HIPKKT_SOLVE_SLICE_KB=str(kb), HIPKKT_SOLVE_SLICE_FROM=str(3 * kb), HIPKKT_VERBOSE="1")
     if no_top:
         env["HIPKKT_NO_TOP"] = "1"
     r = subprocess.run([sys.executable, "-c", _SLICED_PAIR_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
