@@ -496,7 +496,14 @@ private:
             // which the next sweep's bottom levels hide
             // (with the top launches' panels merged into one kernel, the last fork sits in front of that kernel: an event
             //  behind it would wait for the whole top of the tree)
-            const size_t tail_fork = (ov_on && merge_from < nl) ? merge_from : (nl >= kWinvTailLaunches ? nl - kWinvTailLaunches : 0);
+            // (with merged panel kernels every run's first launch is a fork point: the W of everything factorised so far is
+            //  formed beside the run.  With the last run's start as the only late fork, cfg3 and cfg5 formed the W of their
+            //  widest levels behind the tree and the first sweep waited for it: 0.1 and 0.37 ms per step)
+            const bool runs = ov_on && merge_from < nl;
+            const size_t tail_fork = runs ? nl : (nl >= kWinvTailLaunches ? nl - kWinvTailLaunches : 0);
+            const MergeGroup* gq = runs ? group_of(q) : nullptr;
+            static const bool run_forks = !(std::getenv("HIPKKT_WINV_RUN_FORKS") && std::atoi(std::getenv("HIPKKT_WINV_RUN_FORKS")) == 0);
+            const bool run_first = gq && gq->first == q && (run_forks || q == merge_from);
             // (a fork point inside a merged run moves to the run's first launch: an event recorded behind the run's kernel
             //  would wait for the whole run)
             auto fork_at = [&](size_t want) {
@@ -505,7 +512,7 @@ private:
                 return g ? g->first : want;
             };
             const bool fork_here = first_top < nl && (q == fork_at(first_top >= kWinvEarlyLaunches ? first_top - kWinvEarlyLaunches : nl) ||
-                                                      q == fork_at(first_top) || (q > first_top && q == fork_at(tail_fork)));
+                                                      q == fork_at(first_top) || (q > first_top && (run_first || q == tail_fork)));
             if (fork_here && launches[q].tinv_begin > w_done) {
                 ensure_capture_streams();
                 HIP_CHECK(hipEventRecord(ev_fork, st));
@@ -1030,6 +1037,13 @@ private:
             int f = front_size(s), nc = ncols(s), nb = f - nc;
             return f <= kSmallFrontMax && f * nc + nb * nb <= kSmallSliceMax;
         };
+        int sched_cus = 256;
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) sched_cus = prop.multiProcessorCount;
+            else (void)hipGetLastError();
+        }
         int level_no = -1;
         for (const Level& lv : S.levels) {
             ++level_no;
@@ -1045,6 +1059,9 @@ private:
                 big.insert(big.end(), small.begin(), small.end());
                 small.clear();
             }
+            static const int slice_rows = std::getenv("HIPKKT_SLICE_ROWS") ? std::atoi(std::getenv("HIPKKT_SLICE_ROWS")) : 128;
+            static const bool slice_fit = !(std::getenv("HIPKKT_SLICE_FIT") && std::atoi(std::getenv("HIPKKT_SLICE_FIT")) == 0);
+            int level_slice_rows = slice_rows;
             auto slices_of = [&](int s) {        // row slices the panel kernel needs for this front (1: fits one CU)
                 if (panel_cap <= 0) return 1;
                 const int nc = ncols(s), nb = front_size(s) - nc;
@@ -1056,10 +1073,30 @@ private:
                 // diagonal block's factorisation per slice.  128 rows (0 = as few slices as LDS allows): cfg5's
                 // factorisation 5.30 -> 5.06 ms, cfg3's 1.21 -> 1.23 (slices have K and item lists of their own, so the
                 // per-slice overhead no longer grows with their number).
-                static const int slice_rows = std::getenv("HIPKKT_SLICE_ROWS") ? std::atoi(std::getenv("HIPKKT_SLICE_ROWS")) : 128;
-                if (r > 1 && slice_rows > 0) r = std::max(r, std::min(panel_max_slices, (nb + slice_rows - 1) / slice_rows));
+                if (r > 1 && level_slice_rows > 0) r = std::max(r, std::min(panel_max_slices, (nb + level_slice_rows - 1) / level_slice_rows));
                 return r;
             };
+            // One round of panel workgroups where possible: every slice needs a CU to itself, so a level with more slices
+            // than CUs runs its panel kernel in two rounds (cfg3's second level: 99 fronts x 3 slices of 114 rows = 297
+            // workgroups, 112 us; x 2 slices of 171 rows = 198 workgroups, one round).  Such a level takes the shortest
+            // slices (>= the default 128 rows) that bring it down to the CU count, if LDS allows any.
+            level_slice_rows = slice_rows;
+            if (slice_fit && slice_rows > 0) {
+                auto total = [&]() {
+                    int t = 0;
+                    bool any = false;
+                    for (int s : big) { const int r = slices_of(s); t += r; any = any || r > 1; }
+                    return any ? t : 0;
+                };
+                if (total() > sched_cus) {
+                    static const int cand[] = {144, 160, 176, 192, 224, 256, 320, 384, 512, 1 << 20};
+                    for (int c : cand) {
+                        level_slice_rows = c;
+                        if (total() <= sched_cus) break;
+                    }
+                    if (total() > sched_cus) level_slice_rows = slice_rows;
+                }
+            }
             auto work = [&](int s) { return (double)front_size(s) * front_size(s) * ncols(s); };
             auto by_work = [&](int a, int b) { double wa = work(a), wb = work(b); return wa != wb ? wa > wb : a < b; };
             std::sort(small.begin(), small.end(), by_work);
