@@ -420,6 +420,9 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
 
     HIPKKT_STAMP(A, 0);
     const long long clk0 = A.stamps ? clock64() : 0;
+    // (the dense child's offset: a scalar load issued now -- fetched where it is used, behind the waits and barriers, it was
+    //  one more memory round trip on every panel workgroup's path: +1.8 us per launch of cfg2's small panels)
+    const int64_t dense_off_s = T.dense_off[s];
     // this wave's slice of the children's extend-add items (host-cut, 16 slices) and its first 64 descriptors: issued
     // now, used in phase 3
     int64_t it0 = 0, it1 = 0;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(BS) void k_panel(FactorArgs A, int begin)
     //          front -- column by column, coalesced, eight loads per thread in flight; every thread owns its entries, the
     //          barrier separates them from the waves' item adds below
     {
-        const int64_t doff = T.dense_off[s];
+        const int64_t doff = dense_off_s;
         if (doff >= 0) {
             const double* __restrict__ Uc = A.upd + doff;
             const int total = f * nc;                                  // (rectangle walked, entries above the diagonal skipped)
@@ -863,9 +866,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OV ? 3 : 4)
     };
     // the dense child (TreeDev::dense_off): entry (i, j) of this front's update block receives entry (nc + i, nc + j)
     // of the child's (leading dimension f) -- a plain block copy, no lists
+    const int64_t dense_off_s = T.dense_off[s];           // (scalar, fetched with the other descriptors)
     auto dense_ptr = [&]() -> const double* {
-        const int64_t doff = T.dense_off[s];
-        return doff >= 0 ? A.upd + doff + (int64_t)(nc + r0) + (int64_t)(nc + q0) * f : nullptr;
+        return dense_off_s >= 0 ? A.upd + dense_off_s + (int64_t)(nc + r0) + (int64_t)(nc + q0) * f : nullptr;
     };
     if (OV) {
         const double* __restrict__ Ud = dense_ptr();
