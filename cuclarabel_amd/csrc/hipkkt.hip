@@ -371,15 +371,13 @@ private:
     void choose_side_streams(hipStream_t st, bool want_tiles)
     {
         if (sides_for == st && (!want_tiles || ov_stream || ov_disabled)) return;
-        ensure_capture_streams();
         wait_w(st);
         auto plain = [](hipStream_t* out) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); };
-        if (sides_for != st) {
-            cap_side = stream_beside(cap_side, {st}, plain, &side_concurrent);
-            if (!side_concurrent && std::getenv("HIPKKT_VERBOSE"))
-                std::fprintf(stderr, "[hipkkt] no stream beside the main stream for the W formation: it will run in submission order\n");
-        }
-        if (want_tiles && !ov_disabled) {
+        const bool new_main = sides_for != st;
+        // The tile stream first: created before the capture / W-formation streams, as it always was (with the W-formation
+        // stream created first the factorisation of cfg2 measured 13 us longer: which hardware queue a stream lands on
+        // follows the order of creation, and the queues are not served alike)
+        if (want_tiles && !ov_disabled && (new_main || !ov_stream)) {
             // (HIPKKT_OV_CU_MASK=1 confines the tile stream to every other CU.  Measured: on this stack a CU-masked
             // stream slows EVERY stream of the process down as if all of them were masked -- residual 0.032 -> 0.054 ms,
             // sweep 0.29 -> 0.37 ms -- so the default is a plain stream.)
@@ -389,8 +387,10 @@ private:
             std::vector<uint32_t> mask((size_t)std::max((prop.multiProcessorCount + 31) / 32, 1), 0x55555555u);
             auto masked = [&](hipStream_t* out) { return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()); };
             const bool had = ov_stream != nullptr;
-            if (cu_mask) ov_stream = stream_beside(ov_stream, {st, cap_side}, masked, &ov_concurrent);
-            else ov_stream = stream_beside(ov_stream, {st, cap_side}, plain, &ov_concurrent);
+            std::vector<hipStream_t> beside{st};
+            if (cap_side && !new_main) beside.push_back(cap_side);           // (a W-formation stream already chosen for st)
+            if (cu_mask) ov_stream = stream_beside(ov_stream, beside, masked, &ov_concurrent);
+            else ov_stream = stream_beside(ov_stream, beside, plain, &ov_concurrent);
             if (!ov_stream) {
                 ov_disabled = true;
                 std::fprintf(stderr, "[hipkkt] no stream for the Schur tiles: factorisation overlap off\n");
@@ -401,6 +401,14 @@ private:
             if (ov_stream && !ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
                 std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
         }
+        ensure_capture_streams();
+        if (new_main) {
+            std::vector<hipStream_t> beside{st};
+            if (ov_stream) beside.push_back(ov_stream);
+            cap_side = stream_beside(cap_side, beside, plain, &side_concurrent);
+            if (!side_concurrent && std::getenv("HIPKKT_VERBOSE"))
+                std::fprintf(stderr, "[hipkkt] no stream beside the main stream for the W formation: it will run in submission order\n");
+        }
         sides_for = st;
     }
 
@@ -408,6 +416,13 @@ private:
     void enqueue_factor(const double* d_Kval, const double* d_eps, hipStream_t st, hipStream_t side, bool want_stamps)
     {
         wait_w(st);                  // (a refactorisation without a solve in between: the side stream still reads the fronts)
+        if (ov_join_pending) {
+            // the previous factorisation's tile stream (see the end of the overlapped launches below) before its counters
+            // and update blocks are touched again
+            if (side) HIP_CHECK(hipEventSynchronize(ev_ov_join));        // (a stream being captured cannot wait for it)
+            else HIP_CHECK(hipStreamWaitEvent(st, ev_ov_join, 0));
+            ov_join_pending = false;
+        }
         ZeroList zl;
         zl.add(flags.p, 3);
         // overlap mode (eager launches only): the top launches' Schur tiles on their own stream, ordered by counters
@@ -560,8 +575,12 @@ private:
                 launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, ov_stream, L.ntiles);
                 a.ov = 0;
                 if (q + 1 == nl) {
+                    // The tile stream is joined by the NEXT factorisation, not by this one's tail: every tile has been counted
+                    // by its parent's panel (a root has no tiles), so when the main stream's last panel kernel ends all
+                    // tile data has long been stored; what is left on the tile stream are workgroups on their way out.
+                    // A cross-stream wait here cost ~17 us between the last panel and the status kernel, every step.
                     HIP_CHECK(hipEventRecord(ev_ov_join, ov_stream));
-                    HIP_CHECK(hipStreamWaitEvent(st, ev_ov_join, 0));
+                    ov_join_pending = true;
                 }
                 continue;
             }
@@ -994,6 +1013,7 @@ private:
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
     hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
+    bool ov_join_pending = false;    // ev_ov_join recorded, not yet waited for (enqueue_factor)
     size_t nr_cap = 1;           // right-hand sides xp / uvec are sized for
     int top_grid_nr[2] = {-1, -1};   // the persistent kernel's grid for 2 / 4 right-hand sides (asked on first use)
     int top_count = 0, late_count = 0, top_grid = 0, top_epoch = 0;
