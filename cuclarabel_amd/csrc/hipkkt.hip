@@ -246,9 +246,10 @@ public:
     {
         if (KP <= 0 || (KP & 15)) throw ArgError("solve_multi_rm: KP must be a positive multiple of 16");
         multi_prepare(KP);
-        launch_permute_rows(xp_m.p, d_B, KP, d_iperm.p, S.N, 0, stream);
-        multi_sweeps(KP);
-        launch_permute_rows(d_X, xp_m.p, KP, d_iperm.p, S.N, 1, stream, d_add);
+        // (r03: the two row permutations -- 2 x (read + write) of N x KP per sweep pair, 5 GB at 512 columns -- are gone: the
+        //  forward kernels read a front's own rows of B through the permutation, the backward kernels store the solution
+        //  (+ add) to the caller's rows beside the tree-ordered copy the descendants read)
+        multi_sweeps(KP, d_B, d_X, d_add);
         HIP_CHECK(hipGetLastError());
     }
 
@@ -271,15 +272,16 @@ private:
         if (!d_iperm.p) d_iperm.upload(S.iperm);
         return KP;
     }
-    void multi_sweeps(int KP)
+    void multi_sweeps(int KP, const double* b_rm = nullptr, double* out_rm = nullptr, const double* add_rm = nullptr)
     {
         SolveArgs a;
         a.T = tree();
         a.fronts = fronts.p;
         a.tinv = tinv.p;
         a.Dinv = Dinv.p;
-        a.b = nullptr;
-        a.out = nullptr;
+        a.b = b_rm;                  // (row-major N x KP in the caller's row order, or null: xp_m holds the permuted right-hand sides)
+        a.out = out_rm;
+        a.add = add_rm;
         a.xp = xp_m.p;
         a.uvec = uvec_m.p;
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
@@ -679,7 +681,7 @@ private:
         a.top_stamps = nullptr;
         bool stamp_now = false;
         a.ld_b = ldb; a.ld_out = ldx; a.ld_xp = S.N; a.ld_uvec = (int64_t)std::max<size_t>(S.rows.size(), 1);
-        a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p;
+        a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p; a.add = nullptr;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         if (nr > 1 && top_ntask > 0 && (no_top || !use_top || top_disabled || top_sgrid2 <= 0)) {
             // two columns through a set with very tall fronts need its persistent kernel (supports_nr): without it, one

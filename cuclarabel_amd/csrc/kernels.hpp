@@ -194,6 +194,7 @@ struct SolveArgs {
     const int* tk_sl;
     const int* tbase;
     double* xf;
+    const double* add;           // many-column sweeps (row-major N x KP): out = solution + add where non-null
 };
 
 constexpr int kSolveChunk = 128;  // diagonal chunk of the triangular solves: one wave, two unknowns per lane

@@ -1964,7 +1964,9 @@ __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int 
 #pragma unroll
     for (int k = 0; k < kWC; ++k) yk[k] = 0.0;
     for (int i = 0; i < f; ++i) {
-        double v = (i < nc) ? xp[(int64_t)(c0 + i) * KP] : 0.0;
+        // (A.b: the right-hand sides in the caller's row order, row-major like xp -- read through the permutation here
+        //  instead of in a pass of its own)
+        double v = (i < nc) ? (A.b ? A.b[(int64_t)T.perm[c0 + i] * KP + cc] : xp[(int64_t)(c0 + i) * KP]) : 0.0;
         const int64_t lc = (int64_t)c0 + rp + i;
         const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
         for (int64_t g = g0; g < g1; g += 4) {
@@ -2038,7 +2040,13 @@ __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int 
         for (int q = kWC - 1; q >= 0; --q) {
             if (q < w) {
                 const double xj = acc[q];
-                if (act) xp[(int64_t)(c0 + jlo + q) * KP] = xj;
+                if (act) {
+                    xp[(int64_t)(c0 + jlo + q) * KP] = xj;
+                    if (A.out) {         // the solution in the caller's row order (+ add), stored here instead of in a pass of its own
+                        const int64_t o = (int64_t)T.perm[c0 + jlo + q] * KP + cc;
+                        A.out[o] = A.add ? xj + A.add[o] : xj;
+                    }
+                }
                 const double* __restrict__ Lj = F + (jlo + q) + (int64_t)jlo * f;   // L(jlo + q, jlo + q2) = Lj[q2 * f]
 #pragma unroll
                 for (int q2 = 0; q2 < kWC; ++q2)
@@ -2091,7 +2099,7 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
                 const int64_t lc = (int64_t)c0 + rp + i;
                 pg0[p] = T.gl_ptr[lc];
                 pg1[p] = T.gl_ptr[lc + 1];
-                pv[p] = xp[(int64_t)(c0 + i) * KP + (idx & 15)];
+                pv[p] = A.b ? A.b[(int64_t)T.perm[c0 + i] * KP + (xp - A.xp) + (idx & 15)] : xp[(int64_t)(c0 + i) * KP + (idx & 15)];
             }
         }
         // (measured r03: four sources per row and round instead of two -- sixteen loads per thread in flight -- was no
@@ -2255,6 +2263,10 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
         double v = 0.0;
         for (int s = 0; s < ns; ++s) v += part[(s * nt + jt) * 256 + (j & 15) * 16 + n];
         xp[(int64_t)(c0 + j) * KP + n] = v;
+        if (A.out) {
+            const int64_t o = (int64_t)T.perm[c0 + j] * KP + (xp - A.xp) + n;
+            A.out[o] = A.add ? v + A.add[o] : v;
+        }
     }
 }
 
