@@ -287,10 +287,11 @@ private:
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
         a.top_limit = 5000000;       // (the multi-column path has no persistent kernel)
         a.tk_pos = nullptr; a.tk_sl = nullptr; a.tbase = nullptr; a.xf = nullptr;
+        launch_pull_leaves_multi(a, n_pull_rows, KP, stream);        // (the pulled leaves' terms, summed per receiving row)
         for (const Launch& L : launches) launch_fwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
         for (size_t q = launches.size(); q-- > 0;) {
             const Launch& L = launches[q];
-            launch_bwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
+            launch_bwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream, L.level == 0);
         }
     }
 
@@ -1022,6 +1023,9 @@ private:
     bool top_tall = true;        // the persistent kernel's 1024-thread build (default) or its 512-thread one
     std::vector<int64_t> tile_base;   // per supernode: index of its first tile in `tiles` (-1: none)
     DBuf<int> d_gl_src, d_udst;
+    DBuf<int64_t> d_glm_ptr, d_hp_lidx, d_pr_ptr;     // many-column sweeps: gather lists without the pulled leaves, and the pulled terms
+    DBuf<int> d_udst_m, d_hp_col, d_hp_row, d_pr_slot;
+    int n_pull_rows = 0;
     std::vector<Launch> launches;
     std::vector<int> sched;
     std::vector<int64_t> tiles;
@@ -1035,6 +1039,7 @@ private:
         t.child_ptr = d_child_ptr.p; t.child_idx = d_child_idx.p; t.kptr = d_kptr.p;
         t.ksrc = d_ksrc.p; t.kdst = d_kdst.p; t.sched = d_sched.p; t.psign = d_psign.p; t.perm = d_perm.p;
         t.dense_off = d_dense_off.p; t.item_ptr = d_item_ptr.p; t.items = (const ExtItem*)d_items.p; t.gl_ptr = d_item_ptr.p; t.gl_src = d_gl_src.p; t.udst = d_udst.p;
+        t.glm_ptr = d_glm_ptr.p; t.udst_m = d_udst_m.p; t.hp_col = d_hp_col.p; t.hp_row = d_hp_row.p; t.hp_lidx = d_hp_lidx.p; t.pr_ptr = d_pr_ptr.p; t.pr_slot = d_pr_slot.p;
         t.cut_ptr = d_cut_ptr.p; t.cuts = d_cuts.p; t.wave_cut = d_wave_cut.p; t.tinv_off = d_tinv_off.p;
         t.sitems = (const SubItem*)d_sitems.p; t.tile_cut = d_tile_cut.p; t.desc = (const FrontDesc*)d_desc.p; t.sdesc = (const FrontDesc*)d_sdesc.p;
         t.spos = d_spos.p; t.sn_parent = d_sn_parent.p;
@@ -1213,6 +1218,20 @@ private:
 
     void upload(const std::vector<int>& dsigns)
     {
+        // leaves with one column and a short row list, pulled by their parents in the many-column sweeps (see the gather
+        // lists below; HIPKKT_PULL_LEAVES=0: none)
+        static const bool pull_on = !(std::getenv("HIPKKT_PULL_LEAVES") && std::atoi(std::getenv("HIPKKT_PULL_LEAVES")) == 0);
+        std::vector<char> pulled((size_t)S.nsuper, 0);
+        {
+            std::vector<char> in_small((size_t)S.nsuper, 0);       // (one-wave launches only: the block kernels do not know the flag)
+            for (const Launch& L : launches)
+                if (L.small) for (int t = L.begin; t < L.begin + L.count; ++t) in_small[(size_t)sched[(size_t)t]] = 1;
+            for (int s = 0; pull_on && s < S.nsuper; ++s) {
+                const int nb = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+                pulled[(size_t)s] = in_small[(size_t)s] && S.child_ptr[s + 1] == S.child_ptr[s] && S.sn_start[s + 1] - S.sn_start[s] == 1 &&
+                                    S.sn_parent[s] >= 0 && nb >= 1 && nb <= 47;
+            }
+        }
         d_sn_start.upload(S.sn_start);
         d_rowptr.upload(S.rowptr);
         d_rows.upload(S.rows);
@@ -1385,7 +1404,8 @@ private:
                 FrontDesc d;
                 d.front_off = S.front_off[s]; d.upd_off = S.upd_off[s]; d.w_off = toff[s]; d.rp = S.rowptr[s];
                 d.kptr = S.kptr[s]; d.s = s; d.c0 = S.sn_start[s]; d.nc = S.sn_start[s + 1] - S.sn_start[s];
-                d.nb = (int)(S.rowptr[s + 1] - S.rowptr[s]); d.nk = (int)(S.kptr[s + 1] - S.kptr[s]); d.pad = 0;
+                d.nb = (int)(S.rowptr[s + 1] - S.rowptr[s]); d.nk = (int)(S.kptr[s + 1] - S.kptr[s]);
+                d.pad = pulled[(size_t)s] ? 1 : 0;          // (launch records: bit 0 = a pulled leaf of the many-column sweeps, see below)
                 desc[q] = d;
             }
             std::vector<int64_t> rawd(desc.size() * 8);
@@ -1804,6 +1824,50 @@ private:
             std::vector<int> ud(std::max<size_t>(S.rows.size(), 1), 0);
             for (size_t g = 0; g < gsrc.size(); ++g) ud[(size_t)gsrc[g]] = (int)g;
             d_udst.upload(ud);
+            // PULLED LEAVES (many-column sweeps only).  Half of a sparse KKT system's contribution rows come from leaves with
+            // ONE column (cfg2: 113 k of them, the slack rows of the linear cone): forward, such a leaf only forwards
+            // u_r = -L(r,0) b_c to its parent's rows -- 4 KB per row and 512 columns, written and read once.  In the
+            // many-column sweeps the PARENT computes those terms itself from the leaf's row of B (one row instead of nb, and
+            // shared by the parent's rows through L2), the leaf does nothing forward, and its backward step is a gather
+            // kernel of its own (k_bwd_leaf_m).  The parent's gather list is split: the stored contributions of its other
+            // children (contiguous rows of the receiver-ordered store, as before, without the pulled ones) and the pulled
+            // terms (leaf column, position of L(r,0) in the fronts).
+            {
+                std::vector<int> row_sn(std::max<size_t>(S.rows.size(), 1), -1);
+                for (int c = 0; c < S.nsuper; ++c)
+                    for (int64_t q = S.rowptr[c]; q < S.rowptr[c + 1]; ++q) row_sn[(size_t)q] = c;
+                std::vector<int64_t> mptr((size_t)nloc + 1, 0), prp(1, 0);
+                std::vector<int> udm(std::max<size_t>(S.rows.size(), 1), -1), hcol, prs;
+                std::vector<int64_t> hl;
+                int64_t slot = 0;
+                for (int64_t lc = 0; lc < nloc; ++lc) {
+                    mptr[(size_t)lc] = slot;
+                    bool any = false;
+                    for (int64_t g = ptr[(size_t)lc]; g < ptr[(size_t)lc + 1] && !any; ++g) any = pulled[(size_t)row_sn[(size_t)gsrc[(size_t)g]]] != 0;
+                    if (any) prs.push_back((int)slot++);                  // the sum of this row's pulled terms: first of its run
+                    for (int64_t g = ptr[(size_t)lc]; g < ptr[(size_t)lc + 1]; ++g) {
+                        const int q = gsrc[(size_t)g], c = row_sn[(size_t)q];
+                        if (pulled[(size_t)c]) {
+                            hcol.push_back(S.sn_start[c]);
+                            hl.push_back(S.front_off[c] + 1 + ((int64_t)q - S.rowptr[c]));     // L(r, 0): column-major, ld f, nc = 1
+                        } else {
+                            udm[(size_t)q] = (int)slot++;
+                        }
+                    }
+                    if (any) prp.push_back((int64_t)hcol.size());
+                }
+                mptr[(size_t)nloc] = slot;
+                n_pull_rows = (int)prs.size();
+                if (hcol.empty()) { hcol.push_back(0); hl.push_back(0); }
+                if (prs.empty()) prs.push_back(0);
+                std::vector<int> hrow(hcol.size());
+                for (size_t k = 0; k < hcol.size(); ++k) hrow[k] = S.perm[(size_t)hcol[k]];
+                d_glm_ptr.upload(mptr); d_udst_m.upload(udm); d_hp_col.upload(hcol); d_hp_row.upload(hrow); d_hp_lidx.upload(hl);
+                d_pr_ptr.upload(prp); d_pr_slot.upload(prs);
+                if (std::getenv("HIPKKT_VERBOSE"))
+                    std::fprintf(stderr, "[hipkkt] many-column sweeps: %lld of %lld contribution rows pulled from one-column leaves into %d sums\n",
+                                 (long long)(hcol.size()), (long long)ptr[(size_t)nloc], n_pull_rows);
+            }
         }
         d_perm.upload(S.perm);
         std::vector<signed char> ps(S.N);

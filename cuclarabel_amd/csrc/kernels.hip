@@ -1596,24 +1596,29 @@ void launch_unpack_lhs_rm(double* lhsx, double* lhsz, const double* X, int n, in
 // workgroup = 16 rows x 16 columns per step; the row's matrix entries are the same for its 16 lanes, the gathered
 // x rows are 128 contiguous bytes
 constexpr int kRmBlocks = 512;
+template <int V>                 // columns per lane: 1, or 2 (16-byte accesses, KP a multiple of 32; r03, 512 columns: 2.2 -> see DESIGN.md)
 __global__ __launch_bounds__(256) void k_residual_rm(SpmvDev A, const double* __restrict__ B, const double* __restrict__ X,
                                                      double* __restrict__ E, double* __restrict__ partial,
                                                      double* __restrict__ bpartial, int KP)
 {
-    __shared__ double sh[2][16][17];
+    typedef double vec_t __attribute__((ext_vector_type(V)));
+    __shared__ double sh[2][16][16 * V + 1];
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
-    const int cb0 = blockIdx.y * 16;
-    double vmax = 0.0, bmax = 0.0;
+    const int cb0 = blockIdx.y * 16 * V + c * V;
+    double vmax[V], bmax[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) vmax[v] = bmax[v] = 0.0;
     for (int row = blockIdx.x * 16 + r; row < A.N; row += gridDim.x * 16) {
         const int64_t q0 = A.ptr[row], q1 = A.ptr[row + 1];
-        const double bv = B[(int64_t)row * KP + cb0 + c];
-        double acc = 0.0;
-        // eight entries in flight per round (indices and values, then the eight 128-byte rows of X), summed in row order:
+        const vec_t bv = *reinterpret_cast<const vec_t*>(B + (int64_t)row * KP + cb0);
+        vec_t acc = 0.0;
+        // eight entries in flight per round (indices and values, then the eight rows of X), summed in row order:
         // one entry per round left the gather latency-bound (r03, 512 columns: 2.9 ms per residual; four per round 2.25)
         constexpr int RU = 8;
         for (int64_t q = q0; q < q1; q += RU) {
             int cj[RU];
-            double vj[RU], xj[RU];
+            double vj[RU];
+            vec_t xj[RU];
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const bool ok = q + u < q1;
@@ -1621,24 +1626,37 @@ __global__ __launch_bounds__(256) void k_residual_rm(SpmvDev A, const double* __
                 vj[u] = ok ? A.val[q + u] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < RU; ++u) xj[u] = cj[u] >= 0 ? X[(int64_t)cj[u] * KP + cb0 + c] : 0.0;
+            for (int u = 0; u < RU; ++u) xj[u] = cj[u] >= 0 ? *reinterpret_cast<const vec_t*>(X + (int64_t)cj[u] * KP + cb0) : (vec_t)0.0;
 #pragma unroll
-            for (int u = 0; u < RU; ++u) if (cj[u] >= 0) acc = fma(vj[u], xj[u], acc);
+            for (int u = 0; u < RU; ++u)
+                if (cj[u] >= 0) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[v] = fma(vj[u], xj[u][v], acc[v]);
+                }
         }
-        const double rr = bv - acc;
-        E[(int64_t)row * KP + cb0 + c] = rr;
-        vmax = isfinite(rr) ? fmax(vmax, fabs(rr)) : INFINITY;
-        bmax = isfinite(bv) ? fmax(bmax, fabs(bv)) : INFINITY;
+        const vec_t rr = bv - acc;
+        *reinterpret_cast<vec_t*>(E + (int64_t)row * KP + cb0) = rr;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            vmax[v] = isfinite(rr[v]) ? fmax(vmax[v], fabs(rr[v])) : INFINITY;
+            bmax[v] = isfinite(bv[v]) ? fmax(bmax[v], fabs(bv[v])) : INFINITY;
+        }
     }
-    sh[0][r][c] = vmax;
-    sh[1][r][c] = bmax;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        sh[0][r][c * V + v] = vmax[v];
+        sh[1][r][c * V + v] = bmax[v];
+    }
     __syncthreads();
     if (r == 0) {
-        double v = 0.0, w = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { v = fmax(v, sh[0][k][c]); w = fmax(w, sh[1][k][c]); }
-        partial[(int64_t)blockIdx.x * KP + cb0 + c] = v;
-        if (bpartial) bpartial[(int64_t)blockIdx.x * KP + cb0 + c] = w;
+        for (int v = 0; v < V; ++v) {
+            double m = 0.0, w = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { m = fmax(m, sh[0][k][c * V + v]); w = fmax(w, sh[1][k][c * V + v]); }
+            partial[(int64_t)blockIdx.x * KP + cb0 + v] = m;
+            if (bpartial) bpartial[(int64_t)blockIdx.x * KP + cb0 + v] = w;
+        }
     }
 }
 // one workgroup per 64 columns, 16 threads per column over the partial rows (the maximum is order-independent); a single
@@ -1671,7 +1689,8 @@ void launch_residual_rm(const SpmvDev& A, const double* B, const double* X, doub
     if (g > kRmBlocks) g = kRmBlocks;
     if (g < 1) g = 1;
     double* bpartial = normb_out ? partial + (size_t)kRmBlocks * KP : nullptr;
-    hipLaunchKernelGGL(k_residual_rm, dim3(g, KP / 16), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
+    if (KP % 32 == 0) hipLaunchKernelGGL(k_residual_rm<2>, dim3(g, KP / 32), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
+    else hipLaunchKernelGGL(k_residual_rm<1>, dim3(g, KP / 16), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
     hipLaunchKernelGGL(k_finish_norm_rm, dim3((KP + 63) / 64), dim3(1024), 0, st, (const double*)partial, (const double*)bpartial, g,
                        KP, norm_out, normb_out);
 }

@@ -118,6 +118,18 @@ struct TreeDev {                 // device copies of the symbolic structure
     // inverse of gl_src: contribution entry e of the tree (index into uvec) is gather-list entry udst[e] of its
     // receiver.  The multi-column solve stores contributions in THAT order, so a receiver reads a contiguous run.
     const int* udst;
+    // many-column sweeps (solve_kernels.hip, k_*_m): one-column leaves are PULLED -- the parent computes -L(r,0) b_c from
+    // the leaf's row of B instead of reading a stored contribution row.  glm_ptr / udst_m are gl_ptr / udst without the
+    // pulled leaves' entries (udst_m = -1 for them), with one extra slot at the head of a row's run for the SUM of its pulled
+    // terms (k_pull_leaves_m); a term is the leaf's column hp_col (tree order) and the position hp_lidx of L(r,0) in
+    // `fronts`.  A pulled leaf's launch record has FrontDesc::pad bit 0 set.
+    const int64_t* glm_ptr;
+    const int* udst_m;
+    const int* hp_col;
+    const int* hp_row;           // = perm[hp_col]: the leaf's row in the caller's order
+    const int64_t* hp_lidx;
+    const int64_t* pr_ptr;       // receiving rows with pulled terms: row k's terms are pr_ptr[k] .. pr_ptr[k+1] of hp_*, their sum
+    const int* pr_slot;          // goes to slot pr_slot[k] of the receiver-ordered store (the first of the row's run)
     // per child c: cuts[cut_ptr[c] + t] = first child row index whose parent-local row >= nc_p + 64 t
     const int64_t* cut_ptr;
     const int* cuts;
@@ -249,7 +261,8 @@ void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const i
 void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st, const double* add = nullptr);
 void launch_permute_out(double* X, int64_t ldx, const double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
 void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
-void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
+void launch_pull_leaves_multi(const SolveArgs& a, int nrows, int KP, hipStream_t st);
+void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st, bool leaves = false);
 
 // ---- KKT value updates (kktsolver_directldl.jl:130-188, 211-245, 374-386)
 void launch_scatter(double* Kval, const int* idx, const double* vals, int64_t n, double scale, hipStream_t st);

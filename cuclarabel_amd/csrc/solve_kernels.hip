@@ -1950,6 +1950,7 @@ __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int 
     if (item >= count) return;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + item];
+    if (fd.pad & 1) return;                  // a pulled leaf: its parent computes its contributions (TreeDev::hp_*)
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
@@ -1959,6 +1960,7 @@ __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int 
     const int cc = act ? col : KP - 1;
     double* __restrict__ xp = A.xp + cc;
     double* __restrict__ uvec = A.uvec + cc;
+    const double* __restrict__ bsrc = A.b ? A.b + cc : nullptr;
 
     double yk[kWC];
 #pragma unroll
@@ -1966,9 +1968,9 @@ __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int 
     for (int i = 0; i < f; ++i) {
         // (A.b: the right-hand sides in the caller's row order, row-major like xp -- read through the permutation here
         //  instead of in a pass of its own)
-        double v = (i < nc) ? (A.b ? A.b[(int64_t)T.perm[c0 + i] * KP + cc] : xp[(int64_t)(c0 + i) * KP]) : 0.0;
+        double v = (i < nc) ? (bsrc ? bsrc[(int64_t)T.perm[c0 + i] * KP] : xp[(int64_t)(c0 + i) * KP]) : 0.0;
         const int64_t lc = (int64_t)c0 + rp + i;
-        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
+        const int64_t g0 = T.glm_ptr[lc], g1 = T.glm_ptr[lc + 1];
         for (int64_t g = g0; g < g1; g += 4) {
             double u[4];
 #pragma unroll
@@ -1988,13 +1990,107 @@ __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int 
                 if (k == i) yk[k] = v;
             if (act) xp[(int64_t)(c0 + i) * KP] = v;
         } else if (act) {
-            uvec[(int64_t)T.udst[rp + i - nc] * KP] = v;
+            uvec[(int64_t)T.udst_m[rp + i - nc] * KP] = v;
         }
     }
 }
 
 // own columns in chunks of kWC from the last one up: acc_j = D^{-1} y_j - sum over the rows below the chunk,
 // each such row loaded once; then the triangle inside the chunk from registers
+// Forward: the pulled leaves' terms, summed per RECEIVING row before the tree is walked: row k of the list (TreeDev::pr_*)
+// gets sum_h -L(r,0) b_c over its pulled leaves and stores it as the first entry of its run in the receiver-ordered
+// contribution store -- the parents read it like any other stored contribution.  A gather like the residual's: 16 lanes
+// per (row, block of 16 columns), eight leaf rows of B in flight (a leaf's row serves all the parent rows it reaches: L2).
+template <int V>                 // columns per lane (1, or 2: double2 accesses, KP a multiple of 32)
+__global__ __launch_bounds__(256) void k_pull_leaves_m(SolveArgs A, int nrows, int KP)
+{
+    typedef double vec_t __attribute__((ext_vector_type(V)));
+    const int c = threadIdx.x & 15;
+    const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (k >= nrows) return;
+    const TreeDev& T = A.T;
+    const int64_t h0 = T.pr_ptr[k], h1 = T.pr_ptr[k + 1];
+    const int64_t col = ((int64_t)blockIdx.y * 16 + c) * V;
+    const int* __restrict__ hrow = A.b ? T.hp_row : T.hp_col;       // the leaf's row of B: caller's order / tree order
+    const double* __restrict__ src = A.b ? A.b : A.xp;
+    vec_t acc = 0.0;
+    for (int64_t h = h0; h < h1; h += 4) {
+        vec_t u[4];
+        double l[4];
+        int cj[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = h + e < h1;
+            cj[e] = ok ? hrow[h + e] : -1;
+            l[e] = ok ? A.fronts[T.hp_lidx[h + e]] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = cj[e] >= 0 ? *reinterpret_cast<const vec_t*>(src + (int64_t)cj[e] * KP + col) : (vec_t)0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (cj[e] >= 0) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = fma(-l[e], u[e][v], acc[v]);
+            }
+    }
+    *reinterpret_cast<vec_t*>(A.uvec + (int64_t)T.pr_slot[k] * KP + col) = acc;
+}
+void launch_pull_leaves_multi(const SolveArgs& a, int nrows, int KP, hipStream_t st)
+{
+    if (nrows <= 0) return;
+    if (KP % 32 == 0) hipLaunchKernelGGL(k_pull_leaves_m<2>, dim3((nrows + 15) / 16, KP / 32), dim3(256), 0, st, a, nrows, KP);
+    else hipLaunchKernelGGL(k_pull_leaves_m<1>, dim3((nrows + 15) / 16, KP / 16), dim3(256), 0, st, a, nrows, KP);
+}
+
+// Backward step of the PULLED leaves of a launch (one column, a handful of rows: TreeDev::hp_*): x_c = y_c / d_c - sum_r
+// L(r,0) x_r with y_c = b_c -- a gather like the residual's: 16 lanes per (leaf, block of 16 columns), the leaf's rows of
+// the ancestors' x all in flight (they are shared by the leaves of a parent: L2), same order of operations as k_bwd_wave_m.
+template <int V>
+__global__ __launch_bounds__(256) void k_bwd_leaf_m(SolveArgs A, int begin, int count, int KP)
+{
+    typedef double vec_t __attribute__((ext_vector_type(V)));
+    const int c = threadIdx.x & 15;
+    const int item = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (item >= count) return;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + item];
+    if (!(fd.pad & 1)) return;
+    const int c0 = fd.c0, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const double* __restrict__ F = A.fronts + fd.front_off;          // column 0: 1, L(1,0), L(2,0), ...
+    const int64_t col = ((int64_t)blockIdx.y * 16 + c) * V;
+    const int64_t orow = (int64_t)T.perm[c0] * KP + col;
+    const vec_t y = A.b ? *reinterpret_cast<const vec_t*>(A.b + orow) : *reinterpret_cast<const vec_t*>(A.xp + (int64_t)c0 * KP + col);
+    const double dinv = A.Dinv[c0];
+    vec_t acc;
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = y[v] * dinv;
+    for (int r0 = 0; r0 < nb; r0 += 8) {
+        vec_t xr[8];
+        double l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = r0 + e < nb;
+            l[e] = ok ? F[1 + r0 + e] : 0.0;
+            xr[e] = ok ? *reinterpret_cast<const vec_t*>(A.xp + (int64_t)T.rows[rp + r0 + e] * KP + col) : (vec_t)0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (r0 + e < nb) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = fma(-l[e], xr[e][v], acc[v]);
+            }
+    }
+    // (nobody reads a leaf's x from the tree-ordered copy: it is stored there only where that copy IS the result)
+    if (A.out) {
+        vec_t o = acc;
+        if (A.add) { const vec_t a = *reinterpret_cast<const vec_t*>(A.add + orow); o += a; }
+        *reinterpret_cast<vec_t*>(A.out + orow) = o;
+    } else {
+        *reinterpret_cast<vec_t*>(A.xp + (int64_t)c0 * KP + col) = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int count, int KP)
 {
     const int lane = threadIdx.x & 63;
@@ -2002,6 +2098,7 @@ __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int 
     if (item >= count) return;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + item];
+    if (fd.pad & 1) return;                  // a pulled leaf: k_bwd_leaf_m
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
@@ -2097,8 +2194,8 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
             pv[p] = 0.0;
             if (i < nc) {
                 const int64_t lc = (int64_t)c0 + rp + i;
-                pg0[p] = T.gl_ptr[lc];
-                pg1[p] = T.gl_ptr[lc + 1];
+                pg0[p] = T.glm_ptr[lc];
+                pg1[p] = T.glm_ptr[lc + 1];
                 pv[p] = A.b ? A.b[(int64_t)T.perm[c0 + i] * KP + (xp - A.xp) + (idx & 15)] : xp[(int64_t)(c0 + i) * KP + (idx & 15)];
             }
         }
@@ -2138,9 +2235,9 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
             ud[q] = 0;
             if (i >= nc && i < f) {
                 const int64_t lc = (int64_t)c0 + rp + i;
-                g0[q] = T.gl_ptr[lc];
-                g1[q] = T.gl_ptr[lc + 1];
-                ud[q] = T.udst[rp + i - nc];
+                g0[q] = T.glm_ptr[lc];
+                g1[q] = T.glm_ptr[lc + 1];
+                ud[q] = T.udst_m[rp + i - nc];
             }
         }
         d4m_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -2324,11 +2421,16 @@ void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     if (KP >= 128) hipLaunchKernelGGL(k_fwd_block_m<256>, grid, dim3(256), lds, st, a, begin, count, KP);
     else hipLaunchKernelGGL(k_fwd_block_m<512>, grid, dim3(512), lds, st, a, begin, count, KP);
 }
-void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st)
+void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st, bool leaves)
 {
     if (count <= 0) return;
     if (small) {
         hipLaunchKernelGGL(k_bwd_wave_m, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
+        // the launch's pulled leaves (tree level 0 only: they have no children)
+        if (leaves) {
+            if (KP % 32 == 0) hipLaunchKernelGGL(k_bwd_leaf_m<2>, dim3((count + 15) / 16, KP / 32), dim3(256), 0, st, a, begin, count, KP);
+            else hipLaunchKernelGGL(k_bwd_leaf_m<1>, dim3((count + 15) / 16, KP / 16), dim3(256), 0, st, a, begin, count, KP);
+        }
         return;
     }
     // at most max(8, nt) partial tiles of 16 x 16
