@@ -1943,8 +1943,12 @@ __global__ __launch_bounds__(256) void k_permute_out(double* __restrict__ X, int
 constexpr int kWC = 16;
 
 // xp (N x KP) holds the permuted right-hand sides on entry of the forward sweep
+// V columns per lane (2: 16-byte accesses, a wave covers 128 columns; the row loop is a chain of dependent loads, so twice
+// the bytes per step is nearly twice the rate)
+template <int V>
 __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int count, int KP)
 {
+    typedef double vec_t __attribute__((ext_vector_type(V)));
     const int lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= count) return;
@@ -1955,26 +1959,29 @@ __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int 
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    const int col = blockIdx.y * 64 + lane;
+    const int col = (blockIdx.y * 64 + lane) * V;
     const bool act = col < KP;
-    const int cc = act ? col : KP - 1;
+    const int cc = act ? col : KP - V;
     double* __restrict__ xp = A.xp + cc;
     double* __restrict__ uvec = A.uvec + cc;
     const double* __restrict__ bsrc = A.b ? A.b + cc : nullptr;
+    auto ld = [](const double* p) -> vec_t { return *reinterpret_cast<const vec_t*>(p); };
+    auto st = [](double* p, vec_t v) { *reinterpret_cast<vec_t*>(p) = v; };
 
-    double yk[kWC];
+    vec_t yk[kWC];
 #pragma unroll
     for (int k = 0; k < kWC; ++k) yk[k] = 0.0;
     for (int i = 0; i < f; ++i) {
         // (A.b: the right-hand sides in the caller's row order, row-major like xp -- read through the permutation here
         //  instead of in a pass of its own)
-        double v = (i < nc) ? (bsrc ? bsrc[(int64_t)T.perm[c0 + i] * KP] : xp[(int64_t)(c0 + i) * KP]) : 0.0;
+        vec_t v = 0.0;
+        if (i < nc) v = bsrc ? ld(bsrc + (int64_t)T.perm[c0 + i] * KP) : ld(xp + (int64_t)(c0 + i) * KP);
         const int64_t lc = (int64_t)c0 + rp + i;
         const int64_t g0 = T.glm_ptr[lc], g1 = T.glm_ptr[lc + 1];
         for (int64_t g = g0; g < g1; g += 4) {
-            double u[4];
+            vec_t u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = (g + q < g1) ? uvec[(g + q) * KP] : 0.0;
+            for (int q = 0; q < 4; ++q) u[q] = (g + q < g1) ? ld(uvec + (g + q) * KP) : (vec_t)0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) v += u[q];
         }
@@ -1982,15 +1989,24 @@ __global__ __launch_bounds__(256) void k_fwd_wave_m(SolveArgs A, int begin, int 
         const double* __restrict__ Li = F + i;                 // L(i, k) = Li[k * f]
 #pragma unroll
         for (int k = 0; k < kWC; ++k)
-            if (k < km) v = fma(-Li[(int64_t)k * f], yk[k], v);
-        for (int k = kWC; k < km; ++k) v = fma(-Li[(int64_t)k * f], xp[(int64_t)(c0 + k) * KP], v);
+            if (k < km) {
+                const double l = -Li[(int64_t)k * f];
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] = fma(l, yk[k][e], v[e]);
+            }
+        for (int k = kWC; k < km; ++k) {
+            const double l = -Li[(int64_t)k * f];
+            const vec_t y = ld(xp + (int64_t)(c0 + k) * KP);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = fma(l, y[e], v[e]);
+        }
         if (i < nc) {
 #pragma unroll
             for (int k = 0; k < kWC; ++k)
                 if (k == i) yk[k] = v;
-            if (act) xp[(int64_t)(c0 + i) * KP] = v;
+            if (act) st(xp + (int64_t)(c0 + i) * KP, v);
         } else if (act) {
-            uvec[(int64_t)T.udst_m[rp + i - nc] * KP] = v;
+            st(uvec + (int64_t)T.udst_m[rp + i - nc] * KP, v);
         }
     }
 }
@@ -2091,8 +2107,10 @@ __global__ __launch_bounds__(256) void k_bwd_leaf_m(SolveArgs A, int begin, int 
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int count, int KP)
 {
+    typedef double vec_t __attribute__((ext_vector_type(V)));
     const int lane = threadIdx.x & 63;
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= count) return;
@@ -2103,24 +2121,34 @@ __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int 
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ F = A.fronts + fd.front_off;
-    const int col = blockIdx.y * 64 + lane;
+    const int col = (blockIdx.y * 64 + lane) * V;
     const bool act = col < KP;
-    const int cc = act ? col : KP - 1;
+    const int cc = act ? col : KP - V;
     double* __restrict__ xp = A.xp + cc;
+    auto ld = [](const double* p) -> vec_t { return *reinterpret_cast<const vec_t*>(p); };
+    auto st = [](double* p, vec_t v) { *reinterpret_cast<vec_t*>(p) = v; };
 
     for (int jhi = nc; jhi > 0; jhi -= kWC) {
         const int jlo = max(0, jhi - kWC);
         const int w = jhi - jlo;
-        double acc[kWC];
+        vec_t acc[kWC];
 #pragma unroll
-        for (int q = 0; q < kWC; ++q) acc[q] = (q < w) ? xp[(int64_t)(c0 + jlo + q) * KP] * A.Dinv[c0 + jlo + q] : 0.0;
+        for (int q = 0; q < kWC; ++q) {
+            acc[q] = 0.0;
+            if (q < w) {
+                const vec_t y = ld(xp + (int64_t)(c0 + jlo + q) * KP);
+                const double d = A.Dinv[c0 + jlo + q];
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[q][e] = y[e] * d;
+            }
+        }
         for (int r0 = jhi; r0 < f; r0 += 4) {
-            double xr[4];
+            vec_t xr[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = r0 + e;
                 xr[e] = 0.0;
-                if (r < f) xr[e] = xp[(int64_t)(r < nc ? c0 + r : T.rows[rp + r - nc]) * KP];
+                if (r < f) xr[e] = ld(xp + (int64_t)(r < nc ? c0 + r : T.rows[rp + r - nc]) * KP);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2129,25 +2157,35 @@ __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int 
                     const double* __restrict__ Lr = F + r + (int64_t)jlo * f;      // L(r, jlo + q) = Lr[q * f]
 #pragma unroll
                     for (int q = 0; q < kWC; ++q)
-                        if (q < w) acc[q] = fma(-Lr[(int64_t)q * f], xr[e], acc[q]);
+                        if (q < w) {
+                            const double l = -Lr[(int64_t)q * f];
+#pragma unroll
+                            for (int z = 0; z < V; ++z) acc[q][z] = fma(l, xr[e][z], acc[q][z]);
+                        }
                 }
             }
         }
 #pragma unroll
         for (int q = kWC - 1; q >= 0; --q) {
             if (q < w) {
-                const double xj = acc[q];
+                const vec_t xj = acc[q];
                 if (act) {
-                    xp[(int64_t)(c0 + jlo + q) * KP] = xj;
+                    st(xp + (int64_t)(c0 + jlo + q) * KP, xj);
                     if (A.out) {         // the solution in the caller's row order (+ add), stored here instead of in a pass of its own
                         const int64_t o = (int64_t)T.perm[c0 + jlo + q] * KP + cc;
-                        A.out[o] = A.add ? xj + A.add[o] : xj;
+                        vec_t ov = xj;
+                        if (A.add) ov += ld(A.add + o);
+                        st(A.out + o, ov);
                     }
                 }
                 const double* __restrict__ Lj = F + (jlo + q) + (int64_t)jlo * f;   // L(jlo + q, jlo + q2) = Lj[q2 * f]
 #pragma unroll
                 for (int q2 = 0; q2 < kWC; ++q2)
-                    if (q2 < q) acc[q2] = fma(-Lj[(int64_t)q2 * f], xj, acc[q2]);
+                    if (q2 < q) {
+                        const double l = -Lj[(int64_t)q2 * f];
+#pragma unroll
+                        for (int z = 0; z < V; ++z) acc[q2][z] = fma(l, xj[z], acc[q2][z]);
+                    }
             }
         }
     }
@@ -2412,7 +2450,8 @@ void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
 {
     if (count <= 0) return;
     if (small) {
-        hipLaunchKernelGGL(k_fwd_wave_m, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
+        if (KP % 128 == 0) hipLaunchKernelGGL(k_fwd_wave_m<2>, dim3((count + 3) / 4, KP / 128), dim3(256), 0, st, a, begin, count, KP);
+        else hipLaunchKernelGGL(k_fwd_wave_m<1>, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
         return;
     }
     const size_t lds = (size_t)((ncmax + 3) & ~3) * 16 * sizeof(double);
@@ -2425,7 +2464,8 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
 {
     if (count <= 0) return;
     if (small) {
-        hipLaunchKernelGGL(k_bwd_wave_m, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
+        if (KP % 128 == 0) hipLaunchKernelGGL(k_bwd_wave_m<2>, dim3((count + 3) / 4, KP / 128), dim3(256), 0, st, a, begin, count, KP);
+        else hipLaunchKernelGGL(k_bwd_wave_m<1>, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
         // the launch's pulled leaves (tree level 0 only: they have no children)
         if (leaves) {
             if (KP % 32 == 0) hipLaunchKernelGGL(k_bwd_leaf_m<2>, dim3((count + 15) / 16, KP / 32), dim3(256), 0, st, a, begin, count, KP);

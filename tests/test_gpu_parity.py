@@ -315,6 +315,37 @@ def test_solve_multi_matches_single_solves_and_oracle(name, maker):
     assert ok and ir0.size == 0
 
 
+@pytest.mark.parametrize("k", [64, 128])
+def test_many_columns_take_the_wide_access_paths(k):
+    """64 and 128 right-hand sides: the column counts at which the many-column kernels switch to 16-byte accesses
+    (32 | KP: the pulled leaves' gather kernels and the row-major residual; 128 | KP: the one-wave sweep kernels) -- and
+    the pulled one-column leaves themselves (cfg2's slack rows).  Sampled columns against their own single solves and the
+    oracle; a zero and a badly scaled column among them."""
+    _, HipKKTSolver, _ = _hip()
+    pb = problems.config2(n=6000)
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    o = _oracle_for(pb, ks)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    rng = np.random.default_rng(500 + k)
+    RX, RZ = rng.standard_normal((pb.n, k)), rng.standard_normal((pb.m, k))
+    RX[:, 3] = 0.0; RZ[:, 3] = 0.0
+    RX[:, k - 2] *= 1e6; RZ[:, k - 2] *= 1e6
+    ok, LX, LZ, ir = ks.kktsolver_solve_multi(RX, RZ)
+    assert ok and not LX[:, 3].any() and not LZ[:, 3].any() and ir[3] == 0
+    for j in (0, 1, 31, 32, k // 2 + 1, k - 2, k - 1):
+        ks.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        scale = max(np.abs(x).max(), np.abs(z).max())
+        assert max(np.abs(LX[:, j] - x).max(), np.abs(LZ[:, j] - z).max()) / scale < 1e-12, j
+        assert abs(int(ir[j]) - ks.last_ir_iterations) <= 1, j
+        o.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        oko, xo, zo = o.kktsolver_solve()
+        so = max(np.abs(xo).max(), np.abs(zo).max())
+        assert oko and max(np.abs(LX[:, j] - xo).max(), np.abs(LZ[:, j] - zo).max()) / so < 1e-9, j
+
+
 def test_level_A_solve_multi_matches_column_solves():
     _, _, HipDirectLDLSolver = _hip()
     pb = problems.config2(n=1500)
