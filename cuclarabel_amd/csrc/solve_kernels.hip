@@ -2194,7 +2194,9 @@ __global__ __launch_bounds__(256) void k_bwd_wave_m(SolveArgs A, int begin, int 
 // forward, block fronts: Ys = gathered own rows (nc x 16, LDS); every wave takes 16-row tiles of W,
 // out = W Ys on the matrix cores; rows below the diagonal block gather their children's contributions
 // in the epilogue (they are only needed there).
-template <int BS>
+// CT column tiles of 16 per workgroup (2 where 32 | KP: every W entry, gather-list bound, row index and store position is
+// fetched once for 32 columns instead of 16, the gathered rows are 256 contiguous bytes)
+template <int BS, int CT>
 __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int count, int KP)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -2205,7 +2207,8 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
     // Grid (8, ceil(count / 8) * column blocks): workgroup (x, y) takes front 8 (y / ncb) + x and column block y % ncb.  A
     // launch's workgroups go to the XCDs round-robin by linear index, i.e. by x here: all column blocks of a front run on
     // ONE XCD and share its L2, so the front's W comes from HBM once instead of once per XCD (or per column block).
-    const int ncb = KP / kMultiCB;
+    constexpr int CB = 16 * CT;
+    const int ncb = KP / CB;
     const int fi = 8 * ((int)blockIdx.y / ncb) + (int)blockIdx.x, cbk = (int)blockIdx.y % ncb;
     if (fi >= count) return;
     const FrontDesc fd = T.desc[begin + fi];
@@ -2213,28 +2216,28 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ W = A.tinv + fd.w_off;                  // f x nc, ld f
-    double* __restrict__ xp = A.xp + cbk * kMultiCB;
-    double* __restrict__ uvec = A.uvec + cbk * kMultiCB;
+    double* __restrict__ xp = A.xp + cbk * CB;
+    double* __restrict__ uvec = A.uvec + cbk * CB;
     const int ncp = (nc + 3) & ~3;
-    double* Ys = smem;                       // ncp x 16 row-major
+    double* Ys = smem;                       // ncp x CB row-major
 
     // own rows: thread = (row, column); four rows per thread in flight so that the dependent chain
     // gather-list bounds -> sources -> values is paid once per four rows
     constexpr int NW = BS / 64;
-    for (int base = 0; base < ncp * 16; base += 4 * BS) {
+    for (int base = 0; base < ncp * CB; base += 4 * BS) {
         int64_t pg0[4], pg1[4];
         double pv[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int idx = base + p * BS + tid;
-            const int i = idx >> 4;
+            const int i = idx / CB;
             pg0[p] = pg1[p] = 0;
             pv[p] = 0.0;
             if (i < nc) {
                 const int64_t lc = (int64_t)c0 + rp + i;
                 pg0[p] = T.glm_ptr[lc];
                 pg1[p] = T.glm_ptr[lc + 1];
-                pv[p] = A.b ? A.b[(int64_t)T.perm[c0 + i] * KP + (xp - A.xp) + (idx & 15)] : xp[(int64_t)(c0 + i) * KP + (idx & 15)];
+                pv[p] = A.b ? A.b[(int64_t)T.perm[c0 + i] * KP + (xp - A.xp) + (idx & (CB - 1))] : xp[(int64_t)(c0 + i) * KP + (idx & (CB - 1))];
             }
         }
         // (measured r03: four sources per row and round instead of two -- sixteen loads per thread in flight -- was no
@@ -2249,14 +2252,14 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
-                    u[p][d] = (pg0[p] + e + d < pg1[p]) ? uvec[(pg0[p] + e + d) * KP + (tid & 15)] : 0.0;
+                    u[p][d] = (pg0[p] + e + d < pg1[p]) ? uvec[(pg0[p] + e + d) * KP + (tid & (CB - 1))] : 0.0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) pv[p] = (pv[p] + u[p][0]) + u[p][1];
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int idx = base + p * BS + tid;
-            if (idx < ncp * 16) Ys[idx] = pv[p];
+            if (idx < ncp * CB) Ys[idx] = pv[p];
         }
     }
     __syncthreads();
@@ -2278,7 +2281,9 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
                 ud[q] = T.udst_m[rp + i - nc];
             }
         }
-        d4m_t acc = {0.0, 0.0, 0.0, 0.0};
+        d4m_t acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = (d4m_t){0.0, 0.0, 0.0, 0.0};
         const int kend = min(nc, r0 + 16);               // T = L11^{-1} is lower triangular
         const bool rowok = r0 + ml < f;
         const double* __restrict__ Wr = W + r0 + ml;
@@ -2293,31 +2298,44 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
             for (int s = 0; s < 8; ++s) {
                 if (k0 + 4 * s < kend) {
                     const int k = k0 + 4 * s + mk;       // < ncp
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Ys[k * 16 + ml], acc, 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Ys[k * CB + 16 * ct + ml], acc[ct], 0, 0, 0);
                 }
             }
         }
         // epilogue: the four rows' gather lists advance together (one dependent chain for all of them)
-        double gv[4] = {0.0, 0.0, 0.0, 0.0};
+        double gv[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gv[ct][q] = 0.0;
         for (int e = 0;; e += 2) {
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) any = any || g0[q] + e < g1[q];
             if (!any) break;
-            double u[4][2];
+            double u[CT][4][2];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
-                    u[q][d] = (g0[q] + e + d < g1[q]) ? uvec[(g0[q] + e + d) * KP + ml] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gv[q] = (gv[q] + u[q][0]) + u[q][1];
+                    for (int ct = 0; ct < CT; ++ct)
+                        u[ct][q][d] = (g0[q] + e + d < g1[q]) ? uvec[(g0[q] + e + d) * KP + 16 * ct + ml] : 0.0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gv[ct][q] = (gv[ct][q] + u[ct][q][0]) + u[ct][q][1];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = r0 + mk + 4 * q;
-            if (i < nc) xp[(int64_t)(c0 + i) * KP + ml] = acc[q];
-            else if (i < f) uvec[(int64_t)ud[q] * KP + ml] = gv[q] - acc[q];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (i < nc) xp[(int64_t)(c0 + i) * KP + 16 * ct + ml] = acc[ct][q];
+                else if (i < f) uvec[(int64_t)ud[q] * KP + 16 * ct + ml] = gv[ct][q] - acc[ct][q];
+            }
         }
     }
 }
@@ -2332,7 +2350,7 @@ __device__ inline int bwd_multi_slices(int nt, int f, int nwaves)
     if (ns > cap) ns = cap;
     return ns < 1 ? 1 : ns;
 }
-template <int BS>
+template <int BS, int CT>
 __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int count, int KP)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -2340,7 +2358,8 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 15, mk = lane >> 4;
     const TreeDev& T = A.T;
-    const int ncb = KP / kMultiCB;                    // (grid as in k_fwd_block_m: a front's column blocks on one XCD)
+    constexpr int CB = 16 * CT;
+    const int ncb = KP / CB;                    // (grid as in k_fwd_block_m: a front's column blocks on one XCD)
     const int fi = 8 * ((int)blockIdx.y / ncb) + (int)blockIdx.x, cbk = (int)blockIdx.y % ncb;
     if (fi >= count) return;
     const FrontDesc fd = T.desc[begin + fi];
@@ -2348,12 +2367,12 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
     const int64_t rp = fd.rp;
     const int f = nc + nb;
     const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;       // W'(j, r) at j + r*nc
-    double* __restrict__ xp = A.xp + cbk * kMultiCB;
+    double* __restrict__ xp = A.xp + cbk * CB;
     const int nt = (nc + 15) >> 4;
     constexpr int NW = BS / 64;
     const int ns = bwd_multi_slices(nt, f, NW);
     const int sl = ((((f + ns - 1) / ns) + 3) >> 2) << 2;
-    double* part = smem;                     // (ns * nt) tiles of 16 x 16
+    double* part = smem;                     // (ns * nt) x CT tiles of 16 x 16
 
     for (int it = wv; it < nt * ns; it += NW) {
         const int s = it / nt, jt = it - s * nt;
@@ -2362,7 +2381,9 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
         const int rend = min(f, (s + 1) * sl);
         const bool colok = j0 + ml < nc;
         const double* __restrict__ Wc = Wt + j0 + ml;
-        d4m_t acc = {0.0, 0.0, 0.0, 0.0};
+        d4m_t acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = (d4m_t){0.0, 0.0, 0.0, 0.0};
         for (int r0 = rbeg; r0 < rend; r0 += 32) {
             int ri[8];
 #pragma unroll
@@ -2371,32 +2392,39 @@ __global__ __launch_bounds__(BS) void k_bwd_block_m(SolveArgs A, int begin, int 
                 ri[q] = -1;
                 if (r < rend) ri[q] = (r < nc) ? c0 + r : T.rows[rp + r - nc];
             }
-            double a[8], b[8];
+            double a[8], b[CT][8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int r = r0 + 4 * q + mk;
                 a[q] = (colok && r < rend) ? Wc[(int64_t)r * nc] : 0.0;
-                b[q] = ri[q] >= 0 ? xp[(int64_t)ri[q] * KP + ml] : 0.0;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) b[ct][q] = ri[q] >= 0 ? xp[(int64_t)ri[q] * KP + 16 * ct + ml] : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int r = r0 + 4 * q + mk;
-                if (r < nc) b[q] *= A.Dinv[c0 + r];
-                else b[q] = -b[q];
+                const double sc = (r < nc) ? A.Dinv[c0 + r] : -1.0;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) b[ct][q] = (r < nc) ? b[ct][q] * sc : -b[ct][q];
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (r0 + 4 * q < rend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+                if (r0 + 4 * q < rend) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[ct][q], acc[ct], 0, 0, 0);
+                }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) part[it * 256 + (mk + 4 * q) * 16 + ml] = acc[q];
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[(it * CT + ct) * 256 + (mk + 4 * q) * 16 + ml] = acc[ct][q];
     }
     __syncthreads();
-    for (int idx = tid; idx < nc * 16; idx += BS) {
-        const int j = idx >> 4, n = idx & 15;
+    for (int idx = tid; idx < nc * CB; idx += BS) {
+        const int j = idx / CB, n = idx & (CB - 1);
         const int jt = j >> 4;
         double v = 0.0;
-        for (int s = 0; s < ns; ++s) v += part[(s * nt + jt) * 256 + (j & 15) * 16 + n];
+        for (int s = 0; s < ns; ++s) v += part[((s * nt + jt) * CT + (n >> 4)) * 256 + (j & 15) * 16 + (n & 15)];
         xp[(int64_t)(c0 + j) * KP + n] = v;
         if (A.out) {
             const int64_t o = (int64_t)T.perm[c0 + j] * KP + (xp - A.xp) + n;
@@ -2454,11 +2482,18 @@ void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
         else hipLaunchKernelGGL(k_fwd_wave_m<1>, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
         return;
     }
-    const size_t lds = (size_t)((ncmax + 3) & ~3) * 16 * sizeof(double);
     // many column blocks: smaller workgroups, more fronts in flight (measured: 256 columns 21.4 vs 23.4 ms)
+    static const bool wide = !(std::getenv("HIPKKT_MULTI_CT") && std::atoi(std::getenv("HIPKKT_MULTI_CT")) == 1);
+    if (wide && KP % 32 == 0 && KP >= 256) {         // (measured: 128 columns 6.2 vs 6.4 ms, 512 columns 19.8 vs 19.1)
+        const size_t lds = (size_t)((ncmax + 3) & ~3) * 32 * sizeof(double);
+        const dim3 grid(8, ((count + 7) / 8) * (KP / 32));
+        hipLaunchKernelGGL((k_fwd_block_m<256, 2>), grid, dim3(256), lds, st, a, begin, count, KP);
+        return;
+    }
+    const size_t lds = (size_t)((ncmax + 3) & ~3) * 16 * sizeof(double);
     const dim3 grid(8, ((count + 7) / 8) * (KP / kMultiCB));
-    if (KP >= 128) hipLaunchKernelGGL(k_fwd_block_m<256>, grid, dim3(256), lds, st, a, begin, count, KP);
-    else hipLaunchKernelGGL(k_fwd_block_m<512>, grid, dim3(512), lds, st, a, begin, count, KP);
+    if (KP >= 128) hipLaunchKernelGGL((k_fwd_block_m<256, 1>), grid, dim3(256), lds, st, a, begin, count, KP);
+    else hipLaunchKernelGGL((k_fwd_block_m<512, 1>), grid, dim3(512), lds, st, a, begin, count, KP);
 }
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st, bool leaves)
 {
@@ -2475,10 +2510,17 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     }
     // at most max(8, nt) partial tiles of 16 x 16
     const int nt = (ncmax + 15) >> 4;
+    static const bool wide = !(std::getenv("HIPKKT_MULTI_CT") && std::atoi(std::getenv("HIPKKT_MULTI_CT")) == 1);
+    if (wide && KP % 32 == 0 && KP >= 256) {         // (measured: 128 columns 6.2 vs 6.4 ms, 512 columns 19.8 vs 19.1)
+        const size_t lds = (size_t)std::max(8, nt) * 256 * 2 * sizeof(double);
+        const dim3 grid(8, ((count + 7) / 8) * (KP / 32));
+        hipLaunchKernelGGL((k_bwd_block_m<256, 2>), grid, dim3(256), lds, st, a, begin, count, KP);
+        return;
+    }
     const size_t lds = (size_t)std::max(8, nt) * 256 * sizeof(double);
     const dim3 grid(8, ((count + 7) / 8) * (KP / kMultiCB));
-    if (KP >= 128) hipLaunchKernelGGL(k_bwd_block_m<256>, grid, dim3(256), lds, st, a, begin, count, KP);
-    else hipLaunchKernelGGL(k_bwd_block_m<512>, grid, dim3(512), lds, st, a, begin, count, KP);
+    if (KP >= 128) hipLaunchKernelGGL((k_bwd_block_m<256, 1>), grid, dim3(256), lds, st, a, begin, count, KP);
+    else hipLaunchKernelGGL((k_bwd_block_m<512, 1>), grid, dim3(512), lds, st, a, begin, count, KP);
 }
 
 // resident workgroups the device guarantees for the persistent kernel with `lds` bytes of dynamic LDS (the 1024-thread
