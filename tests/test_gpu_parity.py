@@ -315,10 +315,11 @@ def test_solve_multi_matches_single_solves_and_oracle(name, maker):
     assert ok and ir0.size == 0
 
 
-@pytest.mark.parametrize("k", [64, 128])
+@pytest.mark.parametrize("k", [64, 128, 256])
 def test_many_columns_take_the_wide_access_paths(k):
-    """64 and 128 right-hand sides: the column counts at which the many-column kernels switch to 16-byte accesses
-    (32 | KP: the pulled leaves' gather kernels and the row-major residual; 128 | KP: the one-wave sweep kernels) -- and
+    """64, 128 and 256 right-hand sides: the column counts at which the many-column kernels switch to 16-byte accesses
+    (32 | KP: the pulled leaves' gather kernels and the row-major residual; 128 | KP: the one-wave sweep kernels) and to
+    32 columns per workgroup in the block sweep kernels (from 256 columns) -- and
     the pulled one-column leaves themselves (cfg2's slack rows).  Sampled columns against their own single solves and the
     oracle; a zero and a badly scaled column among them."""
     _, HipKKTSolver, _ = _hip()
