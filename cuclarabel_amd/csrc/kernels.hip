@@ -1689,7 +1689,9 @@ void launch_residual_rm(const SpmvDev& A, const double* B, const double* X, doub
     if (g > kRmBlocks) g = kRmBlocks;
     if (g < 1) g = 1;
     double* bpartial = normb_out ? partial + (size_t)kRmBlocks * KP : nullptr;
-    if (KP % 32 == 0) hipLaunchKernelGGL(k_residual_rm<2>, dim3(g, KP / 32), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
+    static const int vmax = std::getenv("HIPKKT_MULTI_VEC") ? std::atoi(std::getenv("HIPKKT_MULTI_VEC")) : 4;
+    if (KP % 64 == 0 && vmax >= 4) hipLaunchKernelGGL(k_residual_rm<4>, dim3(g, KP / 64), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
+    else if (KP % 32 == 0) hipLaunchKernelGGL(k_residual_rm<2>, dim3(g, KP / 32), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
     else hipLaunchKernelGGL(k_residual_rm<1>, dim3(g, KP / 16), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
     hipLaunchKernelGGL(k_finish_norm_rm, dim3((KP + 63) / 64), dim3(1024), 0, st, (const double*)partial, (const double*)bpartial, g,
                        KP, norm_out, normb_out);

@@ -2054,7 +2054,9 @@ __global__ __launch_bounds__(256) void k_pull_leaves_m(SolveArgs A, int nrows, i
 void launch_pull_leaves_multi(const SolveArgs& a, int nrows, int KP, hipStream_t st)
 {
     if (nrows <= 0) return;
-    if (KP % 32 == 0) hipLaunchKernelGGL(k_pull_leaves_m<2>, dim3((nrows + 15) / 16, KP / 32), dim3(256), 0, st, a, nrows, KP);
+    static const int vmax = std::getenv("HIPKKT_MULTI_VEC") ? std::atoi(std::getenv("HIPKKT_MULTI_VEC")) : 4;
+    if (KP % 64 == 0 && vmax >= 4) hipLaunchKernelGGL(k_pull_leaves_m<4>, dim3((nrows + 15) / 16, KP / 64), dim3(256), 0, st, a, nrows, KP);
+    else if (KP % 32 == 0) hipLaunchKernelGGL(k_pull_leaves_m<2>, dim3((nrows + 15) / 16, KP / 32), dim3(256), 0, st, a, nrows, KP);
     else hipLaunchKernelGGL(k_pull_leaves_m<1>, dim3((nrows + 15) / 16, KP / 16), dim3(256), 0, st, a, nrows, KP);
 }
 
@@ -2225,7 +2227,7 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
     // gather-list bounds -> sources -> values is paid once per four rows
     constexpr int NW = BS / 64;
     for (int base = 0; base < ncp * CB; base += 4 * BS) {
-        int64_t pg0[4], pg1[4];
+        int pg0[4], pg1[4];                  // (gather-list bounds fit 32 bits: the row structure is int32-indexed)
         double pv[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -2235,8 +2237,8 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
             pv[p] = 0.0;
             if (i < nc) {
                 const int64_t lc = (int64_t)c0 + rp + i;
-                pg0[p] = T.glm_ptr[lc];
-                pg1[p] = T.glm_ptr[lc + 1];
+                pg0[p] = (int)T.glm_ptr[lc];
+                pg1[p] = (int)T.glm_ptr[lc + 1];
                 pv[p] = A.b ? A.b[(int64_t)T.perm[c0 + i] * KP + (xp - A.xp) + (idx & (CB - 1))] : xp[(int64_t)(c0 + i) * KP + (idx & (CB - 1))];
             }
         }
@@ -2252,7 +2254,7 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
-                    u[p][d] = (pg0[p] + e + d < pg1[p]) ? uvec[(pg0[p] + e + d) * KP + (tid & (CB - 1))] : 0.0;
+                    u[p][d] = (pg0[p] + e + d < pg1[p]) ? uvec[(int64_t)(pg0[p] + e + d) * KP + (tid & (CB - 1))] : 0.0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) pv[p] = (pv[p] + u[p][0]) + u[p][1];
         }
@@ -2267,7 +2269,7 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
     for (int t = wv; t < ntile; t += NW) {
         const int r0 = t * 16;
         // gather lists of this lane's four output rows (r0 + mk + 4q), fetched ahead of the product
-        int64_t g0[4], g1[4];
+        int g0[4], g1[4];
         int ud[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -2276,8 +2278,8 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
             ud[q] = 0;
             if (i >= nc && i < f) {
                 const int64_t lc = (int64_t)c0 + rp + i;
-                g0[q] = T.glm_ptr[lc];
-                g1[q] = T.glm_ptr[lc + 1];
+                g0[q] = (int)T.glm_ptr[lc];
+                g1[q] = (int)T.glm_ptr[lc + 1];
                 ud[q] = T.udst_m[rp + i - nc];
             }
         }
@@ -2322,7 +2324,7 @@ __global__ __launch_bounds__(BS) void k_fwd_block_m(SolveArgs A, int begin, int 
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        u[ct][q][d] = (g0[q] + e + d < g1[q]) ? uvec[(g0[q] + e + d) * KP + 16 * ct + ml] : 0.0;
+                        u[ct][q][d] = (g0[q] + e + d < g1[q]) ? uvec[(int64_t)(g0[q] + e + d) * KP + 16 * ct + ml] : 0.0;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -2503,7 +2505,9 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
         else hipLaunchKernelGGL(k_bwd_wave_m<1>, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
         // the launch's pulled leaves (tree level 0 only: they have no children)
         if (leaves) {
-            if (KP % 32 == 0) hipLaunchKernelGGL(k_bwd_leaf_m<2>, dim3((count + 15) / 16, KP / 32), dim3(256), 0, st, a, begin, count, KP);
+            static const int vmax = std::getenv("HIPKKT_MULTI_VEC") ? std::atoi(std::getenv("HIPKKT_MULTI_VEC")) : 4;
+            if (KP % 64 == 0 && vmax >= 4) hipLaunchKernelGGL(k_bwd_leaf_m<4>, dim3((count + 15) / 16, KP / 64), dim3(256), 0, st, a, begin, count, KP);
+            else if (KP % 32 == 0) hipLaunchKernelGGL(k_bwd_leaf_m<2>, dim3((count + 15) / 16, KP / 32), dim3(256), 0, st, a, begin, count, KP);
             else hipLaunchKernelGGL(k_bwd_leaf_m<1>, dim3((count + 15) / 16, KP / 16), dim3(256), 0, st, a, begin, count, KP);
         }
         return;
