@@ -367,10 +367,21 @@ def main():
                     help="e.g. 1,2,3,4,4b,5: time every listed BASELINE configuration on one GPU (one JSON line each) "
                          "instead of the headline run")
     ap.add_argument("--cfg-cpu-units", type=int, default=2, help="--configs: timed oracle units per configuration")
-    ap.add_argument("--concurrent", action="store_true", help="--configs 4: one stream and host thread per problem")
+    ap.add_argument("--sequential-handles", action="store_true",
+                    help="--mode problems: drive the handles one after the other (rounds 1-3's figure) instead of concurrently")
+    ap.add_argument("--concurrent", action="store_true",
+                    help="--configs 4: one stream and host thread per handle (their latency-bound steps side by side); --mode problems does "
+                         "so by default")
     args = ap.parse_args()
     if args.configs:
         return run_configs(args)
+    if args.mode == "problems" and not args.sequential_handles:
+        args.concurrent = True
+    if args.concurrent and args.mode == "problems":
+        # Handles that share the device must not wait for their own kernels inside kernels: the factorisation's overlap mode
+        # assumes that everything else on the GPU ends by itself, which another handle's waiting panel workgroups do not
+        # (seen: every handle gave up once, 50 ms each, and fell back).  Level by level from the start.
+        os.environ.setdefault("HIPKKT_FACTOR_OVERLAP", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_workers(args.gpus, sys.argv[1:]))
 
@@ -471,13 +482,13 @@ def main():
             if rc != 0:
                 raise RuntimeError("deferred status %d: a factorisation / solve of this step failed or stopped refining early" % rc)
 
-    def make_system(pb, rng, lazy=True):
+    def make_system(pb, rng, lazy=True, stream=None):
         """The reduced-system layer on the device (level C: DefaultKKTSystem, kktsystem.jl:21-215) with a synthetic
         iterate and right-hand sides resident in HBM."""
         from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
         st = _lib.default_settings(device=local_rank, ordering=_lib.ORDER_ND if args.ordering == "nd" else _lib.ORDER_AMD)
         ks = HipKKTSolver(pb.P, pb.A, pb.cones, settings=st)
-        ks.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ks.set_stream(stream.cuda_stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream)
         system = HipKKTSystem(ks)
         system.init(pb.q, pb.b)
         system.set_lazy(lazy)
@@ -519,10 +530,26 @@ def main():
             rng = np.random.default_rng(0)
             for g in groups:
                 pb = problems.block_diagonal([problems.config4(j=j, n=n) for j in g])
-                ks, system, st = make_system(pb, rng)
+                # --concurrent: every handle on a stream and a host thread of its own -- a handle's step is a chain of
+                # narrow, latency-bound launches that leaves most of the device idle; several chains side by side fill it.
+                # (One handle at a time may use the persistent sweep kernel on a device; the others sweep level by level.)
+                stream = torch.cuda.Stream(device=dev) if args.concurrent else None
+                ks, system, st = make_system(pb, rng, stream=stream)
+                st["keep_stream"] = stream
                 handles.append((ks, st, g, system))
 
+        pool = None
+        if args.concurrent and not dry and len(handles) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=len(handles))
+            torch.cuda.synchronize(dev)
+
         def step():
+            if pool is not None:
+                futs = [pool.submit(unit_c, system, st) for ks, st, _, system in handles]
+                for f in futs:
+                    f.result()
+                return
             for ks, st, _, system in handles:
                 unit_c(system, st)
 
@@ -545,6 +572,7 @@ def main():
                                "calls": "kkt_update! / kkt_solve!(:affine) / kkt_solve!(:combined) as three separate level-C calls, lazy constant-RHS solve",
                                "fallbacks": [sum(h[0].fallbacks[i] for h in handles) for i in (0, 1)],
                                "problems_per_rank": len(mine), "handles_per_rank": len(groups),
+                               "handles_driven": "concurrently, a stream and a host thread each" if pool is not None else "one after the other",
                                "parallelism": "independent problems per GPU, record all-gather over RCCL"})
             print(json.dumps(out), flush=True)
         if world > 1:
