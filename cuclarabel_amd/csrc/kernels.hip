@@ -158,52 +158,70 @@ void launch_regularizer(const double* K, const int* diag, int N, double c0, doub
 //  Residual e = b - K_sym x (kktsolver_directldl.jl:455-466) on the full symmetric CSR image of
 //  the un-regularised K; G lanes cooperate on one row (fixed in-row summation order).
 // =====================================================================================
-template <int G>
+// NC columns per workgroup (1, or 2: the 2-column solves' residual reads the matrix ONCE for both columns -- cfg3's
+// 25 M entries: 180 -> see DESIGN.md us per 2-column residual); column c of b, x, e at c * ld, its partials as before
+template <int G, int NC>
 __global__ __launch_bounds__(256) void k_residual(SpmvDev A, const double* __restrict__ K,
                                                   const double* __restrict__ b, const double* __restrict__ x,
                                                   double* __restrict__ e, double* __restrict__ partial, int64_t ld,
                                                   double* __restrict__ bpartial)
 {
     __shared__ double sh[4];
-    b += blockIdx.y * ld;
-    x += blockIdx.y * ld;
-    e += blockIdx.y * ld;
-    partial += blockIdx.y * (gridDim.x + 1);
+    const int col0 = blockIdx.y * NC;
+    b += col0 * ld;
+    x += col0 * ld;
+    e += col0 * ld;
+    partial += col0 * (gridDim.x + 1);
     const int sub = threadIdx.x % G;
     const int rows_per_block = 256 / G;
-    if (bpartial) bpartial += blockIdx.y * gridDim.x;
-    double vmax = 0.0, bmax = 0.0;           // bmax: ||b||_inf rides along when bpartial is given
-    bool bad = false;
+    if (bpartial) bpartial += col0 * gridDim.x;
+    double vmax[NC], bmax[NC];               // bmax: ||b||_inf rides along when bpartial is given
+    bool bad[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { vmax[c] = 0.0; bmax[c] = 0.0; bad[c] = false; }
     for (int row = blockIdx.x * rows_per_block + threadIdx.x / G; row < A.N; row += gridDim.x * rows_per_block) {
         const int64_t q0 = A.ptr[row], q1 = A.ptr[row + 1];
         if (q1 - q0 > kLongRow) continue;               // handled by k_residual_long_*
-        double acc = 0.0;
-        if (A.val) {
-            for (int64_t q = q0 + sub; q < q1; q += G) acc = fma(A.val[q], x[A.col[q]], acc);
-        } else {
-            for (int64_t q = q0 + sub; q < q1; q += G) acc = fma(K[A.vmap[q]], x[A.col[q]], acc);
+        double acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+        for (int64_t q = q0 + sub; q < q1; q += G) {
+            const double a = A.val ? A.val[q] : K[A.vmap[q]];
+            const int j = A.col[q];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fma(a, x[c * ld + j], acc[c]);
         }
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, G);
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) acc[c] += __shfl_down(acc[c], o, G);
+        }
         if (sub == 0) {
-            const double bv = b[row];
-            const double r = bv - acc;
-            e[row] = r;
-            if (!isfinite(r)) bad = true;
-            vmax = fmax(vmax, fabs(r));
-            bmax = isfinite(bv) ? fmax(bmax, fabs(bv)) : INFINITY;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double bv = b[c * ld + row];
+                const double r = bv - acc[c];
+                e[c * ld + row] = r;
+                if (!isfinite(r)) bad[c] = true;
+                vmax[c] = fmax(vmax[c], fabs(r));
+                bmax[c] = isfinite(bv) ? fmax(bmax[c], fabs(bv)) : INFINITY;
+            }
         }
     }
-    if (bad) vmax = INFINITY;        // marks non-finite; finished as NaN below
-    vmax = block_max_256(vmax, sh);
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = vmax;
-        if (blockIdx.x == 0 && A.nlong == 0) partial[gridDim.x] = 0.0;     // the long rows' slot
-    }
-    if (bpartial) {
-        __syncthreads();
-        bmax = block_max_256(bmax, sh);
-        if (threadIdx.x == 0) bpartial[blockIdx.x] = bmax;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c) __syncthreads();
+        double v = bad[c] ? INFINITY : vmax[c];        // marks non-finite; finished as NaN below
+        v = block_max_256(v, sh);
+        if (threadIdx.x == 0) {
+            partial[c * (gridDim.x + 1) + blockIdx.x] = v;
+            if (blockIdx.x == 0 && A.nlong == 0) partial[c * (gridDim.x + 1) + gridDim.x] = 0.0;     // the long rows' slot
+        }
+        if (bpartial) {
+            __syncthreads();
+            const double w = block_max_256(bmax[c], sh);
+            if (threadIdx.x == 0) bpartial[c * gridDim.x + blockIdx.x] = w;
+        }
     }
 }
 // one workgroup per chunk of a long row: fixed assignment of entries to threads, fixed reduction tree
@@ -281,10 +299,15 @@ void launch_residual(const SpmvDev& A, const double* K, const double* b, const d
     // ||b||_inf in the same pass (no long rows: every row's b is read here anyway); partial then holds nrhs * (g + 1)
     // residual partials followed by nrhs * g partials of b, at most kResidualPartial(nrhs) doubles
     double* bpartial = (normb_out && nrhs <= kMaxNormbCols && A.nlong == 0) ? partial + (size_t)nrhs * (g + 1) : nullptr;
-    if (A.lanes_per_row == 8)
-        hipLaunchKernelGGL(k_residual<8>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
+    if (nrhs % 2 == 0) {
+        if (A.lanes_per_row == 8)
+            hipLaunchKernelGGL((k_residual<8, 2>), dim3(g, nrhs / 2), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
+        else
+            hipLaunchKernelGGL((k_residual<64, 2>), dim3(g, nrhs / 2), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
+    } else if (A.lanes_per_row == 8)
+        hipLaunchKernelGGL((k_residual<8, 1>), dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
     else
-        hipLaunchKernelGGL(k_residual<64>, dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
+        hipLaunchKernelGGL((k_residual<64, 1>), dim3(g, nrhs), dim3(256), 0, st, A, K, b, x, e, partial, ld, bpartial);
     if (A.nlong > 0) {
         hipLaunchKernelGGL(k_residual_long_chunks, dim3(A.nchunks, nrhs), dim3(256), 0, st, A, K, x, ld);
         hipLaunchKernelGGL(k_residual_long_finish, dim3(1, nrhs), dim3(256), 0, st, A, b, e, partial, ld, g);
