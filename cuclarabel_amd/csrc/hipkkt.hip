@@ -1992,6 +1992,7 @@ struct hipkkt_kkt_s {
     // residual SpMV
     DBuf<int64_t> fptr;
     DBuf<int> fcol, fmap;
+    DBuf<int64_t> fpend;         // rows < n: end of the row's P entries in the image (SpmvDev::pend)
     DBuf<double> fval;               // K values in the CSR image's order: gathered whole after P / A changed (fval_dirty), kept
     bool fval_dirty = true;          //   current by write-through from the cone update otherwise (kpos: two slots per K entry)
     DBuf<int> kpos;
@@ -2422,6 +2423,15 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
             h->fptr.upload(ptr);
             h->fcol.upload(col);
             h->fmap.upload(vmap);
+            {
+                // rows of the x block: where their P entries end (columns ascend, so those are a prefix of the row) -- the
+                // reduced-system layer's P x products stop there instead of walking the row's A' entries as well (cfg3:
+                // ~250 of them per row behind a handful of P entries)
+                std::vector<int64_t> pend((size_t)std::max<int64_t>(K.n, 1), 0);
+                for (int64_t i = 0; i < K.n; ++i)
+                    pend[(size_t)i] = std::lower_bound(col.begin() + ptr[(size_t)i], col.begin() + ptr[(size_t)i + 1], (int)K.n) - col.begin();
+                h->fpend.upload(pend);
+            }
             h->fval.alloc(vmap.size());
             {
                 std::vector<int> kp((size_t)2 * K.nnzK, -1);
@@ -2711,6 +2721,7 @@ static SpmvDev kkt_spmv(hipkkt_kkt_t h)
     }
     SpmvDev A;
     A.ptr = h->fptr.p; A.col = h->fcol.p; A.vmap = h->fmap.p; A.val = h->fval.p; A.N = h->K.N;
+    A.pend = h->fpend.p;
     A.lanes_per_row = h->lanes_per_row;
     A.nlong = h->nlong; A.nchunks = h->nchunks; A.long_rows = h->long_rows.p; A.long_chunk_ptr = h->long_chunk_ptr.p;
     A.chunk_q = h->chunk_q.p; A.long_partial = h->long_partial.p;

@@ -1177,7 +1177,8 @@ __global__ __launch_bounds__(256) void k_P_spmv(SpmvDev A, const double* __restr
     const int sub = threadIdx.x & 7;
     for (int row = blockIdx.x * 32 + (threadIdx.x >> 3); row < n; row += gridDim.x * 32) {
         double acc = 0.0;
-        for (int64_t q = A.ptr[row] + sub; q < A.ptr[row + 1]; q += 8) {
+        const int64_t qend = A.pend ? A.pend[row] : A.ptr[row + 1];
+        for (int64_t q = A.ptr[row] + sub; q < qend; q += 8) {
             const int c = A.col[q];
             if (c < n) acc = fma(A.val ? A.val[q] : K[A.vmap[q]], x[c], acc);
         }
@@ -1205,7 +1206,8 @@ __global__ __launch_bounds__(256) void k_P_spmv2(SpmvDev A, const double* __rest
     const int sub = threadIdx.x & 7;
     for (int row = blockIdx.x * 32 + (threadIdx.x >> 3); row < n; row += gridDim.x * 32) {
         double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int64_t q = A.ptr[row] + sub; q < A.ptr[row + 1]; q += 8) {
+        const int64_t qend = A.pend ? A.pend[row] : A.ptr[row + 1];       // (the row's P entries are a prefix: SpmvDev::pend)
+        for (int64_t q = A.ptr[row] + sub; q < qend; q += 8) {
             const int c = A.col[q];
             if (c < n) {
                 const double v = A.val ? A.val[q] : K[A.vmap[q]];

@@ -281,6 +281,7 @@ struct SpmvDev {
     const int* col;
     const int* vmap;             // entry -> index into Kval
     const double* val;           // the values in CSR order (a refreshed copy of Kval[vmap[.]]), or null
+    const int64_t* pend;         // nullable; rows of the x block (row < n): end of the row's entries with column < n (P)
     int N;
     int lanes_per_row;           // 8 or 64
     // rows longer than kLongRow entries (a dense constraint row, say) are cut into chunks of kLongChunk entries,
