@@ -1180,7 +1180,11 @@ private:
                 if (L.lds_sliced > kLdsCap) throw std::runtime_error("panel slice does not fit LDS (panel_cap too large?)");
                 int ncmax = 0;
                 for (int s : v) ncmax = std::max(ncmax, ncols(s));
-                L.lds_solve = L.small ? 0 : solve_lds_bytes(fmax, ncmax);
+                // (per front, then the maximum: the tallest front of a launch is a narrow panel and its widest a short one --
+                //  sized from (fmax, ncmax) jointly, a level with a 7000-row panel beside a 96-column one asked for LDS
+                //  nobody needs and the structure was refused as "too large")
+                L.lds_solve = 0;
+                if (!L.small) for (int s : v) L.lds_solve = std::max(L.lds_solve, solve_lds_bytes(front_size(s), ncols(s)));
                 L.fmax = fmax;
                 L.ncmax = ncmax;
                 static const int small_bs_count = std::getenv("HIPKKT_BS128_COUNT") ? std::atoi(std::getenv("HIPKKT_BS128_COUNT")) : 1024;
