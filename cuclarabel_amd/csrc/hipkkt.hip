@@ -72,6 +72,8 @@ struct Launch {
     int nsliced;                // the last nsliced fronts of a block-class launch are factorised in row slices ...
     int slice_begin, slice_count;   // ... their slice records in d_sdesc
     size_t lds_sliced;
+    int ntall;                  // the last ntall fronts of a block-class launch are too tall for the block sweep kernels' LDS
+                                //   (beyond ~10 000 rows): k_fwd_tall / k_bwd_tall; such a launch stays out of the persistent kernels
     int level;                  // tree level: a level has at most one block-class launch, followed by its one-wave launch
 };
 
@@ -130,6 +132,11 @@ public:
                          S.N, S.nsuper, S.levels.size(), launches.size(), nblock, nsl_fronts, slice_list.size(), top_launches,
                          top_count, top_ntask > 0 ? top_sgrid : top_grid, top_ntask, overlap_wanted() ? launches.size() - ov_first : (size_t)0,
                          ov_slices);
+            {
+                int ntall_all = 0;
+                for (const Launch& L : launches) ntall_all += L.ntall;
+                if (ntall_all) std::fprintf(stderr, "[hipkkt] %d fronts too tall for the block sweep kernels (k_fwd_tall / k_bwd_tall)\n", ntall_all);
+            }
             if (std::atoi(std::getenv("HIPKKT_VERBOSE")) >= 2)
                 for (size_t q = 0; q < launches.size(); ++q) {
                     const Launch& L = launches[q];
@@ -222,7 +229,9 @@ public:
         if (top_ntask > 0 && (nr != 2 || top_sgrid2 <= 0)) return false;
         const size_t below = top_ntask > 0 ? launches.size() - top_launches : launches.size();
         for (size_t q = 0; q < below; ++q)
-            if (!launches[q].small && launches[q].lds_solve * (size_t)nr > kLdsCap) return false;
+            if (!launches[q].small && (launches[q].ntall > 0 || launches[q].lds_solve * (size_t)nr > kLdsCap)) return false;
+        // (fronts too tall for the block kernels take one column in the per-level path; inside the (front, slice) set they
+        //  are slices like any other)
         return true;
     }
 
@@ -704,7 +713,7 @@ private:
         // a level's block-class launch and the one-wave launch behind it (sched order) go out as one launch
         static const bool no_merge = std::getenv("HIPKKT_NO_LEVEL_MERGE") != nullptr;
         auto pair_at = [&](size_t q) {      // launches q (block-class) and q + 1 (one-wave) belong to one level
-            return !no_merge && q + 1 + ntl < nl && !launches[q].small && launches[q + 1].small &&
+            return !no_merge && q + 1 + ntl < nl && !launches[q].small && launches[q].ntall == 0 && launches[q + 1].small &&
                    launches[q].level == launches[q + 1].level;
         };
         for (size_t q = 0; q + ntl < nl; ++q) {
@@ -718,7 +727,8 @@ private:
             } else if (L.small) {
                 launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, L.level == 0, nr);
             } else {
-                launch_fwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st, nr);
+                launch_fwd(a, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
+                launch_fwd_tall(a, L.begin + L.count - L.ntall, L.ntall, st);        // (fronts beyond the block kernels' LDS)
             }
         }
         wait_w(st);
@@ -816,7 +826,8 @@ private:
             } else if (L.small) {
                 launch_bwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, nr);
             } else {
-                launch_bwd(a, L.begin, L.count, L.solve_bs, L.lds_solve, st, nr);
+                launch_bwd(a, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
+                launch_bwd_tall(a, L.begin + L.count - L.ntall, L.ntall, st);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -1051,6 +1062,15 @@ private:
         return (S.sn_start[s + 1] - S.sn_start[s]) + (int)(S.rowptr[s + 1] - S.rowptr[s]);
     }
 
+    // too tall for the LDS of the block sweep kernels / of k_top_solve (solve_kernels.hip, k_fwd_tall)
+    // (HIPKKT_SOLVE_TALL_ROWS=n: fronts of n rows or more count as tall as well -- the tests' way to those paths)
+    bool front_is_tall(int s) const
+    {
+        static const int tall_rows = std::getenv("HIPKKT_SOLVE_TALL_ROWS") ? std::atoi(std::getenv("HIPKKT_SOLVE_TALL_ROWS")) : 0;
+        const int f = front_size(s), nc = S.sn_start[s + 1] - S.sn_start[s];
+        return solve_lds_bytes(f, nc) > kLdsCap || (tall_rows > 0 && f >= tall_rows);
+    }
+
     void build_schedule()
     {
         sched.clear();
@@ -1100,7 +1120,9 @@ private:
                 // diagonal block's factorisation per slice.  128 rows (0 = as few slices as LDS allows): cfg5's
                 // factorisation 5.30 -> 5.06 ms, cfg3's 1.21 -> 1.23 (slices have K and item lists of their own, so the
                 // per-slice overhead no longer grows with their number).
-                if (r > 1 && level_slice_rows > 0) r = std::max(r, std::min(panel_max_slices, (nb + level_slice_rows - 1) / level_slice_rows));
+                // (the preference stops at 16 slices: beyond that only what LDS needs -- a 6289-row front in 49 slices of 128
+                //  rows measured 44.9 ms per factorisation against 40.3 in 16)
+                if (r > 1 && level_slice_rows > 0) r = std::max(r, std::min(std::min(panel_max_slices, 16), (nb + level_slice_rows - 1) / level_slice_rows));
                 return r;
             };
             // One round of panel workgroups where possible: every slice needs a CU to itself, so a level with more slices
@@ -1130,6 +1152,8 @@ private:
             std::sort(big.begin(), big.end(), by_work);
             // fronts factorised in row slices go to the end of the block-class launch (own panel kernel launch)
             std::stable_partition(big.begin(), big.end(), [&](int s) { return slices_of(s) == 1; });
+            auto is_tall = [&](int s) { return front_is_tall(s); };
+            std::stable_partition(big.begin(), big.end(), [&](int s) { return !is_tall(s); });
             // the tiny fronts (f <= 8) go to the end of the one-wave launch: the solves give them their own kernel
             std::stable_partition(small.begin(), small.end(), [&](int s) { return front_size(s) > 8; });
             const int ntiny_level = (int)std::count_if(small.begin(), small.end(), [&](int s) { return front_size(s) <= 8; });
@@ -1184,7 +1208,11 @@ private:
                 //  sized from (fmax, ncmax) jointly, a level with a 7000-row panel beside a 96-column one asked for LDS
                 //  nobody needs and the structure was refused as "too large")
                 L.lds_solve = 0;
-                if (!L.small) for (int s : v) L.lds_solve = std::max(L.lds_solve, solve_lds_bytes(front_size(s), ncols(s)));
+                L.ntall = 0;
+                if (!L.small) for (int s : v) {
+                    if (is_tall(s)) { ++L.ntall; continue; }
+                    L.lds_solve = std::max(L.lds_solve, solve_lds_bytes(front_size(s), ncols(s)));
+                }
                 L.fmax = fmax;
                 L.ncmax = ncmax;
                 static const int small_bs_count = std::getenv("HIPKKT_BS128_COUNT") ? std::atoi(std::getenv("HIPKKT_BS128_COUNT")) : 1024;
@@ -1481,7 +1509,7 @@ private:
                 std::vector<int> tp, ts;
                 h_tbase.assign((size_t)top_count + 1, 0);
                 const int b0 = top_launches ? launches[launches.size() - top_launches].begin : 0;
-                bool any_sliced = false;
+                bool any_sliced = false, set_has_tall = false, tall_unsliceable = false;
                 size_t slds = 0;
                 for (int p = 0; p < top_count; ++p) {
                     const int sn = sched[(size_t)b0 + p];
@@ -1490,7 +1518,11 @@ private:
                     int R = 1;
                     if (slice_kb > 0 && wbytes > slice_from)
                         R = (int)std::min<int64_t>(slice_max, (wbytes + (int64_t)slice_kb * 1024 - 1) / ((int64_t)slice_kb * 1024));
+                    const bool tallf = front_is_tall(sn);                        // (too tall for k_top_solve's LDS: slices only)
+                    if (tallf) R = std::max(R, 2);
+                    set_has_tall = set_has_tall || tallf;
                     R = std::max(1, std::min(R, std::max(1, nb)));
+                    if (tallf && R < 2) tall_unsliceable = true;
                     any_sliced = any_sliced || R > 1;
                     h_tbase[(size_t)p] = (int)tp.size();
                     for (int q = 0; q < R; ++q) { tp.push_back(p); ts.push_back(q | (R << 8)); }
@@ -1511,6 +1543,12 @@ private:
                     d_tk_pos.upload(tp); d_tk_sl.upload(ts); d_tbase.upload(h_tbase);
                     xf.alloc((size_t)S.N * 2);
                     if (top_sgrid <= 0) top_ntask = 0;
+                }
+                if (set_has_tall && (top_ntask == 0 || tall_unsliceable)) {
+                    // fronts too tall for the one-front-per-workgroup kernel, and the (front, slice) kernel cannot take the set
+                    // either (a slice's vectors beyond a CU's LDS: fronts of ~18 000 rows and more): no persistent set at all,
+                    // the sweeps go level by level (k_fwd_tall / k_bwd_tall for those fronts)
+                    top_launches = 0; top_count = 0; top_grid = 0; top_ntask = 0; top_nflag = 1;
                 }
             }
             top_flags.alloc((size_t)2 * std::max(top_nflag, 1) + 4);

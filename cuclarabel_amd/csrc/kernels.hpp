@@ -261,6 +261,8 @@ void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const i
 void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st, const double* add = nullptr);
 void launch_permute_out(double* X, int64_t ldx, const double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
 void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
+void launch_fwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st);      // fronts too tall for the block kernels' LDS
+void launch_bwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st);
 void launch_pull_leaves_multi(const SolveArgs& a, int nrows, int KP, hipStream_t st);
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st, bool leaves = false);
 

@@ -961,6 +961,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
 // forward solution slice 0 left there) so that siblings may overwrite xp meanwhile.  The slices of a front never
 // exchange anything; a parent waits for all slices of a child, a child for all slices of its parent.  As in
 // k_top_solve everything static (matrix entries, gather indices, b, D^{-1}, row indices) is parked before the wait.
+constexpr int kBdColsSolveMax = 160;     // columns of a front the tall kernels keep in LDS (panels have at most 144)
 constexpr int kSlPF = 2;         // forward items per wave parked (the kernel must fit 128 VGPRs)
 constexpr int kSlGP = 4;         // gather indices per row parked
 // (front, slice) tasks: wave 0 waits for every task of the children of s inside the set.  Lanes over children for each
@@ -1822,6 +1823,83 @@ static void init_solve_lds()
 }
 
 // per right-hand side; the kernels lay NR columns' shares out one after the other
+// ------------------------------------------------------------------ very tall fronts (f beyond ~10 000 rows)
+// The block kernels keep a front's vector and partial sums in LDS, f (1 + nc / 8) doubles: a front of 14 000 rows does
+// not fit whatever its width (long-range KKT graphs: cfg2 with 1 % of A's entries re-drawn over all columns has a
+// 14 154-row root).  These fronts take kernels of their own, one workgroup each, nothing of size f in LDS: the top nc
+// entries are gathered and solved against T = L11^{-1} in LDS, the rows below stream their row of M = L21 T from W
+// (coalesced over the rows) and are stored straight to the contribution vector; backward, a wave owns columns and
+// walks the rows with its lanes (the ancestors' x gathered on the way), one wave reduction per column.  Single column
+// only; a launch's tall fronts sit at its end (hipkkt.hip, Launch::ntall) and stay out of the persistent kernels.
+__global__ __launch_bounds__(1024) void k_fwd_tall(SolveArgs A, int begin)
+{
+    __shared__ double ytop[kBdColsSolveMax];
+    const int tid = threadIdx.x;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ W = A.tinv + fd.w_off;
+    for (int i = tid; i < nc; i += 1024) {
+        double v = A.b[T.perm[c0 + i]];
+        const int64_t lc = (int64_t)c0 + rp + i;
+        for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += A.uvec[T.gl_src[g]];
+        ytop[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < nc; i += 1024) {
+        double acc = 0.0;
+        for (int k = 0; k <= i; ++k) acc = fma(W[i + (int64_t)k * f], ytop[k], acc);       // T is unit lower triangular
+        A.xp[c0 + i] = acc;
+    }
+    for (int r = nc + tid; r < f; r += 1024) {
+        const int64_t lc = (int64_t)c0 + rp + r;
+        double v = 0.0;
+        for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += A.uvec[T.gl_src[g]];
+        double acc = 0.0;
+        for (int k = 0; k < nc; ++k) acc = fma(W[r + (int64_t)k * f], ytop[k], acc);
+        A.uvec[rp + r - nc] = v - acc;
+    }
+}
+__global__ __launch_bounds__(1024) void k_bwd_tall(SolveArgs A, int begin)
+{
+    __shared__ double ztop[kBdColsSolveMax], xnew[kBdColsSolveMax];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const double* __restrict__ W = A.tinv + fd.w_off;
+    for (int j = tid; j < nc; j += 1024) ztop[j] = A.xp[c0 + j] * A.Dinv[c0 + j];
+    __syncthreads();
+    for (int j = wv; j < nc; j += 16) {
+        double acc = 0.0;
+        const double* __restrict__ Wj = W + (int64_t)j * f;
+        for (int r = j + lane; r < f; r += 64) {
+            const double zr = (r < nc) ? ztop[r] : -A.xp[T.rows[rp + r - nc]];
+            acc = fma(Wj[r], zr, acc);
+        }
+        acc = wave_reduce_sum(acc);
+        if (lane == 0) xnew[j] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < nc; j += 1024) {
+        const double v = xnew[j];
+        A.xp[c0 + j] = v;
+        A.out[T.perm[c0 + j]] = v;
+    }
+}
+void launch_fwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st)
+{
+    if (count > 0) hipLaunchKernelGGL(k_fwd_tall, dim3(count), dim3(1024), 0, st, a, begin);
+}
+void launch_bwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st)
+{
+    if (count > 0) hipLaunchKernelGGL(k_bwd_tall, dim3(count), dim3(1024), 0, st, a, begin);
+}
+
 size_t solve_lds_bytes(int fmax, int ncmax)
 {
     const size_t fpad = (size_t)((fmax + 3) & ~3), ncpad = (size_t)((ncmax + 3) & ~3);

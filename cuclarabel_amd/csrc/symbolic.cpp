@@ -329,8 +329,15 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
                     const int64_t fp = (fa + 3) & ~(int64_t)3, wp = (w + 3) & ~(int64_t)3;
                     return fp * (1 + (w + 7) / 8) <= opt.solve_cap && fp + ((fa + 7) / 8) * wp <= opt.solve_cap;
                 };
+                // (a front too tall for the block sweep kernels at ANY width -- beyond ~10 000 rows -- goes to the tall-front
+                //  kernels, solve_kernels.hip: its width is the panel kernel's business alone)
+                // (r03: the same for a front that does not fit them at the widest panel the factorisation would take -- beyond
+                //  ~1540 rows at 96 columns.  Narrowing its panels to fit cost a level per 17 columns at 6000 rows, and every
+                //  level of a chain passes the whole trailing block through HBM; such fronts go through the sliced
+                //  persistent kernel anyway, the tall kernels are their per-level fallback.)
+                const bool tall = !solve_fits(std::min<int64_t>(wd, c1 - a));
                 while (wd > 1 && (panel_slices_needed(wd, fa - wd, opt.panel_cap, std::max(1, opt.panel_max_slices)) == 0 ||
-                                  !solve_fits(wd))) --wd;
+                                  (!tall && !solve_fits(wd)))) --wd;
                 // slices cost a second launch per level and redundant diagonal work: only where they save a level,
                 // i.e. where the unsliced width would need more chunks for the remaining columns
                 int64_t w1 = wd;

@@ -51,7 +51,7 @@ struct SymbolicOptions {
     // A panel too tall for one CU is cut into ROW slices, one workgroup (CU) each: every slice holds the top nc x nc
     // block and factors it redundantly, so the slices never talk to each other (factor_kernels.hip, k_panel SLICED).
     // That keeps tall fronts wide -- a 1531-row front takes 96 columns per level instead of 12.
-    int panel_max_slices = 16;
+    int panel_max_slices = 128;      // (r03: 16 until then -- a 14 000-row front then had to take 21-column panels, 670 levels of them)
     int panel_slice_below = 64;  // ... and only for fronts whose unsliced panel would be narrower than this (cfg2's
                                  // 289-row fronts take 70+ columns unsliced: slicing them costs more than it saves)
     // the solve kernels keep a front's vector and its partial sums in LDS: (1 + ceil(nc/8)) * f doubles forward,
