@@ -911,6 +911,36 @@ def test_two_columns_through_the_sliced_persistent_kernel(maker, kb, no_top):
     assert sched["top_tasks"] > sched["top_fronts"] > 0, sched       # (front, slice) tasks: k_top_solve_sliced was selected
 
 
+def test_long_range_couplings_at_mid_size():
+    """cfg2's long-range variant (1 % of A's entries re-drawn over all columns) at n = 20 000: a small-world KKT
+    graph.  Nested dissection along breadth-first levels would be catastrophic there (nnz(L) 2.8e8; the ordering hands the
+    graph to AMD: 9e6), the root front has 2884 rows -- 96-column panels in row slices, (front, slice) tasks in the sweeps,
+    the tall kernels as their per-level fallback.  Solution and refinement rounds against the oracle; a 2-column call."""
+    _, HipKKTSolver, _ = _hip()
+    pb = problems.config2(n=20000, long_range_frac=0.01)
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    info = ks.info
+    assert info["max_front"] > 2000 and info["nnzL"] < 2e7, info
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    o = _oracle_for(pb, ks)
+    assert o.update_scaling(pb.s0, pb.z0) and o.kktsolver_update()
+    rng = np.random.default_rng(21)
+    RX, RZ = rng.standard_normal((pb.n, 2)), rng.standard_normal((pb.m, 2))
+    ok, LX, LZ, ir = ks.kktsolver_solve_multi(RX, RZ)
+    assert ok
+    for j in range(2):
+        ks.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        o.kktsolver_setrhs(RX[:, j], RZ[:, j])
+        oko, xo, zo = o.kktsolver_solve()
+        so = max(np.abs(xo).max(), np.abs(zo).max())
+        assert oko and ks.last_ir_iterations == o.last_ir_iters
+        assert max(np.abs(x - xo).max(), np.abs(z - zo).max()) / so < 1e-9
+        assert max(np.abs(LX[:, j] - xo).max(), np.abs(LZ[:, j] - zo).max()) / so < 1e-9
+    assert ks.fallbacks == (0, 0)
+
+
 @pytest.mark.parametrize("maker,rows", [("problems.config2(n=6000)", 96), ("problems.config3(nblocks=4, blk=150)", 100),
                                         ("problems.config5(n=120, npsd=6, psd_dim=8, nsoc=4, soc_dim=12)", 40)])
 @pytest.mark.parametrize("no_top", [False, True])
