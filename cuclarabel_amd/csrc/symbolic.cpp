@@ -478,17 +478,54 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
     // on what are ~30 scattered first touches (address translation, not bytes).  Offsets stay per supernode;
     // entry [nsuper] holds the total.  (HIPKKT_POSTORDER_LAYOUT=1 keeps the postorder layout, for comparison.)
     if (!std::getenv("HIPKKT_POSTORDER_LAYOUT")) {
+        // CHAINS share two update blocks.  In a chain of panels (a supernode cut into panels, 7b: the child's update block
+        // IS its parent's whole front) the block of link i is read by link i + 1 alone -- by its panel and by its tiles --
+        // and is dead once link i + 1's tiles are done, which is before link i + 2's tiles start (a stream's kernels run in
+        // order; in overlap mode the tiles of a launch start when the previous launch's have finished).  Links alternate
+        // between two buffers of the sizes of the first two (the blocks shrink along the chain): a 14 000-row root cut into
+        // 148 panels keeps 2 x 1.6 GB instead of 148 blocks, 150 GB.  (HIPKKT_UPD_PINGPONG=0: every block its own.)
+        static const bool pingpong = !(std::getenv("HIPKKT_UPD_PINGPONG") && std::atoi(std::getenv("HIPKKT_UPD_PINGPONG")) == 0);
+        std::vector<int> pred((size_t)S.nsuper, -1), next((size_t)S.nsuper, -1);
+        auto nbof = [&](int s) { return (int64_t)(S.rowptr[s + 1] - S.rowptr[s]); };
+        auto fof = [&](int s) { return (int64_t)(S.sn_start[s + 1] - S.sn_start[s]) + nbof(s); };
+        for (int c = 0; pingpong && c < S.nsuper; ++c) {
+            const int p = S.sn_parent[c];
+            if (p >= 0 && pred[(size_t)p] < 0 && nbof(c) == fof(p) && nbof(c) > 0) { pred[(size_t)p] = c; next[(size_t)c] = p; }
+        }
+        std::vector<int64_t> chain_a((size_t)S.nsuper, -1), chain_b((size_t)S.nsuper, -1);     // per chain head: its two buffers
+        std::vector<int> head((size_t)S.nsuper, -1), link((size_t)S.nsuper, 0);
+        for (int h = 0; h < S.nsuper; ++h) {
+            if (pred[(size_t)h] >= 0 || next[(size_t)h] < 0) continue;
+            int len = 0;
+            for (int m = h; m >= 0; m = next[(size_t)m]) ++len;
+            if (len < 3) continue;
+            int i = 0;
+            for (int m = h; m >= 0; m = next[(size_t)m], ++i) { head[(size_t)m] = h; link[(size_t)m] = i; }
+        }
         int64_t fo = 0, uo = 0;
         for (int t = 0; t < S.nsuper; ++t) {
             const int s = S.level_sn[t];
             const int64_t nc = S.sn_start[s + 1] - S.sn_start[s], nb = S.rowptr[s + 1] - S.rowptr[s], f = nc + nb;
             S.front_off[s] = fo;
-            S.upd_off[s] = uo;
             fo += f * nc;
-            uo += nb * nb;
+            const int h = head[(size_t)s];
+            if (h < 0) {
+                S.upd_off[s] = uo;
+                uo += nb * nb;
+            } else {
+                if (chain_a[(size_t)h] < 0) {              // (the head comes first in level order: it is the lowest link)
+                    const int second = next[(size_t)h];
+                    chain_a[(size_t)h] = uo;
+                    uo += nbof(h) * nbof(h);
+                    chain_b[(size_t)h] = uo;
+                    uo += nbof(second) * nbof(second);
+                }
+                S.upd_off[s] = (link[(size_t)s] & 1) ? chain_b[(size_t)h] : chain_a[(size_t)h];
+            }
         }
         S.front_off[S.nsuper] = fo;
         S.upd_off[S.nsuper] = uo;
+        S.update_store = uo;
     }
 }
 
