@@ -147,6 +147,10 @@ def run_configs(args):
     dev = torch.device("cuda", 0)
     makers = {"1": lambda: [problems.config1()], "2": lambda: [problems.config2()], "3": lambda: [problems.config3()],
               "4": lambda: [problems.config4(j=j) for j in range(8)], "5": lambda: [problems.config5()],
+              # cfg2's long-range variant (1 % of A's entries re-drawn over all columns): a small-world KKT graph,
+              # nnz(L) 1.4e8, a 14 154-row root, 1.2 TFLOP per factorisation -- no CPU leg (the scalar oracle needs ~half an
+              # hour per unit); its check is the refinement loop's own residual test on the un-regularised K
+              "2lr": lambda: [problems.config2(long_range_frac=0.01)],
               # the per-GPU share of cfg4 as ONE block-diagonal problem: all 8 in the same per-level launches
               "4b": lambda: [problems.block_diagonal([problems.config4(j=j) for j in range(8)])]}
     import tempfile
@@ -252,7 +256,7 @@ def run_configs(args):
                    update_ms=prof["update_ms"] / max(prof["n_update"], 1),
                    ir_rounds_per_unit=prof["ir_iterations"] / args.steps,
                    factor_TFLOPs=info["factor_flops"] / (prof["factor_ms"] / max(prof["n_factor"], 1) * 1e-3) / 1e12)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and c != "2lr":
             native_oracle()
             from tests.oracle_bindings import make_oracle           # the cpu_baseline leg: checker and baseline only
             pb, ks, st = pbs[0], sol[0], state[0]
@@ -367,7 +371,7 @@ def main():
                     help="no GPU: the ranks rendezvous over gloo and exercise the launch / barrier / gather plumbing "
                          "with an empty step (CPU test of the --gpus N path); the JSON line carries dry_run: true")
     ap.add_argument("--configs", default=None,
-                    help="e.g. 1,2,3,4,4b,5: time every listed BASELINE configuration on one GPU (one JSON line each) "
+                    help="e.g. 1,2,3,4,4b,5 (and 2lr, cfg2 with long-range couplings): time every listed configuration on one GPU (one JSON line each) "
                          "instead of the headline run")
     ap.add_argument("--cfg-cpu-units", type=int, default=2, help="--configs: timed oracle units per configuration")
     ap.add_argument("--sequential-handles", action="store_true",
