@@ -49,11 +49,14 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 #define OV_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 // (who / info: which wait expired first -- 1 a panel for a child's tiles, 2 a tile for its panel's blocks, 3 the gate -- and
 //  the supernode or launch it waited for: abort_word[1..4], printed with the fall-back message)
-__device__ inline bool ov_wait_ge(const int* counter, int target, int* abort_word, long long t0, long long limit, int who = 0, int info = 0)
+// (seen_min, nullable: lowered to the counter's value as found -- a caller that polls for a sequence of rising targets
+//  skips the polls a value already seen covers)
+__device__ inline bool ov_wait_ge(const int* counter, int target, int* abort_word, long long t0, long long limit, int who = 0, int info = 0,
+                                  int* seen_min = nullptr)
 {
     for (;;) {
         const int seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen >= target) return true;
+        if (seen >= target) { if (seen_min && seen < *seen_min) *seen_min = seen; return true; }
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         if (wall_clock64() - t0 > limit) {            // (50 ms at 100 MHz: far beyond any real factorisation step)
             if (atomicCAS(abort_word, 0, 1) == 0) { abort_word[1] = who; abort_word[2] = info; abort_word[3] = seen; abort_word[4] = target; }
@@ -884,55 +887,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OV ? 3 : 4)
         pass_through();
     }
     const long long tw = OV ? wall_clock64() : 0;
-
-    for (int k0 = 0; k0 < nc; k0 += KC) {
-        const int kw = min(KC, nc - k0);
-        if (OV) {
-            // the panel kernel of this front publishes its 16-column blocks as they are finished
-            if (tid == 0) {
-                bool ok = true;
-                const int sb = A.ov_sbase[s];
-                if (sb < 0) {
-                    ok = ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw, A.ov_limit, 2, s);
-                } else {
-                    // a front factorised in row slices: the slices that hold this tile's two strips, and the first one
-                    // (it publishes the top block, whose diagonal the product scales with)
-                    const FrontDesc sd = T.sdesc[sb];
-                    const int nsl = sd.pad & 0xffff, rsmax = (nb + nsl - 1) / nsl;
-                    ok = ov_wait_ge(A.ov_sprog + sb, k0 + kw, A.flags + 2, tw, A.ov_limit);
-                    for (int q = r0 / rsmax; ok && q <= (r0 + nr - 1) / rsmax; ++q)
-                        ok = ov_wait_ge(A.ov_sprog + sb + q, k0 + kw, A.flags + 2, tw, A.ov_limit);
-                    for (int q = q0 / rsmax; ok && q <= (q0 + nq - 1) / rsmax; ++q)
-                        ok = ov_wait_ge(A.ov_sprog + sb + q, k0 + kw, A.flags + 2, tw, A.ov_limit);
-                }
-                if (!ok) *sh_ok = 0;
-            }
-            __syncthreads();
-            if (!*sh_ok) return;
+    int known = 0;                 // (thread 0) columns of the panel known to be published by every workgroup this tile reads from
+    // Overlap mode: the panel kernel of this front publishes its 16-column blocks as they are finished; thread 0 makes sure
+    // that columns [k0, k0 + kw) are there (the workgroup learns the outcome behind its next barrier).  What a poll saw is
+    // remembered: on a tall front most tiles start long after their panel has finished (a 14 000-row level has 24 000
+    // tiles), and every chunk used to pay three to five dependent polls again -- 20-30 us of a 35 us tile.
+    auto ensure = [&](int k0, int kw) {
+        if (tid != 0 || k0 + kw <= known) return;
+        bool ok = true;
+        int seen = 1 << 30;
+        const int sb = A.ov_sbase[s];
+        if (sb < 0) {
+            ok = ov_wait_ge(A.ov_prog + s, k0 + kw, A.flags + 2, tw, A.ov_limit, 2, s, &seen);
+        } else {
+            // a front factorised in row slices: the slices that hold this tile's two strips, and the first one
+            // (it publishes the top block, whose diagonal the product scales with)
+            const FrontDesc sd = T.sdesc[sb];
+            const int nsl = sd.pad & 0xffff, rsmax = (nb + nsl - 1) / nsl;
+            ok = ov_wait_ge(A.ov_sprog + sb, k0 + kw, A.flags + 2, tw, A.ov_limit, 0, 0, &seen);
+            for (int q = r0 / rsmax; ok && q <= (r0 + nr - 1) / rsmax; ++q)
+                ok = ov_wait_ge(A.ov_sprog + sb + q, k0 + kw, A.flags + 2, tw, A.ov_limit, 0, 0, &seen);
+            for (int q = q0 / rsmax; ok && q <= (q0 + nq - 1) / rsmax; ++q)
+                ok = ov_wait_ge(A.ov_sprog + sb + q, k0 + kw, A.flags + 2, tw, A.ov_limit, 0, 0, &seen);
         }
-        {
-            const int k = tid >> 4, rr = (tid & 15) * 4;
-            double av[4], bv[4];
-            // (overlap mode: the panel entries were written through by a kernel that is still running)
-            auto ldF = [&](int64_t o) { return OV ? OV_LD(F + o) : F[o]; };
-            const double dk = (k < kw) ? ldF((k0 + k) + (int64_t)(k0 + k) * f) : 0.0;
+        if (!ok) *sh_ok = 0;
+        else known = seen;
+    };
+    // this thread's share of a chunk's operands: row k of the chunk, four entries of each strip, the pivot d_k
+    const int ck = tid >> 4, crr = (tid & 15) * 4;
+    double av[4], bv[4], dk = 0.0;
+    // (overlap mode: the panel entries were written through by a kernel that is still running)
+    auto ldF = [&](int64_t o) { return OV ? OV_LD(F + o) : F[o]; };
+    auto fetch = [&](int k0, int kw) {
+        dk = (ck < kw) ? ldF((k0 + ck) + (int64_t)(k0 + ck) * f) : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                av[q] = (k < kw && rr + q < nr) ? ldF((nc + r0 + rr + q) + (int64_t)(k0 + k) * f) : 0.0;
-                bv[q] = (ti != tj && k < kw && rr + q < nq) ? ldF((nc + q0 + rr + q) + (int64_t)(k0 + k) * f) : 0.0;
-            }
-            if (ti == tj) {                                  // diagonal tile: both strips are the same rows
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[q] = av[q];
-            }
-            __syncthreads();           // previous chunk fully consumed
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                As[k][rr + q] = av[q];
-                Bs[k][rr + q] = bv[q] * dk;
-            }
+        for (int q = 0; q < 4; ++q) {
+            av[q] = (ck < kw && crr + q < nr) ? ldF((nc + r0 + crr + q) + (int64_t)(k0 + ck) * f) : 0.0;
+            bv[q] = (ti != tj && ck < kw && crr + q < nq) ? ldF((nc + q0 + crr + q) + (int64_t)(k0 + ck) * f) : 0.0;
         }
+    };
+    // The chunk loop is software-pipelined through registers: chunk k + 1's operands are on their way from memory while
+    // chunk k's products run (a tile's 6 chunks used to be 6 x (load latency + two barriers)).
+    // (Overlap mode only: without it -- the wide middle levels of cfg2 -- the 18 registers the operands in flight cost the
+    //  kernel were measured as +10 us per factorisation, 1.744 -> 1.755 ms; there the loads stay in front of the barrier.)
+    if (OV && nc > 0) {
+        ensure(0, min(KC, nc));
         __syncthreads();
+        if (!*sh_ok) return;
+        fetch(0, min(KC, nc));
+    }
+    for (int k0 = 0; k0 < nc; k0 += KC) {
+        const bool more = k0 + KC < nc;
+        const int kwn = more ? min(KC, nc - k0 - KC) : 0;
+        if (!OV) fetch(k0, min(KC, nc - k0));
+        __syncthreads();           // previous chunk fully consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            As[ck][crr + q] = av[q];
+            Bs[ck][crr + q] = ((ti == tj) ? av[q] : bv[q]) * dk;          // (diagonal tile: both strips are the same rows)
+        }
+        if (OV && more) ensure(k0 + KC, kwn);
+        __syncthreads();
+        if (OV && !*sh_ok) return;
+        if (OV && more) fetch(k0 + KC, kwn);
         if (active) {
 #pragma unroll
             for (int kk = 0; kk < KC; kk += 4) {
