@@ -1354,7 +1354,17 @@ private:
                 if (L.small || panel_wgs(L) > ov_max) break;
                 --first;
             }
-            ov_first = (launches.size() - first >= 3) ? first : launches.size();
+            // Launches with thousands of tiles stay out of the mode, and with them the whole handle (the overlapped launches
+            // are the schedule's tail): there the tiles ARE the level -- nothing to hide them behind -- and a tile of the mode
+            // is the slower one (54 KB of LDS instead of 33: two workgroups per CU instead of four; operands and results
+            // past the L2's write-back path).  Measured with the mode on / off, by the largest launch of the region:
+            // 1080 tiles 6.25 / 6.45 ms, 1279 tiles 3.17 / 3.65, 1145 tiles 3.74 / 3.72 | 2310 tiles 18.6 / 17.6,
+            // 2428 tiles 9.5 / 8.2, 4253 tiles 10.0 / 7.8, 13 041 tiles 54 / 27, cfg2 with 1 % long-range couplings
+            // (24 000 tiles) 143 / 61 ms.  (cfg2's overlapped launches have at most 418 tiles, cfg5's 630.)
+            static const int ov_max_tiles = std::getenv("HIPKKT_OV_MAX_TILES") ? std::atoi(std::getenv("HIPKKT_OV_MAX_TILES")) : 1600;
+            bool heavy_tiles = false;
+            for (size_t q = first; q < launches.size(); ++q) heavy_tiles = heavy_tiles || launches[q].ntiles > ov_max_tiles;
+            ov_first = (!heavy_tiles && launches.size() - first >= 3) ? first : launches.size();
             {
                 // Runs of narrow launches whose panels share one kernel, found from the root downwards: all launches of a run
                 // are of one kind (whole panels, or row slices -- a launch with sliced fronts runs all its fronts as slices),
