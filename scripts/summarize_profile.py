@@ -12,7 +12,14 @@ import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+
+
+def newest(pattern):
+    """gpurun merges every call's files into the same directories: take the latest run's"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 have_bench = os.path.exists(os.path.join(src, "bench.json")) and os.path.getsize(os.path.join(src, "bench.json")) > 0
 if have_bench:
@@ -26,7 +33,7 @@ def short(name):
 
 traffic = collections.defaultdict(lambda: dict(calls=0, fetch_kb=0.0, write_kb=0.0))
 for key, d in (("fetch_kb", "pmc_fetch"), ("write_kb", "pmc_write")):
-    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))[0]
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         traffic[k][key] += float(r["Counter_Value"])
@@ -39,7 +46,7 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as out:
         out.write(f"{k},{v['calls']},{v['fetch_kb']:.1f},{v['write_kb']:.1f},{v['fetch_kb']/c:.2f},{v['write_kb']/c:.2f}\n")
 # MFMA pipe: SQ_VALU_MFMA_BUSY_CYCLES is summed over all 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs, so the pipe's
 # utilisation inside a kernel is busy / (gui_active / 8 * 1024) = (busy / gui_active) / 128
-mf = glob.glob(os.path.join(src, "pmc_mfma", "*", "*_counter_collection.csv"))
+mf = newest(os.path.join(src, "pmc_mfma", "*", "*_counter_collection.csv"))
 if mf:
     busy = collections.defaultdict(lambda: dict(calls=0, busy=0.0, gui=0.0))
     for r in csv.DictReader(open(mf[0])):
