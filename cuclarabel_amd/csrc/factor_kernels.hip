@@ -793,7 +793,9 @@ constexpr int LDA = TS + 16;    // k-rows 80 doubles apart: consecutive k land 3
 // (The kernel can walk its tiles on a grid smaller than their number -- workgroup b takes tiles b, b + G, ... -- which
 // is how a bounded tile grid was tried for the overlap mode's forward-progress guarantee; measured +0.1 ms on cfg2's
 // factorisation.  The guarantee comes from the gate below instead and the grid is the number of tiles.)
-template <bool OV>
+// PIPE: the chunk loop's operand loads run one chunk ahead (always in overlap mode; without it only in launches of
+// thousands of tiles, launch_schur below).
+template <bool OV, bool PIPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OV ? 3 : 4))) void k_schur(FactorArgs A, const int2* __restrict__ tiles, int tile_begin, int ntiles)
 {
     // the operand chunks are dead once the product is done: the tile buffer shares their LDS (33 KB per
@@ -934,12 +936,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OV ? 3 : 4)
         ensure(0, min(KC, nc));
         __syncthreads();
         if (!*sh_ok) return;
-        fetch(0, min(KC, nc));
     }
+    if (PIPE && nc > 0) fetch(0, min(KC, nc));
     for (int k0 = 0; k0 < nc; k0 += KC) {
         const bool more = k0 + KC < nc;
         const int kwn = more ? min(KC, nc - k0 - KC) : 0;
-        if (!OV) fetch(k0, min(KC, nc - k0));
+        if (!PIPE) fetch(k0, min(KC, nc - k0));
         __syncthreads();           // previous chunk fully consumed
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OV ? 3 : 4)
         if (OV && more) ensure(k0 + KC, kwn);
         __syncthreads();
         if (OV && !*sh_ok) return;
-        if (OV && more) fetch(k0 + KC, kwn);
+        if (PIPE && more) fetch(k0 + KC, kwn);
         if (active) {
 #pragma unroll
             for (int kk = 0; kk < KC; kk += 4) {
@@ -1115,8 +1117,12 @@ void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, 
 void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid)
 {
     if (ntiles <= 0) return;
-    if (a.ov) hipLaunchKernelGGL(k_schur<true>, dim3(std::max(1, std::min(ntiles, ov_grid))), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
-    else hipLaunchKernelGGL(k_schur<false>, dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
+    // (the pipelined chunk loop outside the overlap mode: launches of thousands of tiles -- the trailing blocks of very
+    //  large fronts; on cfg2's wide middle levels its registers cost more than the latency it hides, see k_schur)
+    static const int pipe_tiles = std::getenv("HIPKKT_SCHUR_PIPE_TILES") ? std::atoi(std::getenv("HIPKKT_SCHUR_PIPE_TILES")) : 1600;
+    if (a.ov) hipLaunchKernelGGL((k_schur<true, true>), dim3(std::max(1, std::min(ntiles, ov_grid))), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
+    else if (ntiles > pipe_tiles) hipLaunchKernelGGL((k_schur<false, true>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
+    else hipLaunchKernelGGL((k_schur<false, false>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
 }
 
 }  // namespace hipkkt

@@ -965,6 +965,33 @@ def test_fronts_too_tall_for_the_block_sweep_kernels(maker, rows, no_top):
     assert m and int(m.group(1)) > 0, r.stderr
 
 
+@pytest.mark.parametrize("maker", ["problems.config2(n=6000)", "problems.config3(nblocks=4, blk=400)",
+                                   "problems.config5(n=200, npsd=3, psd_dim=28, nsoc=2, soc_dim=12)",
+                                   "problems.config2(n=3000, long_range_frac=0.01)"])
+def test_launches_of_many_tiles_stay_out_of_the_overlap_mode(maker):
+    """A handle whose overlap region would hold a launch of more than HIPKKT_OV_MAX_TILES Schur tiles (default 1600: the
+    trailing blocks of fronts of some 4000 rows and more) keeps kernel boundaries throughout, and launches of more than
+    HIPKKT_SCHUR_PIPE_TILES tiles take the tile kernel with the pipelined chunk loop (k_schur<false, true>).  Both bounds
+    set to 20 send small problems that way; the solutions must still match the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIPKKT_OV_MAX_TILES="20", HIPKKT_SCHUR_PIPE_TILES="20", HIPKKT_VERBOSE="1")
+    r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SMALL GRID OK" in r.stdout and "gave up" not in r.stderr, r.stderr
+    m = re.search(r"factorisation overlap: last (\d+) launches", r.stderr)
+    assert m and int(m.group(1)) == 0, r.stderr
+    # the same problem with the default bounds does use the mode (so the bound is what switched it off)
+    r2 = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)],
+                        env=dict(os.environ, HIPKKT_VERBOSE="1"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "SMALL GRID OK" in r2.stdout, r2.stdout + r2.stderr
+    m2 = re.search(r"factorisation overlap: last (\d+) launches", r2.stderr)
+    assert m2 and int(m2.group(1)) > 0, r2.stderr
+
+
 def test_json_problem_file_drives_the_c_abi(tmp_path):
     """SURVEY.md section 8 f3: a problem saved in the reference's on-disk format (save_to_file, json.jl:118-156;
     round trip test/UnitTests/test_json.jl:14-25) is loaded back and driven through the C ABI on the GPU; the
