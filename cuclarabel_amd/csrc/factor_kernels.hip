@@ -1114,14 +1114,16 @@ void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, 
     if (a.ov) hipLaunchKernelGGL((k_panel<1024, true, true>), dim3(count), dim3(1024), lds, st, a, begin);
     else hipLaunchKernelGGL((k_panel<1024, true, false>), dim3(count), dim3(1024), lds, st, a, begin);
 }
-void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid)
+void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid, int tile_nc)
 {
     if (ntiles <= 0) return;
-    // (the pipelined chunk loop outside the overlap mode: launches of thousands of tiles -- the trailing blocks of very
-    //  large fronts; on cfg2's wide middle levels its registers cost more than the latency it hides, see k_schur)
+    // (the pipelined chunk loop outside the overlap mode: launches of thousands of tiles whose products are four chunks deep
+    //  or more -- the trailing blocks of very large fronts, cfg5's wide levels; on cfg2's wide middle levels, one to three
+    //  chunks per tile, its registers cost more than the latency it hides, see k_schur)
     static const int pipe_tiles = std::getenv("HIPKKT_SCHUR_PIPE_TILES") ? std::atoi(std::getenv("HIPKKT_SCHUR_PIPE_TILES")) : 1600;
+    static const int pipe_nc = std::getenv("HIPKKT_SCHUR_PIPE_NC") ? std::atoi(std::getenv("HIPKKT_SCHUR_PIPE_NC")) : 64;
     if (a.ov) hipLaunchKernelGGL((k_schur<true, true>), dim3(std::max(1, std::min(ntiles, ov_grid))), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
-    else if (ntiles > pipe_tiles) hipLaunchKernelGGL((k_schur<false, true>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
+    else if (ntiles > pipe_tiles && tile_nc >= pipe_nc) hipLaunchKernelGGL((k_schur<false, true>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
     else hipLaunchKernelGGL((k_schur<false, false>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
 }
 

@@ -68,6 +68,7 @@ struct Launch {
     int solve_bs;               // workgroup size of the block solve kernels for this launch (128 or 256 = the default 512-thread one)
     int ntiny;                  // one-wave launches: the last ntiny fronts have f <= 8 (eight to a wave in the solves)
     int tile_begin, ntiles;     // Schur tiles of this launch's fronts
+    int tile_nc = 0;            // panel columns per tile, averaged over the launch's tiles (the depth of a tile's product)
     int tinv_begin, tinv_count, tinv_ncmax;   // this launch's supernodes that need T = L11^{-1}
     int nsliced;                // the last nsliced fronts of a block-class launch are factorised in row slices ...
     int slice_begin, slice_count;   // ... their slice records in d_sdesc
@@ -147,9 +148,9 @@ public:
                         fmin = std::min(fmin, f); ncmin = std::min(ncmin, nc);
                         flops += (double)nc * (f - nc) * (f - nc) + (double)nc * nc * (f - nc) + (double)nc * nc * nc / 3;
                     }
-                    std::fprintf(stderr, "[hipkkt] launch %zu level %d: %d fronts (%s), f %d..%d, nc %d..%d, %d sliced into %d, %d tiles, %.3f GF\n",
+                    std::fprintf(stderr, "[hipkkt] launch %zu level %d: %d fronts (%s), f %d..%d, nc %d..%d, %d sliced into %d, %d tiles (%d columns deep on average), %.3f GF\n",
                                  q, L.level, L.count, L.small ? "one wave" : "block", fmin, L.fmax, ncmin, L.ncmax, L.nsliced, L.slice_count,
-                                 L.ntiles, flops * 1e-9);
+                                 L.ntiles, L.tile_nc, flops * 1e-9);
                 }
             if (overlap_wanted())
                 for (size_t q = ov_first; q < launches.size(); ++q)
@@ -609,7 +610,7 @@ private:
                     form_w(d_tinv_list.p + L.tinv_begin, L.tinv_count, L.tinv_ncmax, side, 0);
                     forked = true;
                 }
-                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, st);
+                launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, st, 0, L.tile_nc);
             }
         }
         if (forked) {
@@ -1228,11 +1229,13 @@ private:
                 L.tinv_count = (int)tinv_list.size() - L.tinv_begin;
                 if (L.lds_solve > kLdsCap) throw std::runtime_error("front too large for the solve kernels");
                 L.tile_begin = (int)tiles.size();
+                int64_t tile_cols = 0;
                 if (!L.small) {
                     for (int s : v) {
                         int nb = front_size(s) - ncols(s);
                         int nt = (nb + 63) / 64;
                         tile_base[s] = (int64_t)tiles.size();
+                        tile_cols += (int64_t)ncols(s) * (nt * (nt + 1) / 2);
                         for (int ti = 0; ti < nt; ++ti)
                             for (int tj = 0; tj <= ti; ++tj) {
                                 // int2 {x = s, y = ti<<16 | tj}, little endian in one int64
@@ -1242,6 +1245,7 @@ private:
                     }
                 }
                 L.ntiles = (int)tiles.size() - L.tile_begin;
+                L.tile_nc = L.ntiles > 0 ? (int)(tile_cols / L.ntiles) : 0;
                 launches.push_back(L);
                 sched.insert(sched.end(), v.begin(), v.end());
             }

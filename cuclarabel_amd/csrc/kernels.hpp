@@ -237,7 +237,7 @@ void launch_panel(const FactorArgs& a, int begin, int count, int bs, size_t lds,
 // row slices of the panels too tall for one CU (TreeDev::sdesc[begin ..]), one 1024-thread workgroup each
 void launch_panel_sliced(const FactorArgs& a, int begin, int count, size_t lds, hipStream_t st);
 // ov_grid: overlap mode only -- the number of tile workgroups that may exist at a time (they walk the launch's tiles)
-void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid = 0);
+void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int ntiles, hipStream_t st, int ov_grid = 0, int tile_nc = 0);
 // overlap mode: returns (the stream goes on) once *started >= target, i.e. every panel workgroup of the launch is resident
 void launch_ov_gate(const int* started, int target, int* abort_word, long long limit, hipStream_t st);
 // word2[0] must be 0; afterwards word2[1] = 1 iff a kernel on `second`, submitted behind a waiting kernel on `first`, ran

@@ -971,13 +971,14 @@ def test_fronts_too_tall_for_the_block_sweep_kernels(maker, rows, no_top):
 def test_launches_of_many_tiles_stay_out_of_the_overlap_mode(maker):
     """A handle whose overlap region would hold a launch of more than HIPKKT_OV_MAX_TILES Schur tiles (default 1600: the
     trailing blocks of fronts of some 4000 rows and more) keeps kernel boundaries throughout, and launches of more than
-    HIPKKT_SCHUR_PIPE_TILES tiles take the tile kernel with the pipelined chunk loop (k_schur<false, true>).  Both bounds
-    set to 20 send small problems that way; the solutions must still match the oracle."""
+    HIPKKT_SCHUR_PIPE_TILES tiles whose products are HIPKKT_SCHUR_PIPE_NC columns deep on average take the tile kernel with
+    the pipelined chunk loop (k_schur<false, true>).  The tile bounds set to 20 and the depth to 1 send small problems
+    that way; the solutions must still match the oracle."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_OV_MAX_TILES="20", HIPKKT_SCHUR_PIPE_TILES="20", HIPKKT_VERBOSE="1")
+    env = dict(os.environ, HIPKKT_OV_MAX_TILES="20", HIPKKT_SCHUR_PIPE_TILES="20", HIPKKT_SCHUR_PIPE_NC="1", HIPKKT_VERBOSE="1")
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
