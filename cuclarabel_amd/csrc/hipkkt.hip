@@ -76,6 +76,7 @@ struct Launch {
     int ntall;                  // the last ntall fronts of a block-class launch are too tall for the block sweep kernels' LDS
                                 //   (beyond ~10 000 rows): k_fwd_tall / k_bwd_tall; such a launch stays out of the persistent kernels
     int level;                  // tree level: a level has at most one block-class launch, followed by its one-wave launch
+    RecSeg rec;                 // packed sweep records of the launch's fronts (kernels.hpp): class 0 for a block-class launch, 1 and 2 for a one-wave one
 };
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
@@ -199,7 +200,7 @@ public:
             reserve_nr(nr);
         }
         if (no_graph || nr > 1 || n_solve_calls++ == 0) {
-            enqueue_solve(d_b, d_x, stream, allow_top && claim_top(), nr, ldb, ldx);
+            enqueue_solve(d_b, d_x, stream, allow_top && claim_top(), nr, ldb, ldx, allow_top);
             return;
         }
         auto key = std::make_pair((const void*)d_b, (const void*)d_x);
@@ -296,7 +297,7 @@ private:
         a.uvec = uvec_m.p;
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
         a.top_limit = 5000000;       // (the multi-column path has no persistent kernel)
-        a.tk_pos = nullptr; a.tk_sl = nullptr; a.tbase = nullptr; a.xf = nullptr;
+        a.tk_pos = nullptr; a.tk_sl = nullptr; a.tbase = nullptr; a.xf = nullptr; a.chain_cnt = nullptr; a.recs = nullptr;
         launch_pull_leaves_multi(a, n_pull_rows, KP, stream);        // (the pulled leaves' terms, summed per receiving row)
         for (const Launch& L : launches) launch_fwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
         for (size_t q = launches.size(); q-- > 0;) {
@@ -673,7 +674,9 @@ private:
         return g;
     }
 
-    void enqueue_solve(const double* d_b, double* d_x, hipStream_t st, bool use_top, int nr, int64_t ldb, int64_t ldx)
+    // use_top: the persistent kernel may be used (claimed); allow_chain: the caller reads the abort word afterwards and
+    // repeats the solve if a bounded wait expired (the same promise use_top implies), so the chained launches may be used
+    void enqueue_solve(const double* d_b, double* d_x, hipStream_t st, bool use_top, int nr, int64_t ldb, int64_t ldx, bool allow_chain = false)
     {
         SolveArgs a;
         a.T = tree();
@@ -693,44 +696,125 @@ private:
         bool stamp_now = false;
         a.ld_b = ldb; a.ld_out = ldx; a.ld_xp = S.N; a.ld_uvec = (int64_t)std::max<size_t>(S.rows.size(), 1);
         a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p; a.add = nullptr;
+        a.chain_cnt = nullptr;       // (set below when this sweep chains its lower levels)
+        a.recs = d_recs.p ? reinterpret_cast<const char*>(d_recs.p) : nullptr;
         static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
         if (nr > 1 && top_ntask > 0 && (no_top || !use_top || top_disabled || top_sgrid2 <= 0)) {
             // two columns through a set with very tall fronts need its persistent kernel (supports_nr): without it, one
             // column after the other
-            for (int c = 0; c < nr; ++c) enqueue_solve(d_b + (int64_t)c * ldb, d_x + (int64_t)c * ldx, st, use_top, 1, 0, 0);
+            for (int c = 0; c < nr; ++c) enqueue_solve(d_b + (int64_t)c * ldb, d_x + (int64_t)c * ldx, st, use_top, 1, 0, 0, allow_chain);
             return;
         }
         const size_t nl = launches.size();
         // the persistent kernel covers the last ntl launches.  Right after a factorisation the W of the narrow top is
         // still being formed on the side stream: that sweep keeps the per-level launches for the levels below the
         // narrow top, so that the formation hides behind them
-        const int tgrid = (no_top || !use_top || top_disabled) ? 0 : top_grid_for(nr);
+        // Chained launches (chain_kernels.hip): the launches from chain_from on -- the levels with few enough fronts that
+        // a launch per level is one front's latency chain, not throughput -- as segments of ONE grid per direction, ordered
+        // by counters in memory instead of kernel boundaries; the wide levels below keep their launches.  Where the
+        // persistent kernel is available (this handle holds the device's claim) it keeps its set -- its 1024-thread
+        // workgroups park a whole front's matrix items before the wait, a hop costs ~4 us against ~4.2 forward / ~6.3
+        // backward in the 512-thread chained kernel -- and only the launches between chain_from and the set are chained
+        // (cfg2: levels 3 and 4, 32 -> 26 us forward).  A handle WITHOUT the claim (another handle on another stream owns
+        // the persistent kernel) chains everything from chain_from to the root: no residency requirement, so any number
+        // of handles may do that side by side (cfg2's sweep pair then costs what the persistent path costs; level by
+        // level it was half as much again).  HIPKKT_CHAIN=0: off; HIPKKT_CHAIN_TOP=0: chain to the root even with the claim.
+        static const bool chain_env = !(std::getenv("HIPKKT_CHAIN") && std::atoi(std::getenv("HIPKKT_CHAIN")) == 0);
+        static const bool chain_top = !(std::getenv("HIPKKT_CHAIN_TOP") && std::atoi(std::getenv("HIPKKT_CHAIN_TOP")) == 0);
+        // (a set with very tall fronts keeps its (front, slice) kernel: such fronts do not fit one workgroup's LDS)
+        const bool chain_want = chain_env && allow_chain && !chain_disabled && chain_from < nl && chain_lds * (size_t)nr <= 150 * 1024;
+        const bool keep_top = chain_want && (chain_top || top_ntask > 0);
+        const int tgrid = (no_top || !use_top || top_disabled || (chain_want && !keep_top)) ? 0 : top_grid_for(nr);
         size_t ntl = tgrid > 0 ? top_launches : 0;
         int ncount = top_count;
         // (two columns through a set with very tall fronts: the whole set or nothing -- its lower levels do not fit the
         //  per-level kernels with two columns; the sweep then waits for W at the set's first level)
         if (ntl > 0 && w_pending && late_launches > 0 && late_launches < ntl && !(nr > 1 && top_ntask > 0)) { ntl = late_launches; ncount = late_count; }
         const size_t first_w = nl - std::min(nl, late_launches);    // fronts from here on get their W late (w_pending)
+        const bool chain_on = chain_want && chain_from + 2 <= nl - ntl;
+        const size_t nper = chain_on ? chain_from : nl - ntl;        // launches [0, nper) go level by level, [nper, nl - ntl) chained
         // a level's block-class launch and the one-wave launch behind it (sched order) go out as one launch
         static const bool no_merge = std::getenv("HIPKKT_NO_LEVEL_MERGE") != nullptr;
         auto pair_at = [&](size_t q) {      // launches q (block-class) and q + 1 (one-wave) belong to one level
-            return !no_merge && q + 1 + ntl < nl && !launches[q].small && launches[q].ntall == 0 && launches[q + 1].small &&
+            return !no_merge && q + 1 < nper && !launches[q].small && launches[q].ntall == 0 && launches[q + 1].small &&
                    launches[q].level == launches[q + 1].level;
         };
-        for (size_t q = 0; q + ntl < nl; ++q) {
+        // (a level's block-class launch and the one-wave launch behind it as one kernel launch: the records of both)
+        auto pair_rec = [](const Launch& Lb, const Launch& Ls) {
+            RecSeg r = Ls.rec;
+            r.off[0] = Lb.rec.off[0]; r.stride[0] = Lb.rec.stride[0]; r.fmax[0] = Lb.rec.fmax[0];
+            return r;
+        };
+        bool chain_stamp = false;
+        ChainArgs ca;
+        int ca_wgs = 0;
+        size_t ca_lds = 0;
+        auto chain_reset = [&]() {
+            ca.nseg = 0; ca.lo = 1 << 30; ca.hi = 0; ca.cnt = d_chain.p; ca.done = d_chain.p + S.nsuper; ca.nchild = d_chain_nchild.p;
+            ca.abort_word = top_flags.p + 2 * top_nflag; ca.epoch = chain_epoch;
+            ca.lo0 = chain_on ? launches[nper].begin : 0;
+            ca.nstamp = chain_on ? launches[nl - ntl - 1].begin + launches[nl - ntl - 1].count - ca.lo0 : 0;
+            ca_wgs = 0; ca_lds = 0;
+        };
+        auto chain_flush = [&](bool fwd) {
+            if (ca.nseg > 0) {
+                a.top_stamps = chain_stamp ? (long long*)top_stamps.p : nullptr;
+                if (fwd) launch_fwd_chain(a, ca, ca_wgs, ca_lds, st, nr);
+                else launch_bwd_chain(a, ca, ca_wgs, ca_lds, st, nr);
+                a.top_stamps = nullptr;
+            }
+            chain_reset();
+        };
+        auto chain_add = [&](const Launch& L, bool fwd) {
+            const bool blocks = !L.small;
+            if (ca.nseg == kChainMaxSeg) chain_flush(fwd);
+            ChainSeg& sg = ca.seg[ca.nseg++];
+            sg.begin = L.begin;
+            sg.nblock = blocks ? L.count : 0;
+            sg.nwave = blocks ? 0 : L.count - L.ntiny;
+            sg.ntiny = blocks ? 0 : L.ntiny;
+            sg.wg0 = ca_wgs;
+            sg.leaf = (L.small && L.level == 0) ? 1 : 0;
+            sg.rec = L.rec;
+            ca_wgs += chain_seg_wgs(sg);
+            ca.lo = std::min(ca.lo, L.begin);
+            ca.hi = std::max(ca.hi, L.begin + L.count);
+            if (blocks) ca_lds = std::max(ca_lds, L.lds_solve);
+        };
+        if (chain_on) {
+            ++chain_epoch;
+            a.chain_cnt = d_chain.p;
+            // diagnostic (HIPKKT_TOP_STAMPS=n): the n-th single-column chained sweep records six time stamps per
+            // block-class front and direction, printed per launch afterwards
+            if (stamp_call > 0 && nr == 1 && !w_pending && ++n_stamp_sweeps == stamp_call) {
+                const size_t nst = (size_t)(launches[nl - ntl - 1].begin + launches[nl - ntl - 1].count - launches[nper].begin);
+                top_stamps.alloc(2 * nst * 8);
+                top_stamps.zero(st);
+                chain_stamp = true;
+            }
+        }
+        for (size_t q = 0; q < nper; ++q) {
             const Launch& L = launches[q];
             if (q == first_w) wait_w(st);
             if (pair_at(q)) {
                 const Launch& Ls = launches[q + 1];
                 if (q + 1 == first_w) wait_w(st);
-                launch_fwd_level(a, L.begin, L.count, Ls.count - Ls.ntiny, Ls.ntiny, L.solve_bs, L.lds_solve, st, nr);
+                launch_fwd_level(a, pair_rec(L, Ls), L.begin, L.count, Ls.count - Ls.ntiny, Ls.ntiny, L.solve_bs, L.lds_solve, st, nr);
                 ++q;
             } else if (L.small) {
-                launch_fwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, L.level == 0, nr);
+                launch_fwd_small(a, L.rec, L.begin, L.count - L.ntiny, L.ntiny, st, L.level == 0, nr);
             } else {
-                launch_fwd(a, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
+                launch_fwd(a, L.rec, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
                 launch_fwd_tall(a, L.begin + L.count - L.ntall, L.ntall, st);        // (fronts beyond the block kernels' LDS)
             }
+        }
+        if (chain_on) {
+            chain_reset();
+            for (size_t q = nper; q + ntl < nl; ++q) {
+                if (q == first_w) { chain_flush(true); wait_w(st); }
+                chain_add(launches[q], true);
+            }
+            chain_flush(true);
         }
         wait_w(st);
         if (ntl > 0) {
@@ -741,7 +825,7 @@ private:
                 const int pos0 = top_count - ncount;
                 const int task0 = h_tbase[(size_t)pos0];
                 bool sl_stamp = false;
-                if (stamp_call > 0 && nr == 1 && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
+                if (stamp_call > 0 && !chain_on && nr == 1 && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
                     top_stamps.alloc((size_t)2 * (top_ntask - task0) * 8);
                     top_stamps.zero(st);
                     a.top_stamps = (long long*)top_stamps.p;
@@ -776,7 +860,7 @@ private:
                 }
             } else {
                 static const int stamp_nr = std::getenv("HIPKKT_TOP_STAMPS_NR") ? std::atoi(std::getenv("HIPKKT_TOP_STAMPS_NR")) : 1;
-                if (stamp_call > 0 && nr == stamp_nr && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
+                if (stamp_call > 0 && !chain_on && nr == stamp_nr && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
                     top_stamps.alloc((size_t)2 * ncount * 8);
                     top_stamps.zero(st);
                     a.top_stamps = (long long*)top_stamps.p;
@@ -818,16 +902,50 @@ private:
                 }
             }
         }
-        for (size_t q = nl - ntl; q-- > 0;) {
+        if (chain_on) {
+            chain_reset();
+            for (size_t q = nl - ntl; q-- > nper;) chain_add(launches[q], false);
+            chain_flush(false);
+            if (chain_stamp) {
+                const int lo0 = launches[nper].begin;
+                const size_t nst = (size_t)(launches[nl - ntl - 1].begin + launches[nl - ntl - 1].count - lo0);
+                std::vector<long long> h(2 * nst * 8);
+                HIP_CHECK(hipMemcpyAsync(h.data(), top_stamps.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                for (int dir = 0; dir < 2; ++dir) {
+                    long long t00 = 0;
+                    for (size_t k = 0; k < nst; ++k) { const long long v = h[((size_t)dir * nst + k) * 8]; if (v && (!t00 || v < t00)) t00 = v; }
+                    for (size_t qq = nper; qq + ntl < nl; ++qq) {
+                        const size_t q = dir == 0 ? qq : nl - ntl - 1 - (qq - nper);
+                        const Launch& L = launches[q];
+                        if (L.small) continue;
+                        double d[5] = {0, 0, 0, 0, 0}, first_start = 1e30, last_start = 0, last_seen = 0, first_done = 1e30, last_done = 0;
+                        for (int t = L.begin; t < L.begin + L.count; ++t) {
+                            const long long* e = &h[((size_t)dir * nst + (size_t)(t - lo0)) * 8];
+                            for (int k = 0; k < 5; ++k) d[k] += (e[k + 1] - e[k]) * 0.01;
+                            first_start = std::min(first_start, (e[0] - t00) * 0.01);
+                            last_start = std::max(last_start, (e[0] - t00) * 0.01);
+                            last_seen = std::max(last_seen, (e[2] - t00) * 0.01);
+                            first_done = std::min(first_done, (e[5] - t00) * 0.01);
+                            last_done = std::max(last_done, (e[5] - t00) * 0.01);
+                        }
+                        std::fprintf(stderr, "[chain stamps] %s launch %2zu level %2d: %4d fronts, starts %6.2f .. %6.2f, last sees its flag %6.2f, done %6.2f .. %6.2f us | "
+                                     "mean: preload %5.2f wait %6.2f gather %5.2f products %5.2f reduce+store %5.2f\n", dir == 0 ? "fwd" : "bwd", q, L.level, L.count,
+                                     first_start, last_start, last_seen, first_done, last_done, d[0] / L.count, d[1] / L.count, d[2] / L.count, d[3] / L.count, d[4] / L.count);
+                    }
+                }
+            }
+        }
+        for (size_t q = nper; q-- > 0;) {
             const Launch& L = launches[q];
             if (q > 0 && pair_at(q - 1)) {
                 const Launch& Lb = launches[q - 1];
-                launch_bwd_level(a, Lb.begin, Lb.count, L.count - L.ntiny, L.ntiny, Lb.solve_bs, Lb.lds_solve, st, nr);
+                launch_bwd_level(a, pair_rec(Lb, L), Lb.begin, Lb.count, L.count - L.ntiny, L.ntiny, Lb.solve_bs, Lb.lds_solve, st, nr);
                 --q;
             } else if (L.small) {
-                launch_bwd_small(a, L.begin, L.count - L.ntiny, L.ntiny, st, nr);
+                launch_bwd_small(a, L.rec, L.begin, L.count - L.ntiny, L.ntiny, st, nr);
             } else {
-                launch_bwd(a, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
+                launch_bwd(a, L.rec, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
                 launch_bwd_tall(a, L.begin + L.count - L.ntall, L.ntall, st);
             }
         }
@@ -842,6 +960,17 @@ private:
         HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
         w_pending = false;
     }
+
+    // ---- chained launches (chain_kernels.hip)
+    DBuf<int> d_chain;           // [0, nsuper): forward counters (zero between sweeps); [nsuper, 2 nsuper): backward epoch words
+    int chain_epoch = 0;
+    bool chain_disabled = false;
+    size_t chain_from = ~(size_t)0;  // first chained launch (>= launches.size(): none)
+    size_t chain_lds = 0;            // LDS of the largest block-class front in the chained launches, per right-hand side
+    DBuf<int> d_chain_nchild;    // per supernode: its children in chained launches (the ones that count themselves in)
+    std::vector<int64_t> h_toff; // (upload: solve-matrix offsets and chained-children counts, kept for build_records)
+    std::vector<int> h_nch;
+    DBuf<int64_t> d_recs;        // packed sweep records (kernels.hpp: SolveHdr); empty: the legacy layout
 
     // ---- persistent-kernel bookkeeping
     bool top_claimed = false, top_disabled = false;
@@ -872,15 +1001,17 @@ private:
 
 public:
     // device word set by the persistent kernel when one of its bounded waits expired (nullptr: no such kernel)
-    const int* top_abort_word() const { return (top_flags.p && top_launches > 0) ? top_flags.p + 2 * top_nflag : nullptr; }
+    const int* top_abort_word() const { return (top_flags.p && (top_launches > 0 || chain_from < launches.size())) ? top_flags.p + 2 * top_nflag : nullptr; }
     // The caller has synchronised and found the abort word set: clear it and never use the kernel again.
     int64_t n_ov_fallbacks = 0, n_top_fallbacks = 0;      // lifetime counts (hipkkt_profile, hipkkt_ldl_fallbacks)
     void top_gave_up()
     {
         top_disabled = true;
+        chain_disabled = true;       // (the chained launches share the abort word: whichever wait expired, both go)
         ++n_top_fallbacks;
         release_top();
         launch_zero_ints(top_flags.p + 2 * top_nflag, 1, stream);
+        if (d_chain.p) launch_zero_ints(d_chain.p, 2 * S.nsuper, stream);       // (an abandoned sweep leaves counters behind)
         std::fprintf(stderr, "[hipkkt] persistent top-of-tree kernel gave up waiting (GPU shared with another "
                              "resident kernel?); falling back to one launch per level\n");
     }
@@ -1252,6 +1383,98 @@ private:
         }
     }
 
+    // Packed sweep records (kernels.hpp: SolveHdr / RecSeg): per launch and size class one record size, so that a
+    // kernel finds a front's record from its place in the launch and fetches header and row slots in one round of loads.
+    // HIPKKT_PACKED=0, or more than HIPKKT_PACKED_MAX_MB (4096) of records -- a wide level with one very tall front pays
+    // that front's height for every front --: the legacy layout.
+    void build_records(const std::vector<int64_t>& glptr, const std::vector<int>& gsrc)
+    {
+        static const bool packed_on = !(std::getenv("HIPKKT_PACKED") && std::atoi(std::getenv("HIPKKT_PACKED")) == 0);
+        static const int64_t max_mb = std::getenv("HIPKKT_PACKED_MAX_MB") ? std::atoll(std::getenv("HIPKKT_PACKED_MAX_MB")) : 4096;
+        for (Launch& L : launches) L.rec = RecSeg{};
+        if (!packed_on) return;
+        static_assert(sizeof(SolveHdr) == 64, "SolveHdr layout");
+        int64_t total = 0;
+        struct Cls { int first, count, cls; };
+        auto classes = [&](const Launch& L) {
+            std::vector<Cls> v;
+            if (L.small) {
+                if (L.count - L.ntiny > 0) v.push_back({L.begin, L.count - L.ntiny, 1});
+                if (L.ntiny > 0) v.push_back({L.begin + L.count - L.ntiny, L.ntiny, 2});
+            } else if (L.count > 0) {
+                v.push_back({L.begin, L.count, 0});
+            }
+            return v;
+        };
+        // no gather slots for the one-wave launch of tree level 0 (its fronts have no children, and its kernels are told
+        // so: `leaf`) -- unless a block-class launch of that level sits in front of it: the two may then go out as one
+        // level kernel, whose one-wave bodies read the slots
+        auto no_slots = [&](size_t q) {
+            const Launch& L = launches[q];
+            return L.small && L.level == 0 && !(q > 0 && !launches[q - 1].small && launches[q - 1].level == 0);
+        };
+        for (size_t q = 0; q < launches.size(); ++q) {
+            Launch& L = launches[q];
+            const bool leaf = no_slots(q);
+            for (const Cls& c : classes(L)) {
+                const int fmax = c.cls == 0 ? ((L.fmax + 3) & ~3) : (c.cls == 1 ? 64 : 8);
+                const int64_t stride = ((int64_t)sizeof(SolveHdr) + 4 * (int64_t)fmax + (leaf ? 0 : 32 * (int64_t)fmax) + 63) & ~(int64_t)63;
+                if (stride > (1 << 30)) return;
+                L.rec.off[c.cls] = total;
+                L.rec.stride[c.cls] = (int)stride;
+                L.rec.fmax[c.cls] = fmax;
+                total += stride * c.count;
+            }
+        }
+        if (total > max_mb * (1 << 20)) {
+            for (Launch& L : launches) L.rec = RecSeg{};
+            if (std::getenv("HIPKKT_VERBOSE")) std::fprintf(stderr, "[hipkkt] packed sweep records would take %.0f MB: legacy layout\n", total / 1048576.0);
+            return;
+        }
+        std::vector<int64_t> store((size_t)(total / 8) + 8, 0);
+        char* base = reinterpret_cast<char*>(store.data());
+        for (size_t q = 0; q < launches.size(); ++q) {
+            const Launch& L = launches[q];
+            const bool leaf = no_slots(q);
+            for (const Cls& c : classes(L)) {
+                const int fmax = L.rec.fmax[c.cls];
+                for (int k = 0; k < c.count; ++k) {
+                    const int sn = sched[(size_t)(c.first + k)];
+                    char* rec = base + L.rec.off[c.cls] + (int64_t)k * L.rec.stride[c.cls];
+                    const int nc = S.sn_start[sn + 1] - S.sn_start[sn], nb = (int)(S.rowptr[sn + 1] - S.rowptr[sn]), f = nc + nb;
+                    if (f > fmax) throw std::runtime_error("packed record: front larger than its class");
+                    SolveHdr h{};
+                    h.mat_off = c.cls == 0 ? h_toff[(size_t)sn] : S.front_off[sn];
+                    h.rp = S.rowptr[sn];
+                    h.s = sn; h.c0 = S.sn_start[sn]; h.nc = nc; h.nb = nb;
+                    h.par = S.sn_parent[sn];
+                    h.nchild = h_nch.empty() ? 0 : h_nch[(size_t)sn];
+                    std::memcpy(rec, &h, sizeof(h));
+                    int* idx = reinterpret_cast<int*>(rec + sizeof(SolveHdr));
+                    for (int i = 0; i < nc; ++i) idx[i] = S.perm[(size_t)(h.c0 + i)];
+                    for (int i = nc; i < f; ++i) idx[i] = S.rows[(size_t)(h.rp + i - nc)];
+                    if (leaf) continue;
+                    int* slot = idx + fmax;
+                    const int64_t lc0 = (int64_t)h.c0 + h.rp;
+                    for (int i = 0; i < fmax; ++i) {
+                        int* g = slot + 8 * (int64_t)i;
+                        g[0] = 0;
+                        for (int q = 1; q <= 6; ++q) g[q] = -1;
+                        g[7] = 0;
+                        if (i >= f) continue;
+                        const int64_t g0 = glptr[(size_t)(lc0 + i)], g1 = glptr[(size_t)(lc0 + i + 1)];
+                        g[0] = (int)(g1 - g0);
+                        for (int q = 0; q < 6 && g0 + q < g1; ++q) g[1 + q] = gsrc[(size_t)(g0 + q)];
+                        g[7] = (int)(g0 + 6);
+                    }
+                }
+            }
+        }
+        store.resize((size_t)(total / 8) + 8);
+        d_recs.upload(store);
+        if (std::getenv("HIPKKT_VERBOSE")) std::fprintf(stderr, "[hipkkt] packed sweep records: %.1f MB\n", total / 1048576.0);
+    }
+
     void upload(const std::vector<int>& dsigns)
     {
         // leaves with one column and a short row list, pulled by their parents in the many-column sweeps (see the gather
@@ -1443,6 +1666,7 @@ private:
                 toff[S.nsuper] = wo;
             }
             d_tinv_off.upload(toff);
+            h_toff = toff;
             static_assert(sizeof(FrontDesc) == 64, "FrontDesc layout");
             std::vector<FrontDesc> desc(sched.size());
             for (size_t q = 0; q < sched.size(); ++q) {
@@ -1567,6 +1791,32 @@ private:
             }
             top_flags.alloc((size_t)2 * std::max(top_nflag, 1) + 4);
             HIP_CHECK(hipMemset(top_flags.p, 0, top_flags.n * sizeof(int)));
+            // chained launches: every launch must fit the chained kernels (no front beyond the block kernels' LDS)
+            // chain_from: the longest suffix of launches with at most chain_max workgroups each (HIPKKT_CHAIN_MAX; the wide
+            // levels below are throughput-bound: a launch each costs them little, while their thousands of waiting
+            // workgroups would crowd a chained grid), every front of which fits the chained kernels' LDS
+            {
+                static const int chain_max = std::getenv("HIPKKT_CHAIN_MAX") ? std::atoi(std::getenv("HIPKKT_CHAIN_MAX")) : 640;
+                size_t q = launches.size();
+                while (q > 0) {
+                    const Launch& L = launches[q - 1];
+                    ChainSeg sg{L.begin, L.small ? 0 : L.count, L.small ? L.count - L.ntiny : 0, L.small ? L.ntiny : 0, 0, 0, RecSeg{}};
+                    if (L.ntall > 0 || (!L.small && L.lds_solve > 150 * 1024) || chain_seg_wgs(sg) > chain_max) break;
+                    if (!L.small) chain_lds = std::max(chain_lds, L.lds_solve);
+                    --q;
+                }
+                chain_from = launches.size() - q >= 2 ? q : launches.size();
+                std::vector<int> nch((size_t)std::max(S.nsuper, 1), 0);
+                if (chain_from < launches.size()) {
+                    const int p0 = launches[chain_from].begin;
+                    for (int c = 0; c < S.nsuper; ++c)
+                        if (S.sn_parent[c] >= 0 && spos[(size_t)c] >= p0) nch[(size_t)S.sn_parent[c]]++;
+                }
+                d_chain_nchild.upload(nch);
+                h_nch = nch;
+            }
+            d_chain.alloc((size_t)2 * std::max(S.nsuper, 1));
+            HIP_CHECK(hipMemset(d_chain.p, 0, d_chain.n * sizeof(int)));
             tinv.alloc((size_t)toff[S.nsuper]);
             HIP_CHECK(hipMemset(tinv.p, 0, std::max<size_t>(tinv.n, 1) * sizeof(double)));
             d_tinv_list.upload(tinv_list);
@@ -1876,6 +2126,7 @@ private:
             d_sitems.upload(raw2);
             d_tile_cut.upload(tcut);
             d_gl_src.upload(gsrc);
+            build_records(ptr, gsrc);
             // where each contribution entry sits in its receiver's gather list (solve_multi's layout)
             std::vector<int> ud(std::max<size_t>(S.rows.size(), 1), 0);
             for (size_t g = 0; g < gsrc.size(); ++g) ud[(size_t)gsrc[g]] = (int)g;
@@ -2212,6 +2463,51 @@ int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* row
                 std::fprintf(stderr, "[levels] %2zu: %6d fronts (%6d f<=8, %6d f<=64) fmax %4d ncmax %3d cols %7.0f panel %.2f MB "
                              "upd %.2f MB flops %.1f M | panels by LDS <=52K %d, <=79K %d, more %d\n", l, cnt, n8, n64, fmax, ncmax, cols, panel * 8e-6,
                              upd * 8e-6, flops * 1e-6, lds3, lds2, lds1);
+            }
+        }
+        if (std::getenv("HIPKKT_DUMP_SUBTREES")) {        // diagnostic: what the subtrees below a cut level look like (host only)
+            {
+                std::vector<int> hist(8, 0);
+                int mx = 0;
+                for (int sn = 0; sn < S.nsuper; ++sn) {
+                    const int k = S.child_ptr[sn + 1] - S.child_ptr[sn];
+                    mx = std::max(mx, k);
+                    hist[k == 0 ? 0 : k <= 4 ? 1 : k <= 16 ? 2 : k <= 64 ? 3 : k <= 256 ? 4 : k <= 1024 ? 5 : 6]++;
+                }
+                std::fprintf(stderr, "[subtrees] children per front: 0: %d, 1-4: %d, 5-16: %d, 17-64: %d, 65-256: %d, 257-1024: %d, more: %d (max %d)\n",
+                             hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], mx);
+            }
+            for (int cut = 0; cut < (int)S.levels.size() && cut < 10; ++cut) {
+                std::vector<int> root_of((size_t)S.nsuper, -1);
+                // level_sn is leaves first: walk from the top so that a parent's root is known before its children's
+                for (int t = S.nsuper - 1; t >= 0; --t) {
+                    const int sn = S.level_sn[(size_t)t];
+                    if (S.sn_level[(size_t)sn] > cut) continue;
+                    const int p = S.sn_parent[(size_t)sn];
+                    root_of[(size_t)sn] = (p >= 0 && S.sn_level[(size_t)p] <= cut) ? root_of[(size_t)p] : sn;
+                }
+                struct St { double fronts = 0, cols = 0, snb = 0, bytes = 0, border = 0; int fmax = 0; };
+                std::map<int, St> st;
+                for (int sn = 0; sn < S.nsuper; ++sn) {
+                    if (root_of[(size_t)sn] < 0) continue;
+                    St& x = st[root_of[(size_t)sn]];
+                    const int nc = S.sn_start[sn + 1] - S.sn_start[sn], nb = (int)(S.rowptr[sn + 1] - S.rowptr[sn]);
+                    x.fronts += 1; x.cols += nc; x.snb += nb; x.bytes += 8.0 * (nc + nb) * nc * (nc + nb > 64 ? 2 : 1);
+                    x.fmax = std::max(x.fmax, nc + nb);
+                    if (root_of[(size_t)sn] == sn) x.border = nb;
+                }
+                St mx, sum;
+                for (auto& kv : st) {
+                    const St& x = kv.second;
+                    mx.fronts = std::max(mx.fronts, x.fronts); mx.cols = std::max(mx.cols, x.cols); mx.snb = std::max(mx.snb, x.snb);
+                    mx.bytes = std::max(mx.bytes, x.bytes); mx.border = std::max(mx.border, x.border); mx.fmax = std::max(mx.fmax, x.fmax);
+                    sum.fronts += x.fronts; sum.cols += x.cols; sum.snb += x.snb; sum.bytes += x.bytes;
+                }
+                const double k = st.empty() ? 1.0 : (double)st.size();
+                std::fprintf(stderr, "[subtrees] cut %d: %zu subtrees; fronts %.0f total, %.0f mean, %.0f max; cols %.0f mean %.0f max; "
+                             "sum nb %.0f mean %.0f max; matrix %.1f MB total, %.0f KB mean, %.0f KB max; border max %.0f, fmax %d\n",
+                             cut, st.size(), sum.fronts, sum.fronts / k, mx.fronts, sum.cols / k, mx.cols, sum.snb / k, mx.snb,
+                             sum.bytes * 1e-6, sum.bytes / k * 1e-3, mx.bytes * 1e-3, mx.border, mx.fmax);
             }
         }
         if (perm_out) for (int64_t i = 0; i < N; ++i) perm_out[i] = S.perm[i];

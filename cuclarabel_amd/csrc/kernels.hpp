@@ -80,6 +80,28 @@ struct FrontDesc {               // everything a kernel needs to know about one 
     int pad;                     // row-sliced panels (TreeDev::sdesc): slice << 16 | number of slices
 };
 
+// Packed sweep records (hipkkt.hip, build_records): what a sweep kernel needs to know about a front, laid out so that it
+// arrives in ONE round of loads.  The fronts of a launch and size class (block-class / one-wave / tiny) have records of one
+// size, so a record's address follows from the front's place in the launch alone: [SolveHdr (64 B)] [idx: fmax ints]
+// [gather slots: fmax x 32 B, absent on tree level 0] -- a thread fetches the header and its row's slots side by side,
+// and the values (b, the children's contributions, the matrix) in the second round.  The legacy layout (FrontDesc ->
+// gl_ptr / perm / rows -> gl_src -> values) took four.
+//   idx[i]   i < nc: the row of column c0 + i in the caller's order (perm); i >= nc: the permuted index of below-row i (rows)
+//   slot i   {count, six sources (indices into uvec, -1 beyond the count), index into gl_src of the seventh source}
+struct SolveHdr {
+    int64_t mat_off;             // block class: W = [T; M] in the solve-matrix store (W' behind it); one-wave / tiny: the panel in the front store
+    int64_t rp;                  // rowptr[s]: first of the nb rows below in rows[] / uvec
+    int s, c0, nc, nb;
+    int par;                     // parent supernode, -1 for a root
+    int nchild;                  // children swept by chained launches (ChainArgs::nchild)
+    int64_t pad[3];
+};
+struct RecSeg {                  // the records of one kernel launch's fronts, by size class: 0 block-class, 1 one-wave, 2 tiny
+    int64_t off[3];              // byte offset in SolveArgs::recs of the class's first record
+    int stride[3];               // bytes per record
+    int fmax[3];                 // row slots per record (a multiple of 4)
+};
+
 struct TreeDev {                 // device copies of the symbolic structure
     int nsuper;
     const int* sn_start;         // nsuper+1
@@ -207,6 +229,10 @@ struct SolveArgs {
     const int* tbase;
     double* xf;
     const double* add;           // many-column sweeps (row-major N x KP): out = solution + add where non-null
+    const char* recs;            // packed sweep records (SolveHdr ...), or null: the legacy layout (TreeDev::desc, gl_ptr, ...)
+    int* chain_cnt;              // nullable; the chained launches' forward counters (ChainArgs::cnt): a sweep that chains the
+                                 // levels below the persistent set leaves the set's fronts' counters at their bottom
+                                 // children's count, and the persistent kernels put them back to zero
 };
 
 constexpr int kSolveChunk = 128;  // diagonal chunk of the triangular solves: one wave, two unknowns per lane
@@ -245,14 +271,15 @@ void launch_ov_gate(const int* started, int target, int* abort_word, long long l
 void launch_concurrency_probe(int* word2, hipStream_t first, hipStream_t second);
 size_t panel_lds_bytes(int fmax, int panel_max);
 // nr = 1, 2 or 4 right-hand sides per launch (column strides in SolveArgs::ld_*); lds = bytes per right-hand side
-void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);
-void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);
+// (rs: the launch's packed records; ignored when SolveArgs::recs is null)
+void launch_fwd(const SolveArgs& a, const RecSeg& rs, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);
+void launch_bwd(const SolveArgs& a, const RecSeg& rs, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);
 // one launch for a level's one-wave fronts [begin, begin + nwave) and the tiny fronts behind them
-void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf = false, int nr = 1);
-void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, int nr = 1);
+void launch_fwd_small(const SolveArgs& a, const RecSeg& rs, int begin, int nwave, int ntiny, hipStream_t st, bool leaf = false, int nr = 1);
+void launch_bwd_small(const SolveArgs& a, const RecSeg& rs, int begin, int nwave, int ntiny, hipStream_t st, int nr = 1);
 // one launch for a whole level: nblock block-class fronts at [begin, ..), then nwave one-wave, then ntiny tiny fronts
-void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr = 1);
-void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr = 1);
+void launch_fwd_level(const SolveArgs& a, const RecSeg& rs, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr = 1);
+void launch_bwd_level(const SolveArgs& a, const RecSeg& rs, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr = 1);
 
 // several right-hand sides: work vectors row-major N x KP / sum(nb) x KP (KP = columns rounded up to 16)
 // iperm[caller's index] = permuted index
@@ -265,6 +292,34 @@ void launch_fwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st); 
 void launch_bwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st);
 void launch_pull_leaves_multi(const SolveArgs& a, int nrows, int KP, hipStream_t st);
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st, bool leaves = false);
+
+// ---- chained levels (chain_kernels.hip): several tree levels of a sweep in ONE launch, ordered by counters in memory
+// instead of kernel boundaries.  A segment is one launch of the per-level path (same three size classes); workgroups are
+// numbered segment by segment, so that every workgroup depends only on workgroups with a LOWER index.
+struct ChainSeg {
+    int begin;                   // schedule position of the segment's first front
+    int nblock, nwave, ntiny;    // block-class fronts, then one-wave fronts, then tiny fronts (f <= 8)
+    int wg0;                     // the segment's first workgroup
+    int leaf;                    // forward: the fronts have no children (tree level 0)
+    RecSeg rec;                  // the fronts' packed records
+};
+constexpr int kChainMaxSeg = 20;
+struct ChainArgs {
+    int nseg;
+    int lo, hi;                  // schedule positions covered by this launch (backward: a parent at a position >= hi is complete)
+    int* cnt;                    // nsuper: forward, children of supernode s that have handed over their contribution this sweep
+    const int* nchild;           // nsuper: how many of s's children are swept by chained launches (the ones that add to cnt[s])
+    int* done;                   // nsuper: backward, epoch of supernode s's last finished backward step
+    int* abort_word;             // set when a bounded wait expires: everyone leaves, the host repeats the sweep level by level
+    int epoch;
+    int lo0, nstamp;             // diagnostic (SolveArgs::top_stamps): first position and number of fronts of the sweep's chained part
+    ChainSeg seg[kChainMaxSeg];
+};
+// lds = bytes per right-hand side of the largest block-class front in the segments (0: none)
+void launch_fwd_chain(const SolveArgs& a, const ChainArgs& c, int nwg, size_t lds, hipStream_t st, int nr);
+void launch_bwd_chain(const SolveArgs& a, const ChainArgs& c, int nwg, size_t lds, hipStream_t st, int nr);
+constexpr int kChainBS = 512;    // workgroup size of the chained kernels: one block-class front, 8 one-wave or 64 tiny fronts
+inline int chain_seg_wgs(const ChainSeg& s) { return s.nblock + (s.nwave + kChainBS / 64 - 1) / (kChainBS / 64) + (s.ntiny + kChainBS / 8 - 1) / (kChainBS / 8); }
 
 // ---- KKT value updates (kktsolver_directldl.jl:130-188, 211-245, 374-386)
 void launch_scatter(double* Kval, const int* idx, const double* vals, int64_t n, double scale, hipStream_t st);

@@ -15,120 +15,51 @@
 //            workgroup barrier per column); the off-diagonal panel is a dense GEMV streamed from
 //            HBM/L2 with 8 independent loads in flight per lane.
 #include "kernels.hpp"
+#include "solve_common.hpp"
 #include <algorithm>
 #include <cstdlib>
 
 namespace hipkkt {
 
-__device__ inline double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
 
-// Sum over the wave's 64 lanes, returned in every lane.  DPP row shifts inside the 16-lane rows, then the two row
-// broadcasts: 6 steps of two 32-bit DPP moves and one add, no LDS crossbar (the __shfl_xor butterfly costs two
-// ds_bpermute round trips per step: a 45-column slice of the backward sweep spent most of its time in them).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add_step(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __hiloint2double(hi, lo);           // (lanes without a source, or outside the row mask, add +0.0)
-}
-// ... and over aligned groups of eight lanes (the tiny fronts): neighbours, the quad's other pair, the other quad
-__device__ inline double group8_sum(double v)
-{
-    v = dpp_add_step<0xB1, 0xf>(v);                // quad_perm [1,0,3,2]
-    v = dpp_add_step<0x4E, 0xf>(v);                // quad_perm [2,3,0,1] -> every lane holds its quad's sum
-    v = dpp_add_step<0x141, 0xf>(v);               // row_half_mirror: the other quad's sum
-    return v;
-}
-__device__ inline double wave_reduce_sum(double v)
-{
-    v = dpp_add_step<0x111, 0xf>(v);               // row_shr:1
-    v = dpp_add_step<0x112, 0xf>(v);               // row_shr:2
-    v = dpp_add_step<0x114, 0xf>(v);               // row_shr:4
-    v = dpp_add_step<0x118, 0xf>(v);               // row_shr:8   -> lane 15 of every row holds the row's sum
-    v = dpp_add_step<0x142, 0xa>(v);               // row_bcast:15 into rows 1 and 3
-    v = dpp_add_step<0x143, 0xc>(v);               // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return readlane_f64(v, 63);
-}
-
-// Every kernel below takes NR right-hand sides at once (NR = 1, 2 or 4; column c of a vector v lives at
-// v + c * ld_v, SolveArgs::ld_*): the entries of L / W, the gather lists and the row indices are fetched ONCE and used
-// for all NR columns.  These sweeps are bound by the latency of the tree's dependency chain, not by arithmetic, so two
-// columns cost little more than one -- which is what lets an interior-point iteration's independent solves (constant
-// and affine right-hand sides, /root/reference/src/kktsystem.jl:87-88 vs :170-171) share a sweep.
-// ------------------------------------------------------------------ small fronts, one wave each
-// The sweeps' internal vectors (xp, uvec) keep their NR columns interleaved: entry i of column c at i * NR + c.
-// One 8 * NR-byte access fetches / stores an entry of every column (the stores are 256-byte aligned allocations).
-template <int NR>
-__device__ inline void ldv(const double* __restrict__ base, int64_t i, double (&out)[NR])
-{
-    if constexpr (NR == 1) out[0] = base[i];
-    else if constexpr (NR == 2) {
-        const double2 t = *reinterpret_cast<const double2*>(base + 2 * i);
-        out[0] = t.x; out[1] = t.y;
-    } else {
-        static_assert(NR == 4, "1, 2 or 4 right-hand sides");
-        const double4 t = *reinterpret_cast<const double4*>(base + 4 * i);
-        out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
-    }
-}
-template <int NR>
-__device__ inline void stv(double* __restrict__ base, int64_t i, const double (&v)[NR])
-{
-    if constexpr (NR == 1) base[i] = v[0];
-    else if constexpr (NR == 2) *reinterpret_cast<double2*>(base + 2 * i) = make_double2(v[0], v[1]);
-    else *reinterpret_cast<double4*>(base + 4 * i) = make_double4(v[0], v[1], v[2], v[3]);
-}
+// The static description of a front comes from its packed record (A.recs; rec_of) in one round of loads -- header and
+// this lane's row slots side by side -- or, without records, from the legacy chain FrontDesc -> perm / rows / gl_ptr -> gl_src.
+struct FrontLoc { int c0, nc, nb; int64_t rp, mat; };
+__device__ __forceinline__ FrontLoc front_loc(const SolveHdr& h) { return FrontLoc{h.c0, h.nc, h.nb, h.rp, h.mat_off}; }
 
 template <int NR>
-__device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int count, int bx, bool leaf = false)
+__device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, const RecSeg& R, int begin, int count, int bx, bool leaf = false)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int item = bx * (int)(blockDim.x >> 6) + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + item];
-    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
+    FrontLoc L;
+    int pi = 0;
+    RowGather G;
+    G.cnt = 0;
+    if (const char* rec = rec_of(A, R, 1, item)) {
+        const SolveHdr h = *reinterpret_cast<const SolveHdr*>(rec);
+        pi = rec_idx(rec, lane);
+        if (!leaf) G = rec_gather(rec, R.fmax[1], lane);
+        L = front_loc(h);
+    } else {
+        const FrontDesc fd = T.desc[begin + item];
+        L = FrontLoc{fd.c0, fd.nc, fd.nb, fd.rp, fd.front_off};
+        pi = (lane < L.nc) ? T.perm[L.c0 + lane] : 0;
+        if (!leaf && lane < L.nc + L.nb) G = row_gather_lists(T, (int64_t)L.c0 + L.rp + lane);
+    }
+    const int c0 = L.c0, nc = L.nc, nb = L.nb;
+    const int64_t rp = L.rp;
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + fd.front_off;
+    const double* __restrict__ F = A.fronts + L.mat;
 
     // gather: right-hand side entry plus the children's contributions to this row, in child order
     double y[NR];
-    {
-        const int pi = (lane < nc) ? T.perm[c0 + lane] : 0;
 #pragma unroll
-        for (int c = 0; c < NR; ++c) y[c] = (lane < nc) ? A.b[c * A.ld_b + pi] : 0.0;
-    }
-    if (!leaf && lane < f) {                  // (a leaf has no gather lists to look at)
-        const int64_t lc = (int64_t)c0 + rp + lane;
-        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        // four sources per pair of load rounds (indices, then all columns' values); sums in list order
-        for (int64_t g = g0; g < g1; g += 4) {
-            int src[4];
-            double u[NR][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double t[NR];
-#pragma unroll
-                for (int c = 0; c < NR; ++c) t[c] = 0.0;
-                if (src[q] >= 0) ldv<NR>(A.uvec, src[q], t);
-#pragma unroll
-                for (int c = 0; c < NR; ++c) u[c][q] = t[c];
-            }
-#pragma unroll
-            for (int c = 0; c < NR; ++c)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (src[q] >= 0) y[c] += u[c][q];
-        }
-    }
+    for (int c = 0; c < NR; ++c) y[c] = (lane < nc) ? A.b[c * A.ld_b + pi] : 0.0;
+    if (!leaf && lane < f) gather_add<NR, false>(A, G, y);     // (a leaf has no gather lists to look at)
     // column sweep: y_l -= L(l,k) y_k
     for (int k0 = 0; k0 < nc; k0 += 8) {
         double lv[8];
@@ -154,26 +85,37 @@ __device__ __forceinline__ void fwd_wave_body(const SolveArgs& A, int begin, int
 }
 
 template <int NR>
-__device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int count, int bx)
+__device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, const RecSeg& R, int begin, int count, int bx)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int item = bx * (int)(blockDim.x >> 6) + wv;
     if (item >= count) return;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + item];
-    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
+    FrontLoc L;
+    int idx = 0;                   // own columns: the caller's row of the final store; rows below: the ancestor's entry of xp
+    if (const char* rec = rec_of(A, R, 1, item)) {
+        const SolveHdr h = *reinterpret_cast<const SolveHdr*>(rec);
+        idx = rec_idx(rec, lane);
+        L = front_loc(h);
+    } else {
+        const FrontDesc fd = T.desc[begin + item];
+        L = FrontLoc{fd.c0, fd.nc, fd.nb, fd.rp, fd.front_off};
+        // (the store's row is fetched here, beside the other static loads: behind the sweep it was one more memory round
+        //  trip at the end of every wave's life)
+        idx = (lane < L.nc) ? T.perm[L.c0 + lane] : ((lane < L.nc + L.nb) ? T.rows[L.rp + lane - L.nc] : 0);
+    }
+    const int c0 = L.c0, nc = L.nc, nb = L.nb;
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + fd.front_off;
+    const double* __restrict__ F = A.fronts + L.mat;
 
     // lane = row: y_r = D^{-1} x_r for the front's own columns, the ancestors' solution below
     double y[NR];
     {
         const double di = (lane < nc) ? A.Dinv[c0 + lane] : 0.0;
-        const int ri = (lane >= nc && lane < f) ? T.rows[rp + lane - nc] : 0;
 #pragma unroll
         for (int c = 0; c < NR; ++c) y[c] = 0.0;
-        if (lane < f) ldv<NR>(A.xp, lane < nc ? c0 + lane : ri, y);
+        if (lane < f) ldv<NR>(A.xp, lane < nc ? c0 + lane : idx, y);
         if (lane < nc) {
 #pragma unroll
             for (int c = 0; c < NR; ++c) y[c] *= di;
@@ -201,10 +143,9 @@ __device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int
         }
     }
     if (lane < nc) {
-        const int pi = T.perm[c0 + lane];
         stv<NR>(A.xp, c0 + lane, y);
 #pragma unroll
-        for (int c = 0; c < NR; ++c) A.out[c * A.ld_out + pi] = y[c];
+        for (int c = 0; c < NR; ++c) A.out[c * A.ld_out + idx] = y[c];
     }
 }
 
@@ -214,47 +155,35 @@ __device__ __forceinline__ void bwd_wave_body(const SolveArgs& A, int begin, int
 // these kernels are bound by how many waves are in flight: eight fronts share a wave, eight lanes each.
 constexpr int kTinyFront = 8;
 template <int NR>
-__device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int count, int bx, bool leaf = false)
+__device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, const RecSeg& R, int begin, int count, int bx, bool leaf = false)
 {
     const int sub = threadIdx.x & 7;                                 // row inside the front
     const int item = bx * (int)(blockDim.x >> 3) + (threadIdx.x >> 3);
     const bool live = item < count;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
-    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
+    FrontLoc L;
+    int pi = 0;
+    RowGather G;
+    G.cnt = 0;
+    if (const char* rec = rec_of(A, R, 2, live ? item : count - 1)) {
+        const SolveHdr* h = reinterpret_cast<const SolveHdr*>(rec);
+        L = FrontLoc{h->c0, h->nc, h->nb, h->rp, h->mat_off};
+        pi = rec_idx(rec, sub);
+        if (!leaf) G = rec_gather(rec, R.fmax[2], sub);
+    } else {
+        const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
+        L = FrontLoc{fd.c0, fd.nc, fd.nb, fd.rp, fd.front_off};
+        pi = (sub < L.nc) ? T.perm[L.c0 + sub] : 0;
+        if (!leaf && sub < L.nc + L.nb) G = row_gather_lists(T, (int64_t)L.c0 + L.rp + sub);
+    }
+    const int c0 = L.c0, nc = L.nc, nb = L.nb;
+    const int64_t rp = L.rp;
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + fd.front_off;
+    const double* __restrict__ F = A.fronts + L.mat;
     double y[NR];
-    {
-        const int pi = (sub < nc) ? T.perm[c0 + sub] : 0;
 #pragma unroll
-        for (int c = 0; c < NR; ++c) y[c] = (sub < nc) ? A.b[c * A.ld_b + pi] : 0.0;
-    }
-    if (!leaf && sub < f) {
-        const int64_t lc = (int64_t)c0 + rp + sub;
-        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        // four sources per pair of load rounds (indices, then all columns' values); sums in list order
-        for (int64_t g = g0; g < g1; g += 4) {
-            int src[4];
-            double u[NR][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double t[NR];
-#pragma unroll
-                for (int c = 0; c < NR; ++c) t[c] = 0.0;
-                if (src[q] >= 0) ldv<NR>(A.uvec, src[q], t);
-#pragma unroll
-                for (int c = 0; c < NR; ++c) u[c][q] = t[c];
-            }
-#pragma unroll
-            for (int c = 0; c < NR; ++c)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (src[q] >= 0) y[c] += u[c][q];
-        }
-    }
+    for (int c = 0; c < NR; ++c) y[c] = (sub < nc) ? A.b[c * A.ld_b + pi] : 0.0;
+    if (!leaf && sub < f) gather_add<NR, false>(A, G, y);
     double lv[kTinyFront];
 #pragma unroll
     for (int k = 0; k < kTinyFront; ++k) lv[k] = (k < nc && sub > k && sub < f) ? F[sub + k * f] : 0.0;
@@ -272,24 +201,32 @@ __device__ __forceinline__ void fwd_tiny_body(const SolveArgs& A, int begin, int
     }
 }
 template <int NR>
-__device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int count, int bx)
+__device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, const RecSeg& R, int begin, int count, int bx)
 {
     const int sub = threadIdx.x & 7;
     const int item = bx * (int)(blockDim.x >> 3) + (threadIdx.x >> 3);
     const bool live = item < count;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
-    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
+    FrontLoc L;
+    int idx = 0;
+    if (const char* rec = rec_of(A, R, 2, live ? item : count - 1)) {
+        const SolveHdr* h = reinterpret_cast<const SolveHdr*>(rec);
+        L = FrontLoc{h->c0, h->nc, h->nb, h->rp, h->mat_off};
+        idx = rec_idx(rec, sub);
+    } else {
+        const FrontDesc fd = T.desc[begin + (live ? item : count - 1)];
+        L = FrontLoc{fd.c0, fd.nc, fd.nb, fd.rp, fd.front_off};
+        idx = (sub < L.nc) ? T.perm[L.c0 + sub] : ((sub < L.nc + L.nb) ? T.rows[L.rp + sub - L.nc] : 0);
+    }
+    const int c0 = L.c0, nc = L.nc, nb = L.nb;
     const int f = nc + nb;
-    const double* __restrict__ F = A.fronts + fd.front_off;
+    const double* __restrict__ F = A.fronts + L.mat;
     double y[NR];
     {
         const double di = (sub < nc) ? A.Dinv[c0 + sub] : 0.0;
-        const int ri = (sub >= nc && sub < f) ? T.rows[rp + sub - nc] : 0;
 #pragma unroll
         for (int c = 0; c < NR; ++c) y[c] = 0.0;
-        if (sub < f) ldv<NR>(A.xp, sub < nc ? c0 + sub : ri, y);
+        if (sub < f) ldv<NR>(A.xp, sub < nc ? c0 + sub : idx, y);
         if (sub < nc) {
 #pragma unroll
             for (int c = 0; c < NR; ++c) y[c] *= di;
@@ -307,28 +244,27 @@ __device__ __forceinline__ void bwd_tiny_body(const SolveArgs& A, int begin, int
         }
     }
     if (live && sub < nc) {
-        const int pi = T.perm[c0 + sub];
         stv<NR>(A.xp, c0 + sub, y);
 #pragma unroll
-        for (int c = 0; c < NR; ++c) A.out[c * A.ld_out + pi] = y[c];
+        for (int c = 0; c < NR; ++c) A.out[c * A.ld_out + idx] = y[c];
     }
 }
 // A level's one-wave and tiny fronts are independent of each other: one launch for both (the first nwb workgroups
 // take the one-wave fronts [begin, begin + nwave), the others the tiny fronts behind them) saves a launch per sweep
 // leaf: the fronts have no children (tree level 0), so no gather lists are read
 template <int NR>
-__global__ __launch_bounds__(256) void k_fwd_small(SolveArgs A, int begin, int nwave, int ntiny, int leaf)
+__global__ __launch_bounds__(256) void k_fwd_small(SolveArgs A, RecSeg R, int begin, int nwave, int ntiny, int leaf)
 {
     const int nwb = (nwave + 3) >> 2;
-    if ((int)blockIdx.x < nwb) fwd_wave_body<NR>(A, begin, nwave, blockIdx.x, leaf != 0);
-    else fwd_tiny_body<NR>(A, begin + nwave, ntiny, blockIdx.x - nwb, leaf != 0);
+    if ((int)blockIdx.x < nwb) fwd_wave_body<NR>(A, R, begin, nwave, blockIdx.x, leaf != 0);
+    else fwd_tiny_body<NR>(A, R, begin + nwave, ntiny, blockIdx.x - nwb, leaf != 0);
 }
 template <int NR>
-__global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int nwave, int ntiny)
+__global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, RecSeg R, int begin, int nwave, int ntiny)
 {
     const int nwb = (nwave + 3) >> 2;
-    if ((int)blockIdx.x < nwb) bwd_wave_body<NR>(A, begin, nwave, blockIdx.x);
-    else bwd_tiny_body<NR>(A, begin + nwave, ntiny, blockIdx.x - nwb);
+    if ((int)blockIdx.x < nwb) bwd_wave_body<NR>(A, R, begin, nwave, blockIdx.x);
+    else bwd_tiny_body<NR>(A, R, begin + nwave, ntiny, blockIdx.x - nwb);
 }
 
 // ------------------------------------------------------------------ larger fronts, one block each
@@ -343,50 +279,44 @@ __global__ __launch_bounds__(256) void k_bwd_small(SolveArgs A, int begin, int n
 // sums are combined in a fixed order (bit-reproducible).
 // LDS (doubles): forward NR * (1 + nks) * fpad  (y, then the partial sums per column slice),
 //                backward NR * (fpad + nrs * ncpad); column c's share sits behind column c - 1's.
-constexpr int kItemsInFlight = 2;     // matrix items (8 loads per lane each) a wave of the block solve kernels fetches at a time
-// Sum of the n partials p[0], p[stride], p[2 stride], ... in index order (the order fixes the rounding), their LDS loads
-// issued eight at a time: a plain loop compiles to read - wait - add per term, ~70 cycles each, which was a quarter
-// of a hop of the persistent kernel (27 terms per entry in the backward sweep).
-__device__ inline double lds_sum_strided(const double* p, int n, int stride)
-{
-    double v = 0.0;
-    int k = 0;
-    for (; k + 8 <= n; k += 8) {
-        double t[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = p[(k + q) * stride];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v += t[q];
-    }
-    double t[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) t[q] = (k + q < n) ? p[(k + q) * stride] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) if (k + q < n) v += t[q];
-    return v;
-}
 
 template <int BS, int NR>
-__device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, int bx)
+__device__ __forceinline__ void fwd_block_body(const SolveArgs& A, const RecSeg& R, int begin, int bx)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + bx];
-    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
+    // the header and this thread's row slots in ONE round of loads (packed records), or the legacy chain
+    const char* rec = rec_of(A, R, 0, bx);
+    FrontLoc L;
+    int pi = 0;
+    RowGather G;
+    G.cnt = 0;
+    if (rec) {
+        const SolveHdr h = *reinterpret_cast<const SolveHdr*>(rec);
+        if (tid < R.fmax[0]) { pi = rec_idx(rec, tid); G = rec_gather(rec, R.fmax[0], tid); }
+        L = front_loc(h);
+    } else {
+        const FrontDesc fd = T.desc[begin + bx];
+        L = FrontLoc{fd.c0, fd.nc, fd.nb, fd.rp, fd.w_off};
+        if (tid < L.nc + L.nb) {
+            pi = (tid < L.nc) ? T.perm[L.c0 + tid] : 0;
+            G = row_gather_lists(T, (int64_t)L.c0 + L.rp + tid);
+        }
+    }
+    const int c0 = L.c0, nc = L.nc, nb = L.nb;
+    const int64_t rp = L.rp;
     const int f = nc + nb;
-    const double* __restrict__ W = A.tinv + fd.w_off;                  // f x nc, ld f
+    const double* __restrict__ W = A.tinv + L.mat;                     // f x nc, ld f
     const int fpad = (f + 3) & ~3;
     const int nks = (nc + 7) >> 3, nrb = (f + 63) >> 6;
     const int cst = (1 + nks) * fpad;        // LDS doubles per column
     double* y = smem;                        // column c: y at c * cst, its partial sums behind it
     double* part = smem + fpad;
 
-    // The wave's FIRST batch of matrix items is fetched now: it depends on nothing but the descriptor, so its loads fly
-    // during the gather's chain of dependent loads (pointers -> indices -> values) instead of after it.
+    // The wave's FIRST batch of matrix items is fetched with the values of the gather: both depend on the header only.
     constexpr int U = kItemsInFlight;
     double m[U][8];
     auto load_items = [&](int it0) {
@@ -403,33 +333,14 @@ __device__ __forceinline__ void fwd_block_body(const SolveArgs& A, int begin, in
     load_items(wv);
     // gather: right-hand side entry plus the children's contributions to each row, in child order
     for (int i = tid; i < f; i += BS) {
+        if (i != tid) {                       // (fronts taller than the workgroup: the further rows' slots)
+            if (rec) { pi = rec_idx(rec, i); G = rec_gather(rec, R.fmax[0], i); }
+            else { pi = (i < nc) ? T.perm[c0 + i] : 0; G = row_gather_lists(T, (int64_t)c0 + rp + i); }
+        }
         double v[NR];
-        {
-            const int pi = (i < nc) ? T.perm[c0 + i] : 0;
 #pragma unroll
-            for (int c = 0; c < NR; ++c) v[c] = (i < nc) ? A.b[c * A.ld_b + pi] : 0.0;
-        }
-        const int64_t lc = (int64_t)c0 + rp + i;
-        const int64_t g0 = T.gl_ptr[lc], g1 = T.gl_ptr[lc + 1];
-        for (int64_t g = g0; g < g1; g += 8) {
-            int src[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
-            double u[NR][8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double t[NR];
-#pragma unroll
-                for (int c = 0; c < NR; ++c) t[c] = 0.0;
-                if (src[q] >= 0) ldv<NR>(A.uvec, src[q], t);
-#pragma unroll
-                for (int c = 0; c < NR; ++c) u[c][q] = t[c];
-            }
-#pragma unroll
-            for (int c = 0; c < NR; ++c)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (src[q] >= 0) v[c] += u[c][q];
-        }
+        for (int c = 0; c < NR; ++c) v[c] = (i < nc) ? A.b[c * A.ld_b + pi] : 0.0;
+        gather_add<NR, false>(A, G, v);
 #pragma unroll
         for (int c = 0; c < NR; ++c) y[c * cst + i] = v[c];
     }
@@ -511,24 +422,35 @@ __device__ inline void bwd_items(BwdBatch& B, const double* __restrict__ Wt, int
 }
 
 template <int BS, int NR>
-__global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, int begin)
+__global__ __launch_bounds__(BS) void k_fwd_block(SolveArgs A, RecSeg R, int begin)
 {
-    fwd_block_body<BS, NR>(A, begin, blockIdx.x);
+    fwd_block_body<BS, NR>(A, R, begin, blockIdx.x);
 }
 
 template <int BS, int NR>
-__device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, int bx)
+__device__ __forceinline__ void bwd_block_body(const SolveArgs& A, const RecSeg& R, int begin, int bx)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = BS / 64;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + bx];
-    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
+    const char* rec = rec_of(A, R, 0, bx);
+    FrontLoc L;
+    int idx = 0;                  // own columns: the caller's row of the final store; rows below: the ancestor's entry of xp
+    if (rec) {
+        const SolveHdr h = *reinterpret_cast<const SolveHdr*>(rec);
+        if (tid < R.fmax[0]) idx = rec_idx(rec, tid);
+        L = front_loc(h);
+    } else {
+        const FrontDesc fd = T.desc[begin + bx];
+        L = FrontLoc{fd.c0, fd.nc, fd.nb, fd.rp, fd.w_off};
+        if (tid < L.nc + L.nb) idx = (tid < L.nc) ? T.perm[L.c0 + tid] : T.rows[L.rp + tid - L.nc];
+    }
+    const int c0 = L.c0, nc = L.nc, nb = L.nb;
+    const int64_t rp = L.rp;
     const int f = nc + nb;
-    const double* __restrict__ Wt = A.tinv + fd.w_off + (int64_t)f * nc;       // W'(j, r) at j + r*nc
+    const double* __restrict__ Wt = A.tinv + L.mat + (int64_t)f * nc;          // W'(j, r) at j + r*nc
     const int fpad = (f + 3) & ~3, ncpad = (nc + 3) & ~3;
     const int nrs = (f + 7) >> 3;
     const int cst = fpad + nrs * ncpad;
@@ -540,7 +462,8 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
     // z = [D^{-1} y_s ; -x_below]
     for (int i = tid; i < f; i += BS) {
         const double di = (i < nc) ? A.Dinv[c0 + i] : 0.0;
-        const int ri = (i < nc) ? 0 : T.rows[rp + i - nc];
+        int ri = idx;
+        if (i != tid && i >= nc) ri = rec ? rec_idx(rec, i) : T.rows[rp + i - nc];
         double w[NR];
         ldv<NR>(A.xp, i < nc ? c0 + i : ri, w);
 #pragma unroll
@@ -550,7 +473,7 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
     bwd_items<NR>(first, Wt, nc, f, z, part, ncpad, cst, wv, NW, lane);
     __syncthreads();
     for (int j = tid; j < nc; j += BS) {
-        const int pi = T.perm[c0 + j];
+        const int pi = j == tid ? idx : (rec ? rec_idx(rec, j) : T.perm[c0 + j]);
         double w[NR];
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
@@ -562,41 +485,28 @@ __device__ __forceinline__ void bwd_block_body(const SolveArgs& A, int begin, in
     }
 }
 template <int BS, int NR>
-__global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, int begin)
+__global__ __launch_bounds__(BS) void k_bwd_block(SolveArgs A, RecSeg R, int begin)
 {
-    bwd_block_body<BS, NR>(A, begin, blockIdx.x);
+    bwd_block_body<BS, NR>(A, R, begin, blockIdx.x);
 }
 // A level's block-class, one-wave and tiny fronts are independent of each other: one launch for all three
 // -- workgroups [0, nblock) take a block-class front each, the next ones BS/64 one-wave fronts
 // each, the last ones BS/8 tiny fronts each.  Saves a launch (~5 us of pure latency) per sweep and level.
 template <int BS, int NR>
-__global__ __launch_bounds__(BS) void k_fwd_level(SolveArgs A, int begin, int nblock, int nwave, int ntiny)
+__global__ __launch_bounds__(BS) void k_fwd_level(SolveArgs A, RecSeg R, int begin, int nblock, int nwave, int ntiny)
 {
     const int bx = blockIdx.x, nwb = (nwave + BS / 64 - 1) / (BS / 64);
-    if (bx < nblock) fwd_block_body<BS, NR>(A, begin, bx);
-    else if (bx < nblock + nwb) fwd_wave_body<NR>(A, begin + nblock, nwave, bx - nblock);
-    else fwd_tiny_body<NR>(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
+    if (bx < nblock) fwd_block_body<BS, NR>(A, R, begin, bx);
+    else if (bx < nblock + nwb) fwd_wave_body<NR>(A, R, begin + nblock, nwave, bx - nblock);
+    else fwd_tiny_body<NR>(A, R, begin + nblock + nwave, ntiny, bx - nblock - nwb);
 }
 template <int BS, int NR>
-__global__ __launch_bounds__(BS) void k_bwd_level(SolveArgs A, int begin, int nblock, int nwave, int ntiny)
+__global__ __launch_bounds__(BS) void k_bwd_level(SolveArgs A, RecSeg R, int begin, int nblock, int nwave, int ntiny)
 {
     const int bx = blockIdx.x, nwb = (nwave + BS / 64 - 1) / (BS / 64);
-    if (bx < nblock) bwd_block_body<BS, NR>(A, begin, bx);
-    else if (bx < nblock + nwb) bwd_wave_body<NR>(A, begin + nblock, nwave, bx - nblock);
-    else bwd_tiny_body<NR>(A, begin + nblock + nwave, ntiny, bx - nblock - nwb);
-}
-
-struct ItemRegs { double m[8]; };
-// part[ks*ldp + r] = sum_q R.m[q] * v[8 ks + q]  for the item (row block rb, column slice ks)
-__device__ inline void item_apply(const ItemRegs& R, const double* v, int Rn, int Kn, double* part, int ldp, int it,
-                                  int nrb, int lane)
-{
-    const int ks = it / nrb, rb = it - ks * nrb;
-    const int r = rb * 64 + lane, k0 = 8 * ks;
-    double acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc = fma(R.m[q], (k0 + q < Kn) ? v[k0 + q] : 0.0, acc);
-    if (r < Rn) part[ks * ldp + r] = acc;
+    if (bx < nblock) bwd_block_body<BS, NR>(A, R, begin, bx);
+    else if (bx < nblock + nwb) bwd_wave_body<NR>(A, R, begin + nblock, nwave, bx - nblock);
+    else bwd_tiny_body<NR>(A, R, begin + nblock + nwave, ntiny, bx - nblock - nwb);
 }
 
 // ------------------------------------------------------------------ top of the tree, persistent
@@ -610,41 +520,6 @@ __device__ inline void item_apply(const ItemRegs& R, const double* v, int Rn, in
 // relaxed agent-scope loads and reads the payload with agent-scope (L1-bypassing) loads only.
 // Flags carry an epoch (a kernel argument, incremented per call), so nothing is re-zeroed.
 // Every spin is bounded by wall clock; on expiry the abort word is set and everyone leaves.
-typedef __attribute__((address_space(1))) double gdouble;
-typedef __attribute__((address_space(1))) int gint;
-#define LD_AGENT_F64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ST_AGENT_F64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-
-// The tail of a row's gather list, GPB sources per pair of load rounds (indices, then values) instead of two dependent
-// loads per source; sums in list order.
-template <int GPB>
-__device__ inline double gather_rest(const TreeDev& T, const double* uvec, int64_t g, int64_t g1, double v)
-{
-    for (; g < g1; g += GPB) {
-        int src[GPB];
-        double u[GPB];
-#pragma unroll
-        for (int q = 0; q < GPB; ++q) src[q] = (g + q < g1) ? T.gl_src[g + q] : -1;
-#pragma unroll
-        for (int q = 0; q < GPB; ++q) u[q] = src[q] >= 0 ? LD_AGENT_F64(uvec + src[q]) : 0.0;
-#pragma unroll
-        for (int q = 0; q < GPB; ++q) if (src[q] >= 0) v += u[q];
-    }
-    return v;
-}
-
-__device__ inline bool wait_flag(int* flag, int epoch, int* abort_word, long long t0, long long limit)
-{
-    for (;;) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (wall_clock64() - t0 > limit) {
-            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
 
 // Everything that does not depend on other fronts is fetched BEFORE the flag wait and parked in
 // registers: the wave's matrix items (up to PF per sweep), the row's gather-list indices, b, D^{-1},
@@ -824,7 +699,10 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
         __syncthreads();
         TOP_STAMP(0, 5);
-        if (tid == 0) __hip_atomic_store(flag_f + pos, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(flag_f + pos, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (A.chain_cnt) A.chain_cnt[s] = 0;          // (its bottom children were swept by an earlier, chained kernel)
+        }
     }
 
     // ================= backward =================
@@ -853,7 +731,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         }
         int ridx = -1;
         double dinv = 0.0;
-        if (tid < nc) dinv = A.Dinv[c0 + tid];
+        if (tid < nc) { dinv = A.Dinv[c0 + tid]; ridx = T.perm[c0 + tid]; }     // (own columns: the caller's row of the final store)
         else if (tid < f) ridx = T.rows[rp + tid - nc];
         if (tid == 0) sh_ok = 1;
         __syncthreads();
@@ -935,7 +813,7 @@ __global__ __launch_bounds__(BS, BS == 1024 ? 4 : 2) void k_top_solve(SolveArgs 
         __syncthreads();
         TOP_STAMP(1, 4);
         for (int j = tid; j < nc; j += BS) {
-            const int pi = T.perm[c0 + j];
+            const int pi = j == tid ? ridx : T.perm[c0 + j];       // (fetched before the wait: it sat on every hop's path)
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
                 const double v = lds_sum_strided(part + c * cst + j, nrs, ncpad);
@@ -1171,8 +1049,10 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains
             __syncthreads();
             SL_STAMP(0, 5);
-            if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
+            if (tid == 0) {
+                __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (A.chain_cnt) A.chain_cnt[s] = 0;
+            }
             continue;
         }
         const FrontDesc fd = T.desc[begin + pos];
@@ -1367,7 +1247,10 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         SL_STAMP(0, 5);
-            if (tid == 0) __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(flag_f + tk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (A.chain_cnt && sl == 0) A.chain_cnt[s] = 0;
+        }
     }
 
     // ================= backward =================
@@ -1908,58 +1791,54 @@ size_t solve_lds_bytes(int fmax, int ncmax)
     return (fwd > bwd ? fwd : bwd) * sizeof(double);
 }
 
-void launch_fwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr)
+void launch_fwd(const SolveArgs& a, const RecSeg& rs, int begin, int count, int bs, size_t lds, hipStream_t st, int nr)
 {
     if (count <= 0) return;
-    if (bs == 8) { launch_fwd_small(a, begin, 0, count, st, false, nr); return; }
-    if (bs == 64) { launch_fwd_small(a, begin, count, 0, st, false, nr); return; }
     init_solve_lds();
     // bs = 128: a wide level of small fronts -- more fronts in flight per CU matter more than waves per front
-    if (bs == 128) HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_block<128, NR>), dim3(count), dim3(128), lds * NR, st, a, begin));
-    else HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_block<kSolveBS, NR>), dim3(count), dim3(kSolveBS), lds * NR, st, a, begin));
+    if (bs == 128) HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_block<128, NR>), dim3(count), dim3(128), lds * NR, st, a, rs, begin));
+    else HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_block<kSolveBS, NR>), dim3(count), dim3(kSolveBS), lds * NR, st, a, rs, begin));
 }
-void launch_fwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr)
+void launch_fwd_level(const SolveArgs& a, const RecSeg& rs, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr)
 {
     init_solve_lds();
     if (bs == 128) {
         const int grid = nblock + (nwave + 1) / 2 + (ntiny + 15) / 16;
-        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_level<128, NR>), dim3(grid), dim3(128), lds * NR, st, a, begin, nblock, nwave, ntiny));
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_level<128, NR>), dim3(grid), dim3(128), lds * NR, st, a, rs, begin, nblock, nwave, ntiny));
     } else {
         const int grid = nblock + (nwave + kSolveBS / 64 - 1) / (kSolveBS / 64) + (ntiny + kSolveBS / 8 - 1) / (kSolveBS / 8);
-        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_level<kSolveBS, NR>), dim3(grid), dim3(kSolveBS), lds * NR, st, a, begin, nblock, nwave, ntiny));
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_level<kSolveBS, NR>), dim3(grid), dim3(kSolveBS), lds * NR, st, a, rs, begin, nblock, nwave, ntiny));
     }
 }
-void launch_bwd_level(const SolveArgs& a, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr)
+void launch_bwd_level(const SolveArgs& a, const RecSeg& rs, int begin, int nblock, int nwave, int ntiny, int bs, size_t lds, hipStream_t st, int nr)
 {
     init_solve_lds();
     if (bs == 128) {
         const int grid = nblock + (nwave + 1) / 2 + (ntiny + 15) / 16;
-        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_level<128, NR>), dim3(grid), dim3(128), lds * NR, st, a, begin, nblock, nwave, ntiny));
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_level<128, NR>), dim3(grid), dim3(128), lds * NR, st, a, rs, begin, nblock, nwave, ntiny));
     } else {
         const int grid = nblock + (nwave + kSolveBS / 64 - 1) / (kSolveBS / 64) + (ntiny + kSolveBS / 8 - 1) / (kSolveBS / 8);
-        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_level<kSolveBS, NR>), dim3(grid), dim3(kSolveBS), lds * NR, st, a, begin, nblock, nwave, ntiny));
+        HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_level<kSolveBS, NR>), dim3(grid), dim3(kSolveBS), lds * NR, st, a, rs, begin, nblock, nwave, ntiny));
     }
 }
-void launch_fwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, bool leaf, int nr)
+void launch_fwd_small(const SolveArgs& a, const RecSeg& rs, int begin, int nwave, int ntiny, hipStream_t st, bool leaf, int nr)
 {
     if (nwave + ntiny <= 0) return;
     const int grid = (nwave + 3) / 4 + (ntiny + 31) / 32;
-    HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_small<NR>), dim3(grid), dim3(256), 0, st, a, begin, nwave, ntiny, leaf ? 1 : 0));
+    HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_fwd_small<NR>), dim3(grid), dim3(256), 0, st, a, rs, begin, nwave, ntiny, leaf ? 1 : 0));
 }
-void launch_bwd_small(const SolveArgs& a, int begin, int nwave, int ntiny, hipStream_t st, int nr)
+void launch_bwd_small(const SolveArgs& a, const RecSeg& rs, int begin, int nwave, int ntiny, hipStream_t st, int nr)
 {
     if (nwave + ntiny <= 0) return;
     const int grid = (nwave + 3) / 4 + (ntiny + 31) / 32;
-    HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_small<NR>), dim3(grid), dim3(256), 0, st, a, begin, nwave, ntiny));
+    HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_small<NR>), dim3(grid), dim3(256), 0, st, a, rs, begin, nwave, ntiny));
 }
-void launch_bwd(const SolveArgs& a, int begin, int count, int bs, size_t lds, hipStream_t st, int nr)
+void launch_bwd(const SolveArgs& a, const RecSeg& rs, int begin, int count, int bs, size_t lds, hipStream_t st, int nr)
 {
     if (count <= 0) return;
-    if (bs == 8) { launch_bwd_small(a, begin, 0, count, st, nr); return; }
-    if (bs == 64) { launch_bwd_small(a, begin, count, 0, st, nr); return; }
     init_solve_lds();
-    if (bs == 128) HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_block<128, NR>), dim3(count), dim3(128), lds * NR, st, a, begin));
-    else HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_block<kSolveBS, NR>), dim3(count), dim3(kSolveBS), lds * NR, st, a, begin));
+    if (bs == 128) HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_block<128, NR>), dim3(count), dim3(128), lds * NR, st, a, rs, begin));
+    else HIPKKT_NR_SWITCH(nr, hipLaunchKernelGGL((k_bwd_block<kSolveBS, NR>), dim3(count), dim3(kSolveBS), lds * NR, st, a, rs, begin));
 }
 // ------------------------------------------------------------------ several right-hand sides
 // The single-column kernels above are latency-bound; with many columns the cost is fetching the
