@@ -374,6 +374,8 @@ def main():
                     help="e.g. 1,2,3,4,4b,5 (and 2lr, cfg2 with long-range couplings): time every listed configuration on one GPU (one JSON line each) "
                          "instead of the headline run")
     ap.add_argument("--cfg-cpu-units", type=int, default=2, help="--configs: timed oracle units per configuration")
+    ap.add_argument("--no-scale-modes", action="store_true",
+                    help="iter mode: skip the short `problems` and `rhs` passes whose rows go into scale_modes")
     ap.add_argument("--sequential-handles", action="store_true",
                     help="--mode problems: drive the handles one after the other (rounds 1-3's figure) instead of concurrently")
     ap.add_argument("--concurrent", action="store_true",
@@ -384,11 +386,9 @@ def main():
         return run_configs(args)
     if args.mode == "problems" and not args.sequential_handles:
         args.concurrent = True
-    if args.concurrent and args.mode == "problems":
-        # Handles that share the device must not wait for their own kernels inside kernels: the factorisation's overlap mode
-        # assumes that everything else on the GPU ends by itself, which another handle's waiting panel workgroups do not
-        # (seen: every handle gave up once, 50 ms each, and fell back).  Level by level from the start.
-        os.environ.setdefault("HIPKKT_FACTOR_OVERLAP", "0")
+    # (Concurrent handles need no setting: the library admits one overlapped factorisation per device at a time -- a handle
+    #  that finds the device's claim busy factorises level by level that time -- and a handle without the persistent sweep
+    #  kernel's claim takes the chained sweep kernels.  Until round 3 this line set HIPKKT_FACTOR_OVERLAP=0.)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_workers(args.gpus, sys.argv[1:]))
 
@@ -425,12 +425,12 @@ def main():
         if not dry:
             torch.cuda.synchronize(dev)
 
-    def timed(step):
-        for _ in range(args.warmup):
+    def timed(step, steps=None, warmup=None):
+        for _ in range(args.warmup if warmup is None else warmup):
             step()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps if steps is None else steps):
             step()
         barrier()
         return reduce_max(time.perf_counter() - t0, device=dev)      # MAX over ranks (RCCL, 8 bytes)
@@ -528,8 +528,10 @@ def main():
         base["dry_run"] = True
 
     # ------------------------------------------------------------------ mode problems (cfg4)
-    if args.mode == "problems":
-        n = args.n or 10_000
+    def run_problems(steps, warmup):
+        """the batch of independent SOCPs dealt to the ranks.  Returns rank 0's result row."""
+        n = (args.n if args.mode == "problems" else None) or 10_000
+        concurrent = args.concurrent or (args.mode != "problems" and not args.sequential_handles)
         mine = assign_problems(args.problems, world, rank)            # independent problems: no data-path collective
         if args.per_handle is None:
             args.per_handle = max(8, -(-len(mine) // 3))
@@ -542,13 +544,13 @@ def main():
                 # --concurrent: every handle on a stream and a host thread of its own -- a handle's step is a chain of
                 # narrow, latency-bound launches that leaves most of the device idle; several chains side by side fill it.
                 # (One handle at a time may use the persistent sweep kernel on a device; the others sweep level by level.)
-                stream = torch.cuda.Stream(device=dev) if args.concurrent else None
+                stream = torch.cuda.Stream(device=dev) if concurrent else None
                 ks, system, st = make_system(pb, rng, stream=stream)
                 st["keep_stream"] = stream
                 handles.append((ks, st, g, system))
 
         pool = None
-        if args.concurrent and not dry and len(handles) > 1:
+        if concurrent and not dry and len(handles) > 1:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=len(handles))
             torch.cuda.synchronize(dev)
@@ -562,7 +564,7 @@ def main():
             for ks, st, _, system in handles:
                 unit_c(system, st)
 
-        elapsed = timed(step)
+        elapsed = timed(step, steps, warmup)
         # per-problem records [index, status, refinement rounds of the last solve, N of its handle]: the one exchange
         recs = []
         for gi, g in enumerate(groups):
@@ -570,27 +572,31 @@ def main():
                 recs.append([j, 1.0, float(handles[gi][0].last_ir_iterations) if handles else 0.0,
                              float(handles[gi][0].info["N"]) if handles else 0.0])
         table = gather_records(recs, args.problems, 4, device=dev)
+        fb_sum = [sum(h[0].fallbacks[i] for h in handles) for i in (0, 1)]
+        deferrals = sum(int(h[0].profile()["overlap_deferrals"]) for h in handles)
+        if pool is not None:
+            pool.shutdown()
+        handles.clear()                 # (the handles' device memory goes back before the next pass)
         if rank == 0:
             assert bool((table[:, 1] == 1.0).all()), "a problem is missing from the gathered records"
             out = dict(base, metric="KKT factorize+solve/sec (fp64) per IPM iter, batch of %d independent SOCPs n=%d" % (args.problems, n),
-                       value=args.problems * args.steps / elapsed, unit="KKT factorize+solve/s",
-                       ms_per_step=elapsed / args.steps * 1e3, scaling="strong",
+                       value=args.problems * steps / elapsed, unit="KKT factorize+solve/s",
+                       ms_per_step=elapsed / steps * 1e3, scaling="strong", steps=steps, warmup=warmup,
                        config={"workload": "cfg4: %d independent SOCPs n=%d m=%d NN(%d)+%dxSOC(100), dealt round-robin to the ranks, "
                                            "%d per block-diagonal handle; per problem 1 update + 1 LDL' refactor + 3 solves with IR per step"
                                            % (args.problems, n, 2 * n, n, n // 100, args.per_handle),
                                "calls": "kkt_update! / kkt_solve!(:affine) / kkt_solve!(:combined) as three separate level-C calls, lazy constant-RHS solve",
-                               "fallbacks": [sum(h[0].fallbacks[i] for h in handles) for i in (0, 1)],
+                               "fallbacks": fb_sum, "overlap_deferrals": deferrals,
                                "problems_per_rank": len(mine), "handles_per_rank": len(groups),
                                "handles_driven": "concurrently, a stream and a host thread each" if pool is not None else "one after the other",
                                "parallelism": "independent problems per GPU, record all-gather over RCCL"})
-            print(json.dumps(out), flush=True)
-        if world > 1:
-            dist.destroy_process_group()
-        return
+            return out
+        return None
 
     # ------------------------------------------------------------------ mode rhs (batched right-hand sides, cfg2's factor)
-    if args.mode == "rhs":
-        n = args.n or 100_000
+    def run_rhs(steps, warmup):
+        """the columns of one factor dealt to the ranks.  Returns rank 0's result row."""
+        n = (args.n if args.mode == "rhs" else None) or 100_000
         k = args.nrhs
         mine = shard_columns(k, world, rank)
         km = len(mine)
@@ -632,10 +638,10 @@ def main():
             if world > 1:
                 gather.finish()
 
-        elapsed = timed(step)
+        elapsed = timed(step, steps, warmup)
         if rank == 0:
             out = dict(base, metric="KKT solves/sec (fp64, with refinement) against one factorisation, %d right-hand sides" % k,
-                       value=k * args.steps / elapsed, unit="KKT solves/s", ms_per_step=elapsed / args.steps * 1e3,
+                       value=k * steps / elapsed, unit="KKT solves/s", ms_per_step=elapsed / steps * 1e3, steps=steps, warmup=warmup,
                        scaling="strong",
                        config={"workload": "cfg2's factor (n=%d) replicated per rank; %d right-hand sides dealt round-robin, "
                                            "hipkkt_kkt_solve_multi_dev on each share, solutions all-gathered" % (n, k),
@@ -644,13 +650,19 @@ def main():
                                               "columns, block i's exchange overlapping block i + 1's solves"})
             if not dry:
                 info = ks.info
-                sweeps = 1.0 + rounds[0] / max(km * (args.steps + args.warmup), 1)
+                sweeps = 1.0 + rounds[0] / max(km * (steps + warmup), 1)
                 B = 2 * info["nnzL"] * 12 + km * 6 * info["N"] * 8         # B_solve(k)
-                gbs = B * sweeps / (elapsed / args.steps) / 1e9
+                gbs = B * sweeps / (elapsed / steps) / 1e9
                 out["roofline"] = dict(kernel="multi-column tri-solve", bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                                        frac=gbs / HBM_PEAK_GBS, traffic=None,
                                        note="B_solve(k) = 2 nnz(L) 12 + k 6 N 8 per sweep pair, k = %d columns on this rank, "
                                             "%.2f sweep pairs per column incl. refinement; whole call timed" % (km, sweeps))
+            return out
+        return None
+
+    if args.mode in ("problems", "rhs"):
+        out = run_problems(args.steps, args.warmup) if args.mode == "problems" else run_rhs(args.steps, args.warmup)
+        if rank == 0:
             print(json.dumps(out), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -658,13 +670,30 @@ def main():
 
     # ------------------------------------------------------------------ mode iter (the headline)
     n = args.n or 100_000
+    def scale_modes():
+        """The two sharded axes of SURVEY.md 8(e) in the SAME ranks, behind the headline pass: (i) the batch of independent
+        SOCPs (cfg4) dealt to the ranks, (ii) 512 right-hand sides against cfg2's factor dealt to the ranks with the
+        blocked (x, z) exchange -- so that the one command the driver runs at N = 1, 2, 4, 8 measures both (the headline
+        pass itself is one independent cfg2 per rank: linear by construction).  Short passes; --no-scale-modes skips them."""
+        if args.no_scale_modes:
+            return None
+        sm = {}
+        row = run_problems(max(3, min(args.steps, 8)), 2)
+        if row is not None:
+            sm["problems"] = {k: row[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config")}
+        row = run_rhs(max(2, min(args.steps, 4)), 1)
+        if row is not None:
+            sm["rhs"] = {k: row[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config", "roofline") if k in row}
+        return sm if rank == 0 else None
+
     if dry:
         elapsed = timed(lambda: None)
+        sm = scale_modes()
         if rank == 0:
             print(json.dumps(dict(base, metric="KKT factorize+solve/sec (fp64) per IPM iter, 100k-var SOCP",
                                   value=world * args.steps / max(elapsed, 1e-9), unit="KKT factorize+solve/s",
                                   ms_per_step=elapsed / args.steps * 1e3, scaling="weak",
-                                  config={"workload": "dry run (no GPU work)"})), flush=True)
+                                  config={"workload": "dry run (no GPU work)"}, scale_modes=sm)), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -730,7 +759,41 @@ def main():
         barrier()
         level_b[name] = (time.perf_counter() - t0) / args.steps * 1e3
     ks.set_deferred_status(False)
+    # ---- the drop-in figure: the same three level-C calls with HOST vectors, as integration/HipKKTExt.jl issues them for
+    #      the reference's DefaultVariables (kktsystem.jl:135-143 takes host vectors): kkt_update! from the cones' scaling
+    #      (w, eta, lambda: the Hs blocks and the sparse cones' u / v are formed on the device), the two kkt_solve! through
+    #      the *_host entry points (the combined one re-using the affine one's variables), every array page-locked once
+    #      as the glue does at construction.  PCIe-inclusive: never `value`.
+    host_ms = {}
+    if not args.sequential_solves:
+        system.set_lazy(True)
+        lam_h, psd_h = ks.scaling()
+        w_h, eta_h = ks.scaling_w()
+        hs_full = ks.get_Hs()
+        rngh = np.random.default_rng(5)
+        hv = dict(var=[rngh.standard_normal(pb.n), pb.s0.copy(), pb.z0.copy()],
+                  rhs=[[rngh.standard_normal(k) for k in (pb.n, pb.m, pb.m)] for _ in range(2)],
+                  lhs=[np.zeros(k) for k in (pb.n, pb.m, pb.m)],
+                  scal=[np.ascontiguousarray(w_h), np.ascontiguousarray(eta_h), np.ascontiguousarray(lam_h), np.zeros(0), np.zeros(0)])
+        pinned = [a for a in hv["var"] + hv["rhs"][0] + hv["rhs"][1] + hv["lhs"] + hv["scal"][:3] if a.size]
+        n_pinned = sum(1 for a in pinned if _lib.host_register(a))
+        calls_h = system.prepared_host(hv["lhs"], hv["rhs"], 0.3, -0.1, hv["var"], stc["tau"], stc["kappa"], hv["scal"])
+        for tag, calls in (("lazy_reduced_upload_pinned", calls_h),):
+            st_h = dict(calls=calls)
+            unit_c(system, st_h)
+            unit_c(system, st_h)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                unit_c(system, st_h)
+            barrier()
+            host_ms[tag] = (time.perf_counter() - t0) / args.steps * 1e3
+        for a in pinned:
+            _lib.host_unregister(a)
+        host_ms["arrays_page_locked"] = n_pinned
+        del hs_full
     fb2 = ks.fallbacks
+    sm = scale_modes()
 
     if rank == 0:
         info = ks.info
@@ -819,9 +882,17 @@ def main():
                        "kkt_update! solving the constant right-hand side itself (three single-column solves)"),
             "fallbacks": {"overlap": fb2[0], "top": fb2[1], "in_timed_region": 0},
             # value updates (= factorisations) this process has run, for per-launch averages of profiler counters
-            "updates_in_run": args.warmup + 3 * args.steps + 1 + (0 if args.sequential_solves else 2 * (args.steps + 1)),
+            "updates_in_run": args.warmup + 3 * args.steps + 1 + (0 if args.sequential_solves else 2 * (args.steps + 1) + args.steps + 2),
             # rounds 1-2 quoted this: level B alone (no right-hand-side construction / step recovery), deferred status
             "level_B_ms_per_step": level_b,
+            # The figure a caller with HOST vectors gets (the Julia glue: DefaultVariables are Vector{T}) -- the same three
+            # lazy level-C calls through the *_host entry points, PCIe included; `value` / `ms_per_step` are the resident ones.
+            "ms_per_step_host_vectors": host_ms.get("lazy_reduced_upload_pinned"),
+            "host_vectors": dict(host_ms, calls="hipkkt_kkt_system_update_scaling (w, eta, lambda up; Hs, u, v formed on the device), "
+                                                "hipkkt_kkt_system_solve_host x 2 (combined step re-uses the affine step's variables), "
+                                                "arrays page-locked once (hipkkt_host_register)") if host_ms else None,
+            # SURVEY.md 8(e)'s two sharded axes, measured in the same ranks behind the headline pass (None: --no-scale-modes)
+            "scale_modes": sm,
             "ms_per_step_instrumented": elapsed_profiled / args.steps * 1e3,
             "ms_per_step_outside_phases": elapsed_profiled / args.steps * 1e3 - phase_sum,
         })

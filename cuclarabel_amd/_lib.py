@@ -54,7 +54,7 @@ class Profile(C.Structure):
                 ("n_update", C.c_int64), ("n_factor", C.c_int64), ("n_trisolve", C.c_int64),
                 ("n_residual", C.c_int64), ("ir_iterations", C.c_int64),
                 ("dynamic_regularizations", C.c_int64),
-                ("overlap_fallbacks", C.c_int64), ("top_fallbacks", C.c_int64)]
+                ("overlap_fallbacks", C.c_int64), ("top_fallbacks", C.c_int64), ("overlap_deferrals", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -106,6 +106,9 @@ SYMBOLS = {
                                                             _P, _P, _P, C.c_double, C.c_double]),
     "hipkkt_kkt_system_set_lazy": (C.c_int, [_P, C.c_int]),
     "hipkkt_kkt_system_update_cones": (C.c_int, [_P] * 10),
+    "hipkkt_kkt_system_update_scaling": (C.c_int, [_P] * 6),
+    "hipkkt_host_register": (C.c_int, [_P, C.c_int64]),
+    "hipkkt_host_unregister": (C.c_int, [_P]),
     "hipkkt_kkt_system_update_host": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_system_solve_initial_point_host": (C.c_int, [_P, _P, _P, _P]),
     "hipkkt_kkt_system_solve_host": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
@@ -205,3 +208,13 @@ def symbolic_analyse(K_triu, ordering=ORDER_ND, nd_leaf_size=0):
     check(lib().hipkkt_symbolic_analyse(N, ptr(cp), ptr(ri), 0, ordering, nd_leaf_size, ptr(perm), C.byref(info)),
           "hipkkt_symbolic_analyse")
     return perm, info.as_dict()
+
+
+def host_register(a):
+    """Page-lock a numpy array the caller keeps (hipkkt_host_register): the *_host entry points then copy at the link's
+    rate.  Returns True if the range could be registered."""
+    return lib().hipkkt_host_register(ptr(a), int(a.nbytes)) == 0
+
+
+def host_unregister(a):
+    return lib().hipkkt_host_unregister(ptr(a)) == 0

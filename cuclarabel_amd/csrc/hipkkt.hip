@@ -95,6 +95,20 @@ struct TopOwner { hipStream_t stream = nullptr; int refs = 0; };
 static std::mutex g_top_mu;
 static std::map<int, TopOwner> g_top_owner;
 
+// The factorisation's overlap mode has the same kind of requirement: its forward-progress argument (gate + admission
+// rule, enqueue_factor) assumes that every other kernel on the device ends by itself, which another handle's waiting
+// panel workgroups do not -- two handles' resident, waiting panel workgroups can together hold every CU.  So per device
+// ONE overlapped factorisation is in flight at a time: a handle takes the device's claim for the duration of a
+// factorisation (it may be taken over once the holder's last overlapped factorisation has left both its streams);
+// a handle that finds the claim busy factorises level by level THAT time -- it is not switched out of the mode.
+struct OvOwner {
+    const void* eng = nullptr;
+    bool enqueuing = false;                      // the holder is between taking the claim and recording the two events
+    hipEvent_t done_main = nullptr, done_tiles = nullptr;
+};
+static std::mutex g_ov_mu;
+static std::map<int, OvOwner> g_ov_owner;
+
 // ------------------------------------------------------------------------------------
 //  The numeric engine shared by both API levels
 // ------------------------------------------------------------------------------------
@@ -319,7 +333,9 @@ public:
         if (ev_side) (void)hipEventDestroy(ev_side);
         if (ov_stream) (void)hipStreamDestroy(ov_stream);
         if (ev_ov_fork) (void)hipEventDestroy(ev_ov_fork);
+        release_ov();
         if (ev_ov_join) (void)hipEventDestroy(ev_ov_join);
+        if (ev_ov_done) (void)hipEventDestroy(ev_ov_done);
     }
 
 private:
@@ -411,6 +427,7 @@ private:
             } else if (!had) {
                 HIP_CHECK(hipEventCreateWithFlags(&ev_ov_fork, hipEventDisableTiming));
                 HIP_CHECK(hipEventCreateWithFlags(&ev_ov_join, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&ev_ov_done, hipEventDisableTiming));
             }
             if (ov_stream && !ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
                 std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
@@ -449,7 +466,11 @@ private:
         const bool use_ov = want_ov && !side && !want_stamps && !ov_disabled && ov_first < launches.size();
         // the side streams (W formation, Schur tiles) are chosen once per main stream, each probed to run BESIDE it
         if (!side && !want_stamps) choose_side_streams(st, use_ov);
-        const bool ov_on = use_ov && !ov_disabled && ov_stream != nullptr;
+        const bool ov_on = use_ov && !ov_disabled && ov_stream != nullptr && claim_ov();
+        struct OvRelease {                       // (the claim's "enqueuing" mark ends with this call, however it ends)
+            LDLEngine* e; bool on;
+            ~OvRelease() { if (on) e->ov_enqueued(false); }
+        } ov_release{this, ov_on};
         // The merged panel kernels of the narrow top (below) wait for tile kernels that are submitted BEHIND them: that
         // needs the two streams on different hardware queues (ov_concurrent: choose_side_streams' probe; seen without it,
         // eight handles in one process: two of them waited for their 50 ms bound).  Without concurrency every level keeps
@@ -631,6 +652,11 @@ private:
         } else {
             // one launch over every supernode, after the tree (all of them independent)
             form_w(d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st, 0);
+        }
+        if (ov_on) {
+            HIP_CHECK(hipEventRecord(ev_ov_done, st));       // (with ev_ov_join: this factorisation has left both streams)
+            ov_release.on = false;
+            ov_enqueued(true);
         }
         HIP_CHECK(hipGetLastError());
         if (want_stamps) {
@@ -972,6 +998,39 @@ private:
     std::vector<int> h_nch;
     DBuf<int64_t> d_recs;        // packed sweep records (kernels.hpp: SolveHdr); empty: the legacy layout
 
+    // ---- the device's overlap-mode claim (OvOwner)
+    bool claim_ov()
+    {
+        std::lock_guard<std::mutex> lk(g_ov_mu);
+        OvOwner& o = g_ov_owner[device_id];
+        if (o.eng != this) {
+            if (o.eng != nullptr) {
+                // another handle holds it: free once its last overlapped factorisation has left its two streams
+                if (o.enqueuing) return false;
+                const bool idle = hipEventQuery(o.done_main) == hipSuccess && hipEventQuery(o.done_tiles) == hipSuccess;
+                (void)hipGetLastError();
+                if (!idle) { ++n_ov_busy; return false; }
+            }
+            o.eng = this;
+            o.done_main = ev_ov_done;
+            o.done_tiles = ev_ov_join;
+        }
+        o.enqueuing = true;
+        return true;
+    }
+    void ov_enqueued(bool)       // the events that mark this factorisation's end are recorded (or the call was abandoned)
+    {
+        std::lock_guard<std::mutex> lk(g_ov_mu);
+        OvOwner& o = g_ov_owner[device_id];
+        if (o.eng == this) o.enqueuing = false;
+    }
+    void release_ov()
+    {
+        std::lock_guard<std::mutex> lk(g_ov_mu);
+        auto it = g_ov_owner.find(device_id);
+        if (it != g_ov_owner.end() && it->second.eng == this) it->second = OvOwner{};
+    }
+
     // ---- persistent-kernel bookkeeping
     bool top_claimed = false, top_disabled = false;
     hipStream_t claimed_stream = nullptr;
@@ -1004,6 +1063,7 @@ public:
     const int* top_abort_word() const { return (top_flags.p && (top_launches > 0 || chain_from < launches.size())) ? top_flags.p + 2 * top_nflag : nullptr; }
     // The caller has synchronised and found the abort word set: clear it and never use the kernel again.
     int64_t n_ov_fallbacks = 0, n_top_fallbacks = 0;      // lifetime counts (hipkkt_profile, hipkkt_ldl_fallbacks)
+    int64_t n_ov_busy = 0;       // factorisations that went level by level because another handle held the device's overlap claim
     void top_gave_up()
     {
         top_disabled = true;
@@ -1039,7 +1099,10 @@ public:
     {
         ov_disabled = true;
         ++n_ov_fallbacks;
+        release_ov();
         if (std::getenv("HIPKKT_VERBOSE")) {            // which wait expired first (factor_kernels.hip, ov_wait_ge)
+            // (the diagnostic words are plain stores behind the abort's CAS: let the tile stream drain first)
+            if (ov_stream) (void)hipStreamSynchronize(ov_stream);
             int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipMemcpy(w, flags.p, sizeof(w), hipMemcpyDeviceToHost);
             const int sn = w[4];
@@ -1158,7 +1221,7 @@ private:
     bool ov_concurrent = false;          // the main and the tile stream run side by side (choose_side_streams)
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
-    hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr;
+    hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr, ev_ov_done = nullptr;
     bool ov_join_pending = false;    // ev_ov_join recorded, not yet waited for (enqueue_factor)
     size_t nr_cap = 1;           // right-hand sides xp / uvec are sized for
     int top_grid_nr[2] = {-1, -1};   // the persistent kernel's grid for 2 / 4 right-hand sides (asked on first use)
@@ -1572,8 +1635,9 @@ private:
                 side_winv_blocks = kSideWinvBlocksEnv > 0 ? kSideWinvBlocksEnv : std::max(8, n_cus * 3 / 8);
             }
             constexpr int kOvMargin = 8;
-            static const int ov_max_env = std::getenv("HIPKKT_OV_MAX_FRONTS") ? std::atoi(std::getenv("HIPKKT_OV_MAX_FRONTS")) : 120 * n_cus / 256;
-            const int ov_max = std::min(ov_max_env, n_cus - 1 - kOvMargin);
+            // (the environment override is per process, the default per handle: n_cus is this handle's device's)
+            static const int ov_max_env = std::getenv("HIPKKT_OV_MAX_FRONTS") ? std::atoi(std::getenv("HIPKKT_OV_MAX_FRONTS")) : 0;
+            const int ov_max = std::min(ov_max_env > 0 ? ov_max_env : 120 * n_cus / 256, n_cus - 1 - kOvMargin);
             auto panel_wgs = [&](const Launch& L) { return L.count - L.nsliced + L.slice_count; };   // whole panels + row slices
             size_t first = launches.size();
             while (first > 0) {
@@ -2343,12 +2407,26 @@ struct hipkkt_kkt_s {
     bool sys_const_pending = false;  // ... and that solve is still due
     bool sys_update_unread = false;  // lazy mode: the last kkt_update!'s status sits in the sticky record, read with the next solve's
     DBuf<double> hst;                // staging of the *_host entry points of level C: 3 x (n + 2 m) doubles (rhs, variables, lhs)
+    bool host_vars_valid = false;    // hst holds the variables of the previous hipkkt_kkt_system_solve_host call
+    // "the caller's host arrays may be reused": an event behind the uploads, waited for at the end of the call -- the
+    // kernels enqueued in between keep the device busy meanwhile (a stream synchronise would wait for them as well)
+    hipEvent_t ev_upload = nullptr;
+    void host_upload_mark(hipStream_t st)
+    {
+        if (!ev_upload) HIP_CHECK(hipEventCreateWithFlags(&ev_upload, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev_upload, st));
+    }
+    void host_upload_wait() { if (ev_upload) HIP_CHECK(hipEventSynchronize(ev_upload)); }
     // solve_multi work space, N x mcap each (grown on demand)
     DBuf<double> mB, mX, mC, mE, mE2, mpartial, mnorms;
     DBuf<int> mmask;
     size_t mcap = 0;
     Profiler prof;
-    ~hipkkt_kkt_s() { if (stream && own_stream) (void)hipStreamDestroy(stream); }
+    ~hipkkt_kkt_s()
+    {
+        if (ev_upload) (void)hipEventDestroy(ev_upload);
+        if (stream && own_stream) (void)hipStreamDestroy(stream);
+    }
 
     ConeDev cone_dev() const
     {
@@ -3214,11 +3292,17 @@ int hipkkt_kkt_set_deferred_status(hipkkt_kkt_t h, int defer)
 
 // what the sticky record {bad, more, abort, rounds, #dyn. regularisations, eps, solves, overlap gave up} read back into
 // pinned memory says about everything enqueued since the last query: OK / NUMERIC_FAILURE / REFINEMENT_INCOMPLETE
-static int kkt_eval_sticky(hipkkt_kkt_t h, const double* s)
+// gave_up_out (nullable): a bounded wait expired -- the factor (or the solution) is void, as opposed to "a solve would
+// have refined further".  will_repeat: the caller repeats the whole attempt synchronously whenever this returns
+// HIPKKT_REFINEMENT_INCOMPLETE, so that attempt's counts stay out of the profile (the repeat adds its own).
+static int kkt_eval_sticky(hipkkt_kkt_t h, const double* s, bool* gave_up_out = nullptr, bool will_repeat = false)
 {
         const int max_iter = std::max(h->st.iterative_refinement_max_iter, 0);
-        h->prof.acc.ir_iterations += (int64_t)s[3];
-        h->prof.acc.dynamic_regularizations += (int64_t)s[4];
+        const bool void_step = s[7] != 0.0 || (s[2] != 0.0 && h->eng->top_abort_word() != nullptr);
+        const bool repeat = will_repeat && (void_step || (s[0] == 0.0 && s[1] != 0.0));
+        if (gave_up_out) *gave_up_out = false;
+        if (!repeat) h->prof.acc.ir_iterations += (int64_t)s[3];
+        if (!(will_repeat && void_step)) h->prof.acc.dynamic_regularizations += (int64_t)s[4];   // (a void factorisation is repeated too)
         if (s[5] != 0.0 || !h->st.static_regularization_enable) h->last_eps = h->st.static_regularization_enable ? s[5] : 0.0;
         if (s[6] > 0.0) h->last_ir = (int64_t)(s[3] / s[6] + 0.5);      // mean rounds per solve since the last query
         // The give-up words come first (as on the synchronous paths: kkt_update_device, kkt_solve_core): after a bounded
@@ -3227,6 +3311,7 @@ static int kkt_eval_sticky(hipkkt_kkt_t h, const double* s)
         bool gave_up = false;
         if (s[7] != 0.0) { h->eng->ov_gave_up(); gave_up = true; }      // never expected; see LDLEngine::ov_gave_up
         if (s[2] != 0.0 && h->eng->top_abort_word() != nullptr) { h->eng->top_gave_up(); gave_up = true; }   // see TopOwner
+        if (gave_up_out) *gave_up_out = gave_up;
         if (gave_up) return HIPKKT_REFINEMENT_INCOMPLETE;               // (the step's results are void: repeat it)
         if (s[0] != 0.0) return HIPKKT_NUMERIC_FAILURE;
         if (s[1] != 0.0) {                                              // some solve would have gone on refining
@@ -3614,6 +3699,8 @@ static int sys_solve_into(hipkkt_kkt_t h, const double* rx, const double* rz, do
 }
 
 static void sys_cache_constant_terms(hipkkt_kkt_t h);
+static int sys_flush_update_status(hipkkt_kkt_t h);
+static int sys_flush_startup(hipkkt_kkt_t h);
 static int sys_constant_rhs(hipkkt_kkt_t h)
 {
     // _kkt_solve_constant_rhs! (kktsystem.jl:80-92): (x2, z2) = K \ (-q, b)
@@ -3629,6 +3716,8 @@ int hipkkt_kkt_system_solve_constant_rhs(hipkkt_kkt_t h)
         if (!h || !h->sys_ready) throw ArgError("hipkkt_kkt_system_*: call hipkkt_kkt_system_init first");
         HIP_CHECK(hipSetDevice(h->device));
         h->sys_const_pending = false;
+        const int rc = sys_flush_update_status(h);      // (an enqueued-only kkt_update! before it: its status is due here)
+        if (rc != HIPKKT_OK) return rc;
         return sys_constant_rhs(h);
     });
 }
@@ -3642,7 +3731,14 @@ int hipkkt_kkt_system_set_lazy(hipkkt_kkt_t h, int lazy)
             HIP_CHECK(hipSetDevice(h->device));
             h->sys_const_pending = false;
             h->sys_lazy = false;
+            const int rc = sys_flush_update_status(h);
+            if (rc != HIPKKT_OK) return rc;
             return sys_constant_rhs(h);
+        }
+        if (!lazy && h->sys_ready) {                   // (an enqueued-only update's record does not outlive the mode)
+            HIP_CHECK(hipSetDevice(h->device));
+            const int rc = sys_flush_update_status(h);
+            if (rc != HIPKKT_OK) { h->sys_lazy = false; return rc; }
         }
         h->sys_lazy = lazy != 0;
         return HIPKKT_OK;
@@ -3685,7 +3781,8 @@ int hipkkt_kkt_system_solve_initial_point(hipkkt_kkt_t h, double* d_x, double* d
         if ((h->K.n && !d_x) || (h->K.m && (!d_s || !d_z))) throw ArgError("hipkkt_kkt_system_solve_initial_point: bad argument");
         HIP_CHECK(hipSetDevice(h->device));
         const int n = h->K.n, m = h->K.m;
-        int rc;
+        int rc = sys_flush_startup(h);
+        if (rc != HIPKKT_OK) return rc;
         if (h->mapP.n == 0) {
             // LP initialisation (kktsystem.jl:107-128): [0; b] -> (x, -s), then [-q; 0] -> z
             if (n) HIP_CHECK(hipMemsetAsync(h->sworkx.p, 0, (size_t)n * sizeof(double), h->stream));
@@ -3749,9 +3846,18 @@ static int sys_flush_update_status(hipkkt_kkt_t h)
     HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     launch_zero_ints((int*)h->ir_sticky, 16, h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    int rc = kkt_eval_sticky(h, h->pin->h + 40);
-    if (rc == HIPKKT_REFINEMENT_INCOMPLETE) rc = kkt_update_device(h);      // a bounded wait gave up: level by level, synchronously
+    bool gave_up = false;
+    int rc = kkt_eval_sticky(h, h->pin->h + 40, &gave_up);
+    if (rc == HIPKKT_REFINEMENT_INCOMPLETE) rc = gave_up ? kkt_update_device(h) : HIPKKT_OK;   // a bounded wait gave up: level by level, synchronously
     return rc;
+}
+// ... before the calls of the start-up sequence (solver.jl:389-393: kkt_update!, then kkt_solve_initial_point!, the
+// update's Bool ignored): the record is read so that a give-up is repaired and no stale word reaches the first
+// iteration; a numeric failure of that update is the reference's to ignore -- the solve that follows reports its own
+static int sys_flush_startup(hipkkt_kkt_t h)
+{
+    const int rc = sys_flush_update_status(h);
+    return rc == HIPKKT_NUMERIC_FAILURE ? HIPKKT_OK : rc;
 }
 // the x2-only terms of tau_den (kktsystem.jl:194-196) are the same for both solves of the iteration
 static void sys_cache_constant_terms(hipkkt_kkt_t h)
@@ -3831,7 +3937,8 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
         HIP_CHECK(hipMemcpyAsync(h->pin->h + 48, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         launch_zero_ints((int*)h->ir_sticky, 16, st);
         HIP_CHECK(hipStreamSynchronize(st));
-        rc = kkt_eval_sticky(h, h->pin->h + 40);
+        bool gave_up = false;
+        rc = kkt_eval_sticky(h, h->pin->h + 40, &gave_up, true);
         h->last_ir = (int64_t)h->pin->h[43];           // this call's refinement rounds, summed over its columns (as the synchronous path reports)
         if (rc == HIPKKT_OK) {
             lhs_tau_kappa[0] = h->pin->h[48];
@@ -3839,8 +3946,8 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
             return HIPKKT_OK;
         }
         if (rc != HIPKKT_REFINEMENT_INCOMPLETE) return rc;
-        if (update_unread) {                           // (the factorisation itself may be void: a wait of the overlap mode gave up)
-            rc = kkt_update_device(h);
+        if (update_unread && gave_up) {                // (the factorisation itself may be void: a wait of the overlap mode gave up;
+            rc = kkt_update_device(h);                 //  a solve that merely wanted another refinement round keeps its factor)
             if (rc != HIPKKT_OK) return rc;
         }
     } else {
@@ -3915,11 +4022,70 @@ int hipkkt_kkt_system_update_cones(hipkkt_kkt_t h, const double* Hs, const doubl
     });
 }
 
+int hipkkt_kkt_system_update_scaling(hipkkt_kkt_t h, const double* w, const double* eta, const double* lambda,
+                                     const double* psd_R, const double* psd_Rinv)
+{
+    if (h && h->deferred) {
+        g_last_error = "hipkkt_kkt_system_*: level C reads its scalars back (deferred status is for level B)";
+        return HIPKKT_ERR_ARG;
+    }
+    bool enqueue_only = false;
+    int rc = guarded([&]() {
+        if (!h) throw ArgError("null handle");
+        const size_t m = (size_t)h->K.m, nc = h->K.cones.size();
+        if ((m && (!w || !lambda)) || (h->nsoc > 0 && !eta) || (h->npsd > 0 && (!psd_R || !psd_Rinv)))
+            throw ArgError("hipkkt_kkt_system_update_scaling: missing scaling data");
+        if (h->psd_too_big) throw ArgError("hipkkt_kkt_system_*: PSD cones with side > 48 are not covered by level C");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        if (m) {
+            HIP_CHECK(hipMemcpyAsync(h->w.p, w, m * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(h->lam.p, lambda, m * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        if (eta && nc) HIP_CHECK(hipMemcpyAsync(h->eta.p, eta, nc * sizeof(double), hipMemcpyHostToDevice, st));
+        if (h->npsd > 0) {
+            HIP_CHECK(hipMemcpyAsync(h->psdR.p, psd_R, h->psdR.n * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(h->psdRinv.p, psd_Rinv, h->psdRinv.n * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        // the caller's arrays are free again once these copies have run; the kernels behind them need not have
+        h->host_upload_mark(st);
+        launch_zero_ints(h->fail.p, 1, st);
+        int pu = h->prof.begin(0, st);
+        launch_cone_from_scaling(h->cone_dev(), h->cone_state(), h->K.m, st);      // Hs, u, v, eta^2 (and R R') on the device
+        h->prof.end(pu, st);
+        h->scaling_valid = true;
+        enqueue_only = h->sys_lazy && h->sys_ready;
+        const int r = kkt_update_device(h, enqueue_only);
+        h->host_upload_wait();
+        return r;
+    });
+    if (rc != HIPKKT_OK) return rc;
+    if (enqueue_only) h->sys_update_unread = true;
+    return guarded([&]() { return sys_after_update(h); });
+}
+
+int hipkkt_host_register(void* ptr, int64_t bytes)
+{
+    return guarded([&]() {
+        if (!ptr || bytes <= 0) throw ArgError("hipkkt_host_register: bad argument");
+        HIP_CHECK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+        return HIPKKT_OK;
+    });
+}
+int hipkkt_host_unregister(void* ptr)
+{
+    return guarded([&]() {
+        if (!ptr) throw ArgError("hipkkt_host_unregister: bad argument");
+        HIP_CHECK(hipHostUnregister(ptr));
+        return HIPKKT_OK;
+    });
+}
+
 // ---- host-vector variants: the iterate, right-hand side and step live in host memory (DefaultVariables)
 static double* sys_host_stage(hipkkt_kkt_t h)
 {
     const size_t len = (size_t)h->K.n + 2 * (size_t)h->K.m;
-    if (h->hst.n < 3 * len) h->hst.alloc(3 * len);
+    if (h->hst.n < 3 * len) { h->hst.alloc(3 * len); h->host_vars_valid = false; }
     return h->hst.p;
 }
 
@@ -3971,7 +4137,9 @@ int hipkkt_kkt_system_solve_host(hipkkt_kkt_t h, double* lhs_x, double* lhs_s, d
         if (!h) throw ArgError("null handle");
         const size_t n = (size_t)h->K.n, m = (size_t)h->K.m, len = n + 2 * m;
         const bool affine = steptype == 0;
-        if ((n && (!lhs_x || !rhs_x || !var_x)) || (m && (!lhs_s || !lhs_z || !rhs_z || !var_s || !var_z)) ||
+        // (var_x = var_s = var_z = NULL: the variables uploaded by the previous call -- the combined step's are the affine step's)
+        const bool reuse_vars = !var_x && !var_s && !var_z && h->host_vars_valid;
+        if ((n && (!lhs_x || !rhs_x || (!var_x && !reuse_vars))) || (m && (!lhs_s || !lhs_z || !rhs_z || ((!var_s || !var_z) && !reuse_vars))) ||
             (m && !affine && !rhs_s) || !lhs_tau_kappa)
             throw ArgError("hipkkt_kkt_system_solve_host: bad argument");
         HIP_CHECK(hipSetDevice(h->device));
@@ -3982,7 +4150,7 @@ int hipkkt_kkt_system_solve_host(hipkkt_kkt_t h, double* lhs_x, double* lhs_s, d
             if (k && src) HIP_CHECK(hipMemcpyAsync(dst, src, k * sizeof(double), hipMemcpyHostToDevice, st));
         };
         up(dr, rhs_x, n); up(dr + n, affine ? nullptr : rhs_s, m); up(dr + n + m, rhs_z, m);
-        up(dv, var_x, n); up(dv + n, var_s, m); up(dv + n + m, var_z, m);
+        if (!reuse_vars) { up(dv, var_x, n); up(dv + n, var_s, m); up(dv + n + m, var_z, m); h->host_vars_valid = true; }
         int rc = sys_solve_step(h, dl, dl + n, dl + n + m, lhs_tau_kappa, dr, dr + n, dr + n + m, rhs_tau, rhs_kappa,
                                 dv, dv + n, dv + n + m, var_tau, var_kappa, steptype);
         if (rc != HIPKKT_OK) return rc;
@@ -4262,6 +4430,7 @@ int hipkkt_kkt_profile_get(hipkkt_kkt_t h, hipkkt_profile* out)
         *out = h->prof.acc;
         out->overlap_fallbacks = h->eng->n_ov_fallbacks;
         out->top_fallbacks = h->eng->n_top_fallbacks;
+        out->overlap_deferrals = h->eng->n_ov_busy;
         return HIPKKT_OK;
     });
 }

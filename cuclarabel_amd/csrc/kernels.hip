@@ -1036,6 +1036,100 @@ void launch_psd_A_from_R(const ConeDev& C, const ConeState& S, hipStream_t st)
 {
     if (C.npsd > 0) hipLaunchKernelGGL(k_psd_A_from_R, dim3(C.npsd), dim3(256), 0, st, C, S);
 }
+
+// ---- get_Hs! and the sparse second-order-cone vectors from a GIVEN scaling (w, eta; psdA = R R'): what a caller that
+// holds the reference's cone objects need not send over PCIe -- Hsblocks, u, v, eta^2 are functions of (w, eta, R)
+// (coneops_nncone.jl:91-101, coneops_socone.jl:125-192, coneops_psdtrianglecone.jl:135-161).  The arithmetic is the
+// tail of k_cone_elementwise / k_cone_soc / k_cone_psd, term for term and in the same order, so that a scaling computed
+// on the device and fed back gives bit-identical K values for the elementwise and second-order cones.
+__global__ void k_hs_from_w_elementwise(ConeDev C, ConeState S, int m)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int c = C.elem_cone[i];
+        const int kind = C.kind[c];
+        if (kind == 0) S.Hs[C.boff[c] + (i - C.off[c])] = 0.0;
+        else if (kind == 1) { const double w = S.w[i]; S.Hs[C.boff[c] + (i - C.off[c])] = w * w; }
+    }
+}
+__global__ __launch_bounds__(64) void k_soc_from_w(ConeDev C, ConeState S)
+{
+    const int c = C.soc_list[blockIdx.x];
+    const int off = C.off[c], n = C.numel[c];
+    const int lane = threadIdx.x;
+    const double* w = S.w + off;
+    double w1sqn = 0.0;
+    for (int i = 1 + lane; i < n; i += 64) { const double wi = w[i]; w1sqn += wi * wi; }
+    w1sqn = wave_sum(w1sqn);
+    const double w0n = w[0];
+    const double eta = S.eta[c];
+    const double eta2 = eta * eta;
+    double* Hs = S.Hs + C.boff[c];
+    const int sidx = C.sidx[c];
+    if (sidx >= 0) {
+        const double alpha = 2.0 * w0n;
+        const double wsq = w0n * w0n + w1sqn, wsqinv = 1.0 / wsq;
+        const double d = wsqinv / 2.0;
+        const double u0 = sqrt(wsq - d), u1 = alpha / u0;
+        const double v1 = sqrt(2.0 * (2.0 + wsqinv) / (2.0 * wsq - wsqinv));
+        double* u = S.u + C.soff[c];
+        double* v = S.v + C.soff[c];
+        for (int i = lane; i < n; i += 64) {
+            if (i == 0) { u[0] = u0; v[0] = 0.0; Hs[0] = eta2 * d; }
+            else { const double wi = w[i]; u[i] = u1 * wi; v[i] = v1 * wi; Hs[i] = eta2; }
+        }
+        if (lane == 0) S.eta2[sidx] = eta2;
+    } else if (lane == 0) {
+        Hs[0] = (sqrt(2.0) * w0n - 1.0) * (sqrt(2.0) * w0n + 1.0) * eta2;
+        int h = 1;
+        for (int col = 1; col < n; ++col) {
+            const double wc = w[col];
+            for (int row = 0; row <= col; ++row) {
+                const double wr = row == 0 ? w0n : w[row];
+                double val = 2.0 * wr * wc;
+                if (row == col) val += 1.0;
+                Hs[h++] = val * eta2;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_psd_hs_from_A(ConeDev C, ConeState S)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int c = C.psd_list[blockIdx.x];
+    const int k = C.psd_dim[c], t = k * (k + 1) / 2;
+    double* Am = smem;
+    const double* A = S.psdA + C.psd_aoff[c];
+    for (int idx = tid; idx < k * k; idx += 256) Am[idx] = A[idx];
+    __syncthreads();
+    double* Hs = S.Hs + C.boff[c];
+    const double s2 = 1.41421356237309504880;
+    const int nh = t * (t + 1) / 2;
+    for (int e = tid; e < nh; e += 256) {
+        int row, col;
+        svec_index(e, row, col);
+        int i, j, kq, l;
+        svec_index(row, i, j);
+        svec_index(col, kq, l);
+        double v;
+        const bool ij = (i == j), kl = (kq == l);
+        if (!ij && !kl) v = Am[i + kq * k] * Am[j + l * k] + Am[i + l * k] * Am[j + kq * k];
+        else if (ij && !kl) v = s2 * Am[j + l * k] * Am[j + kq * k];
+        else if (!ij && kl) v = s2 * Am[i + l * k] * Am[j + kq * k];
+        else v = Am[j + l * k] * Am[j + l * k];
+        Hs[e] = v;
+    }
+}
+void launch_cone_from_scaling(const ConeDev& C, const ConeState& S, int m, hipStream_t st)
+{
+    if (m > 0) hipLaunchKernelGGL(k_hs_from_w_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, m);
+    if (C.nsoc > 0) hipLaunchKernelGGL(k_soc_from_w, dim3(C.nsoc), dim3(64), 0, st, C, S);
+    if (C.npsd > 0) {
+        hipLaunchKernelGGL(k_psd_A_from_R, dim3(C.npsd), dim3(256), 0, st, C, S);
+        const size_t lds = (size_t)C.psd_kmax * C.psd_kmax * sizeof(double);
+        hipLaunchKernelGGL(k_psd_hs_from_A, dim3(C.npsd), dim3(256), lds, st, C, S);
+    }
+}
 void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend)
 {
     if (m > 0) hipLaunchKernelGGL(k_mul_Hs_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, y, x, m, addend);

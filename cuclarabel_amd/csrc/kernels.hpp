@@ -455,6 +455,8 @@ void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, 
 // addend != null: y = -(W'W x + addend) (the Delta_s recovery of kkt_solve!, kktsystem.jl:206-212)
 void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend = nullptr);
 void launch_psd_A_from_R(const ConeDev& C, const ConeState& S, hipStream_t st);    // psdA = psdR psdR' per PSD cone
+// Hs blocks, sparse second-order-cone u / v / eta^2 (and psdA) from the scaling already in S (w, eta, psdR): get_Hs! on the device
+void launch_cone_from_scaling(const ConeDev& C, const ConeState& S, int m, hipStream_t st);
 
 // ---- the reduced-system algebra around the three solves of an IPM iteration (kktsystem.jl:135-215), device-resident
 // konst = Delta_s_from_Delta_z_offset!(cones, ds, z) (coneops_compositecone.jl:185-202; zero :137-150, nonnegative

@@ -318,6 +318,37 @@ class HipKKTSystem:
             return ok, tk[0], tk[1]
         return update, (lambda: solve(0)), (lambda: solve(1))
 
+    def prepared_host(self, lhs, rhs, rhs_tau, rhs_kappa, var, var_tau, var_kappa, scaling, reduced=True, reuse_variables=True):
+        """The same three closures for HOST-resident numpy vectors -- what integration/HipKKTExt.jl does per iteration:
+        kkt_update! from the caller's cone scaling (reduced: hipkkt_kkt_system_update_scaling with (w, eta, lambda, R,
+        Rinv); otherwise hipkkt_kkt_system_update_cones with the full nine arrays), then the two kkt_solve! through
+        hipkkt_kkt_system_solve_host, the combined one re-using the affine one's variables.  lhs, var: (x, s, z) arrays;
+        rhs = (affine (x, s, z), combined (x, s, z)); the arrays must stay alive (and may be page-locked: _lib.host_register)."""
+        L = _lib.lib()
+        h = self.ks._h
+        tk = np.zeros(2)
+        keep = (lhs, rhs, var, scaling, tk)
+        fs = L.hipkkt_kkt_system_solve_host
+        if reduced:
+            w, eta, lam, R, Ri = scaling[-5:]
+            fu, upd_args = L.hipkkt_kkt_system_update_scaling, (h, ptr(w), ptr(eta), ptr(lam), ptr(R), ptr(Ri))
+        else:
+            fu, upd_args = L.hipkkt_kkt_system_update_cones, (h,) + tuple(ptr(v) for v in scaling)
+        sol_args = []
+        for r, st in ((rhs[0], 0), (rhs[1], 1)):
+            vv = (None, None, None) if (st == 1 and reuse_variables) else (ptr(var[0]), ptr(var[1]), ptr(var[2]))
+            sol_args.append((h, ptr(lhs[0]), ptr(lhs[1]), ptr(lhs[2]), ptr(tk), ptr(r[0]), ptr(r[1]), ptr(r[2]), C.c_double(rhs_tau),
+                             C.c_double(rhs_kappa)) + vv + (C.c_double(var_tau), C.c_double(var_kappa), C.c_int(st)))
+
+        def update():
+            return check(fu(*upd_args), "kkt_update! (host scaling)")
+
+        def solve(i):
+            ok = check(fs(*sol_args[i]), "hipkkt_kkt_system_solve_host")
+            return ok, tk[0], tk[1]
+        update._keep = keep
+        return update, (lambda: solve(0)), (lambda: solve(1))
+
     # ---- lazy constant-RHS solve (hipkkt_kkt_system_set_lazy): kkt_update! + kkt_solve!(:affine) as two SEPARATE calls
     #      whose two solves still share one 2-column sweep
     def set_lazy(self, on=True):
@@ -338,6 +369,19 @@ class HipKKTSystem:
             raise ValueError("psd_R / psd_Rinv have the wrong length")
         return check(_lib.lib().hipkkt_kkt_system_update_cones(self.ks._h, *[ptr(v) for v in a]),
                      "hipkkt_kkt_system_update_cones")
+
+    def update_scaling(self, w, eta, lam, psd_R=None, psd_Rinv=None):
+        """kkt_update! from the NT scaling alone (hipkkt_kkt_system_update_scaling): the Hs blocks and the sparse
+        second-order-cone vectors are formed on the device from (w, eta, R) instead of crossing PCIe."""
+        a = [f64(v if v is not None else []) for v in (w, eta, lam, psd_R, psd_Rinv)]
+        if a[0].size != self.ks.m or a[2].size != self.ks.m or a[1].size != len(self.ks.cones):
+            raise ValueError("scaling data has the wrong length")
+        tot = sum(c.dim * c.dim for c in self.ks.cones if c.kind == 3)
+        if a[3].size != tot or a[4].size != tot:
+            raise ValueError("psd_R / psd_Rinv have the wrong length")
+        self._keep = a          # (registered or not, the arrays outlive the call)
+        return check(_lib.lib().hipkkt_kkt_system_update_scaling(self.ks._h, *[ptr(v) for v in a]),
+                     "hipkkt_kkt_system_update_scaling")
 
     # ---- numpy interface.  staging = "host": the *_host entry points of the C ABI (vectors staged by the library: what
     #      a caller with host-resident DefaultVariables uses); "torch": device tensors + the device-pointer entry points
@@ -404,7 +448,9 @@ class HipKKTSystem:
         ok = self.solve_initial_point_dev(x.data_ptr(), s.data_ptr(), z.data_ptr())
         return ok, x[:n].cpu().numpy(), s[:m].cpu().numpy(), z[:m].cpu().numpy()
 
-    def solve(self, rhs_x, rhs_s, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa, affine):
+    def solve(self, rhs_x, rhs_s, rhs_z, rhs_tau, rhs_kappa, x, s, z, tau, kappa, affine, reuse_variables=False):
+        """reuse_variables (host staging): (x, s, z) are those of the previous call -- the combined step's are the affine
+        step's (solver.jl:289-323) -- and are not sent again."""
         n, m = self.ks.n, self.ks.m
         if self.staging == "host":
             a = [f64(v) for v in (rhs_x, rhs_s, rhs_z, x, s, z)]
@@ -415,8 +461,8 @@ class HipKKTSystem:
             tk = np.zeros(2)
             ok = check(_lib.lib().hipkkt_kkt_system_solve_host(
                 self.ks._h, ptr(lhs[0]), ptr(lhs[1]), ptr(lhs[2]), ptr(tk), ptr(a[0]), ptr(a[1]), ptr(a[2]),
-                float(rhs_tau), float(rhs_kappa), ptr(a[3]), ptr(a[4]), ptr(a[5]), float(tau), float(kappa),
-                0 if affine else 1), "hipkkt_kkt_system_solve_host")
+                float(rhs_tau), float(rhs_kappa), *([None, None, None] if reuse_variables else [ptr(a[3]), ptr(a[4]), ptr(a[5])]),
+                float(tau), float(kappa), 0 if affine else 1), "hipkkt_kkt_system_solve_host")
             if not ok:
                 return False, None
             return True, (lhs[0][:n], lhs[2][:m], lhs[1][:m], float(tk[0]), float(tk[1]))

@@ -102,6 +102,11 @@ typedef struct {
      * Bool of refactor! / solve!, directldl_qdldl.jl:79): results stay correct, but a non-zero count means a 50 ms stall
      * happened and the handle runs on its slower path from then on.  Expected value: 0. */
     int64_t overlap_fallbacks, top_fallbacks;
+    /* Factorisations of this handle (lifetime) that ran level by level because ANOTHER handle's overlapped factorisation
+     * was in flight on the device: one overlapped factorisation per device at a time (the mode's forward-progress
+     * argument needs every other kernel on the device to end by itself).  Not a fallback: no stall, nothing is
+     * switched off, the next factorisation asks again. */
+    int64_t overlap_deferrals;
 } hipkkt_profile;
 
 /* -------------------------------------------------------------------- general */
@@ -257,8 +262,18 @@ int hipkkt_kkt_system_set_lazy(hipkkt_kkt_t h, int lazy);
 int hipkkt_kkt_system_update_cones(hipkkt_kkt_t h, const double *Hsblocks, const double *soc_u, const double *soc_v,
                                    const double *soc_eta2, const double *w, const double *eta, const double *lambda,
                                    const double *psd_R, const double *psd_Rinv);
+/* The same kkt_update! from the NT scaling ALONE: the Hs blocks and the sparse second-order-cone vectors u, v, eta^2 are
+ * functions of (w, eta) and of R (get_Hs!: coneops_nncone.jl:91-101, coneops_socone.jl:125-192,
+ * coneops_psdtrianglecone.jl:135-161) and are formed on the device -- for the headline workload 3.2 MB cross PCIe per
+ * iteration instead of 6.4, for PSD cones of side k the k x k factor R instead of the t(t+1)/2-entry block, t = k(k+1)/2.
+ * The values equal get_Hs!'s to round-off (bit for bit when the scaling came from the device: the tests pin that).  In
+ * lazy mode the call only enqueues, like hipkkt_kkt_system_update; the arrays may be reused when it returns. */
+int hipkkt_kkt_system_update_scaling(hipkkt_kkt_t h, const double *w, const double *eta, const double *lambda,
+                                     const double *psd_R, const double *psd_Rinv);
 /* The same entry points for a caller whose iterate lives in HOST memory (DefaultVariables are Vector{T},
- * variables.jl:1-30): vectors are staged through buffers the handle owns (n + 2m doubles each way per call). */
+ * variables.jl:1-30): vectors are staged through buffers the handle owns (n + 2m doubles each way per call).
+ * hipkkt_kkt_system_solve_host: var_x = var_s = var_z = NULL means "the variables of the previous call" -- they do not
+ * change between the affine and the combined kkt_solve! of an iteration (solver.jl:289-323), so the glue sends them once. */
 int hipkkt_kkt_system_update_host(hipkkt_kkt_t h, const double *s, const double *z);
 int hipkkt_kkt_system_solve_initial_point_host(hipkkt_kkt_t h, double *x, double *s, double *z);
 int hipkkt_kkt_system_solve_host(hipkkt_kkt_t h, double *lhs_x, double *lhs_s, double *lhs_z, double *lhs_tau_kappa,
@@ -266,6 +281,14 @@ int hipkkt_kkt_system_solve_host(hipkkt_kkt_t h, double *lhs_x, double *lhs_s, d
                                  double rhs_tau, double rhs_kappa,
                                  const double *var_x, const double *var_s, const double *var_z,
                                  double var_tau, double var_kappa, int steptype);
+
+/* Page-lock a host array the caller keeps for the solver's lifetime (an interior-point method's work vectors:
+ * DefaultVariables, the right-hand sides, the cones' w / lambda) so that the copies of the *_host entry points run at
+ * the link's rate and without the runtime's per-call pinning (cfg2: the host-vector iteration 4.4 -> 3.9 ms).  Optional;
+ * unregister before the array is freed.  Returns HIPKKT_OK, or HIPKKT_ERR_HIP if the range cannot be registered (the
+ * entry points work with unregistered memory all the same). */
+int hipkkt_host_register(void *ptr, int64_t bytes);
+int hipkkt_host_unregister(void *ptr);
 
 /* ------------------------------------------- problem-data scaling (before the KKT solver is built)
  * data_equilibrate! (/root/reference/src/problemdata.jl:133-221): Ruiz equilibration of

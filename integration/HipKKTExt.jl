@@ -248,6 +248,8 @@ mutable struct HipKKTSystem{T} <: AbstractKKTSystem{T}
     psd_R::Vector{T}
     psd_Rinv::Vector{T}
     tk::Vector{T}                    # (dtau, dkappa) read-back
+    variables_sent::Bool             # (x, s, z) of this iteration are on the device already (set by the affine kkt_solve!)
+    registered::Vector{Vector{T}}    # host arrays page-locked for the copies (hipkkt_host_register), kept for the finalizer
 
     function HipKKTSystem{T}(data::DefaultProblemData{T}, cones::CompositeCone{T}, settings::Settings{T}) where {T}
         ks = HipKKTSolver{T}(data.P, data.A, cones, data.m, data.n, settings)
@@ -255,34 +257,49 @@ mutable struct HipKKTSystem{T} <: AbstractKKTSystem{T}
             ks.handle, data.q, data.b), "hipkkt_kkt_system_init")
         check(ccall((:hipkkt_kkt_system_set_lazy, libhipkkt), Cint, (Ptr{Cvoid}, Cint), ks.handle, 1), "hipkkt_kkt_system_set_lazy")
         npsd = sum(c isa PSDTriangleCone ? c.n^2 : 0 for c in cones; init = 0)
-        return new(ks, ones(T, data.m), ones(T, length(cones)), zeros(T, data.m), zeros(T, npsd), zeros(T, npsd), zeros(T, 2))
+        obj = new(ks, ones(T, data.m), ones(T, length(cones)), zeros(T, data.m), zeros(T, npsd), zeros(T, npsd), zeros(T, 2),
+                  false, Vector{T}[])
+        for v in (obj.w, obj.lambda) register!(obj, v) end
+        finalizer(o -> foreach(v -> ccall((:hipkkt_host_unregister, libhipkkt), Cint, (Ptr{Cvoid},), v), o.registered), obj)
+        return obj
     end
+end
+
+# Page-lock the vectors that cross PCIe every iteration.  The solver's DefaultVariables (variables, the step, the two
+# right-hand sides) are allocated once per Solver (solver.jl:150-160) and live as long as it does, like this object's
+# own scaling vectors: registered the first time they are seen.  Optional -- a vector that cannot be registered is
+# copied through the runtime's pageable path as before.
+function register!(s::HipKKTSystem{T}, v::Vector{T}) where {T}
+    (isempty(v) || any(r -> r === v, s.registered)) && return
+    rc = ccall((:hipkkt_host_register, libhipkkt), Cint, (Ptr{Cvoid}, Int64), v, sizeof(v))
+    rc == 0 && push!(s.registered, v)
+    return
+end
+function register_once!(s::HipKKTSystem{T}, vs::DefaultVariables{T}...) where {T}
+    length(s.registered) >= 2 + 3 * length(vs) && return
+    for d in vs, v in (d.x, d.s, d.z) register!(s, v) end
 end
 
 kkt_linear_solver_info(s::HipKKTSystem{T}) where {T} = kktsolver_linear_solver_info(s.kktsolver)
 kkt_update_P!(s::HipKKTSystem{T}, P::SparseMatrixCSC{T}) where {T} = kktsolver_update_P!(s.kktsolver, P)
 kkt_update_A!(s::HipKKTSystem{T}, A::SparseMatrixCSC{T}) where {T} = kktsolver_update_A!(s.kktsolver, A)
 
-# kkt_update! gets the CONES, not the iterate (solver.jl:279): everything the device needs is read from them --
-# the data of kktsolver_update! (get_Hs!, sparse-SOC u / v / eta^2, as in B above) and the NT scaling that
-# kkt_solve!'s Delta_s_from_Delta_z_offset! / mul_Hs! use (fields of the same cone objects, cone_types.jl:40-60,
-# 84-115, 125-160).
+# kkt_update! gets the CONES, not the iterate (solver.jl:279): what the device needs is the NT scaling -- fields of the
+# cone objects (cone_types.jl:40-60, 84-115, 125-160): w, eta, lambda, and R / Rinv of the PSD cones.  get_Hs!'s blocks
+# and the sparse second-order cones' u / v / eta^2 are functions of those (coneops_nncone.jl:91-101,
+# coneops_socone.jl:125-192, coneops_psdtrianglecone.jl:135-161) and are formed on the device
+# (hipkkt_kkt_system_update_scaling): for the 100k-variable SOCP 3.2 MB cross PCIe per iteration instead of 6.4, and the
+# host skips get_Hs! altogether.  (hipkkt_kkt_system_update_cones, which takes get_Hs!'s output as well, remains for a
+# caller that wants the reference's own rounding of those blocks.)
 function kkt_update!(s::HipKKTSystem{T}, data::DefaultProblemData{T}, cones::CompositeCone{T}) where {T}
     ks = s.kktsolver
-    get_Hs!(cones, ks.Hsblocks)
-    off = 0; k = 0; zoff = 0; poff = 0
+    zoff = 0; poff = 0
     for (i, c) in enumerate(cones)
         d = numel(c)
         if c isa NonnegativeCone
             s.w[zoff+1:zoff+d] .= c.w;  s.lambda[zoff+1:zoff+d] .= c.λ
         elseif c isa SecondOrderCone
             s.w[zoff+1:zoff+d] .= c.w;  s.lambda[zoff+1:zoff+d] .= c.λ;  s.eta[i] = c.η
-            if is_sparse_expandable(c)
-                ks.soc_u[off+1:off+d] .= c.sparse_data.u
-                ks.soc_v[off+1:off+d] .= c.sparse_data.v
-                k += 1; ks.soc_eta2[k] = c.η^2
-                off += d
-            end
         elseif c isa PSDTriangleCone
             n = c.n
             s.lambda[zoff+1:zoff+n] .= c.data.λ
@@ -292,11 +309,10 @@ function kkt_update!(s::HipKKTSystem{T}, data::DefaultProblemData{T}, cones::Com
         end
         zoff += d
     end
-    GC.@preserve s ks check(ccall((:hipkkt_kkt_system_update_cones, libhipkkt), Cint,
-        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
-         Ptr{Cdouble}, Ptr{Cdouble}),
-        ks.handle, ks.Hsblocks, ks.soc_u, ks.soc_v, ks.soc_eta2, s.w, s.eta, s.lambda, s.psd_R, s.psd_Rinv),
-        "hipkkt_kkt_system_update_cones")
+    s.variables_sent = false         # a new iteration: the next kkt_solve! sends (x, s, z) again
+    GC.@preserve s ks check(ccall((:hipkkt_kkt_system_update_scaling, libhipkkt), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        ks.handle, s.w, s.eta, s.lambda, s.psd_R, s.psd_Rinv), "hipkkt_kkt_system_update_scaling")
 end
 
 function kkt_solve_initial_point!(s::HipKKTSystem{T}, variables::DefaultVariables{T}, data::DefaultProblemData{T}) where {T}
@@ -307,12 +323,17 @@ end
 
 function kkt_solve!(s::HipKKTSystem{T}, lhs::DefaultVariables{T}, rhs::DefaultVariables{T}, data::DefaultProblemData{T},
                     variables::DefaultVariables{T}, cones::CompositeCone{T}, steptype::Symbol) where {T}
+    # `variables` does not change between the affine and the combined kkt_solve! of an iteration (solver.jl:289-323):
+    # it goes over PCIe with the first of them only (NULL = "the variables of the previous call").
+    register_once!(s, lhs, rhs, variables)
+    vx, vs, vz = s.variables_sent ? (C_NULL, C_NULL, C_NULL) : (pointer(variables.x), pointer(variables.s), pointer(variables.z))
     ok = GC.@preserve s lhs rhs variables check(ccall((:hipkkt_kkt_system_solve_host, libhipkkt), Cint,
         (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
          Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint),
         s.kktsolver.handle, lhs.x, lhs.s, lhs.z, s.tk, rhs.x, rhs.s, rhs.z, rhs.τ, rhs.κ,
-        variables.x, variables.s, variables.z, variables.τ, variables.κ, steptype === :affine ? 0 : 1),
+        vx, vs, vz, variables.τ, variables.κ, steptype === :affine ? 0 : 1),
         "hipkkt_kkt_system_solve_host")
+    s.variables_sent = true
     ok || return false
     lhs.τ = s.tk[1]
     lhs.κ = s.tk[2]

@@ -26,6 +26,14 @@ def test_bench_spawns_its_own_ranks(mode, scaling):
     out = _run("--gpus", "2", "--mode", mode, "--nrhs", "7", "--problems", "5")
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["dry_run"] is True
     assert out["scaling"] == scaling and out["value"] > 0 and out["higher_is_better"] is True
+    if mode == "iter":
+        # the driver's one command measures both sharded axes of SURVEY.md 8(e) behind the headline pass: the rows of a
+        # short `problems` pass and a short `rhs` pass ride in the same JSON line (and exist at N = 1 as anchors)
+        sm = out["scale_modes"]
+        assert set(sm) == {"problems", "rhs"}, sm
+        assert sm["problems"]["scaling"] == "strong" and sm["problems"]["config"]["problems_per_rank"] == 3
+        assert sm["rhs"]["scaling"] == "strong" and sm["rhs"]["config"]["columns_per_rank"] == 4
+        assert sm["problems"]["value"] > 0 and sm["rhs"]["value"] > 0
     if mode == "problems":
         assert out["config"]["problems_per_rank"] == 3       # rank 0 of 2 holds problems 0, 2, 4
     if mode == "rhs":
@@ -35,6 +43,8 @@ def test_bench_spawns_its_own_ranks(mode, scaling):
 def test_bench_single_rank_needs_no_launcher():
     out = _run()
     assert out["n_gpus"] == 1 and out["dry_run"] is True
+    assert set(out["scale_modes"]) == {"problems", "rhs"}        # the N = 1 anchors of the two sharded axes
+    assert _run("--no-scale-modes")["scale_modes"] is None
 
 
 def test_bench_without_gpu_fails_loudly():

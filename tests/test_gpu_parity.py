@@ -376,8 +376,10 @@ def test_level_A_solve_multi_matches_column_solves():
 
 def test_two_handles_on_their_own_streams_driven_concurrently():
     """Several Solvers may coexist (threading): two handles, each on its own HIP stream and
-    host thread.  Only one of them may use the persistent top-of-tree kernel at a time; both must return
-    what a lone handle returns."""
+    host thread.  Only one of them may use the persistent top-of-tree kernel at a time (the other takes the chained
+    sweep kernels) and one overlapped factorisation is in flight per device at a time (the other handle factorises level
+    by level that time); both must return what a lone handle returns, and NO bounded wait may expire: the library
+    arbitrates, no environment setting (until round 3: HIPKKT_FACTOR_OVERLAP=0, or one 50 ms give-up per handle)."""
     import threading
     _, HipKKTSolver, _ = _hip()
     pbs = [problems.config2(n=4000, seed=77), problems.config2(n=4000, seed=78)]
@@ -410,6 +412,27 @@ def test_two_handles_on_their_own_streams_driven_concurrently():
         assert len(outs[i]) == 1
         for a, b in zip(outs[i][0], alone[i]):
             assert np.abs(a - b).max() / np.abs(b).max() < 1e-12
+        assert sol[i].fallbacks == (0, 0), (i, sol[i].fallbacks, sol[i].profile())
+
+
+def test_concurrent_handles_of_mode_problems_take_no_fallback():
+    """`bench.py --mode problems` drives three block-diagonal handles concurrently (a stream and a host thread each) with
+    NO environment setting: the library admits one overlapped factorisation per device at a time and hands the sweeps of
+    the handles without the persistent kernel's claim to the chained kernels.  No bounded wait may expire (until round 3
+    every handle took the overlap mode's 50 ms give-up once unless the process set HIPKKT_FACTOR_OVERLAP=0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "HIPKKT_FACTOR_OVERLAP"}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "problems", "--problems", "24", "--n", "4000",
+                        "--steps", "4", "--warmup", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    row = json.loads(r.stdout.strip().splitlines()[-1])
+    assert row["config"]["handles_per_rank"] == 3 and row["config"]["handles_driven"].startswith("concurrently"), row["config"]
+    assert row["config"]["fallbacks"] == [0, 0], row["config"]
+    assert "gave up" not in r.stderr, r.stderr
 
 
 def test_block_diagonal_batch_equals_the_individual_problems():

@@ -304,6 +304,137 @@ def test_lazy_constant_solve_failure_and_flush():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("maker,exact", [("problems.config2(n=3000)", True),
+                                         ("problems.small_mixed(seed=43, psds=(2, 3, 6), socs=(3, 4, 6, 15))", False)])
+def test_update_scaling_forms_the_kkt_values_on_the_device(maker, exact):
+    """hipkkt_kkt_system_update_scaling takes the NT scaling alone (w, eta, lambda, R, Rinv) and forms get_Hs!'s blocks and
+    the sparse second-order cones' u, v, eta^2 on the device -- half the bytes of hipkkt_kkt_system_update_cones over PCIe.
+    Fed with the device's own scaling it must reproduce the K values of hipkkt_kkt_system_update BIT FOR BIT on
+    elementwise and second-order cones (same arithmetic in the same order; PSD blocks: R R' is re-formed, round-off), in
+    eager and in lazy mode, and the combined kkt_solve! that re-uses the affine one's uploaded variables
+    (hipkkt_kkt_system_solve_host with NULL variables) must return what the call with variables returns."""
+    from cuclarabel_amd import problems, _lib
+    from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+    pb = eval(maker)
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(pb.n)
+    rhs_x, rhs_s, rhs_z = rng.standard_normal(pb.n), rng.standard_normal(pb.m), rng.standard_normal(pb.m)
+    args = (0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+    ka = HipKKTSolver(pb.P, pb.A, pb.cones)
+    sa = HipKKTSystem(ka)
+    sa.init(pb.q, pb.b)
+    assert sa.update(pb.s0, pb.z0)
+    Ka = ka.KKT().data.copy()
+    ok, aff_a = sa.solve(rhs_x, pb.s0, rhs_z, *args, True)
+    assert ok
+    ok, com_a = sa.solve(rhs_x, rhs_s, rhs_z, *args, False)
+    assert ok
+    lam, psd = ka.scaling()
+    w, eta = ka.scaling_w()
+    R = np.concatenate([t[0].ravel(order="F") for t in psd]) if psd else np.zeros(0)
+    Ri = np.concatenate([t[1].ravel(order="F") for t in psd]) if psd else np.zeros(0)
+    for lazy in (False, True):
+        kb = HipKKTSolver(pb.P, pb.A, pb.cones)
+        sb = HipKKTSystem(kb)
+        sb.init(pb.q, pb.b)
+        sb.set_lazy(lazy)
+        keep = [np.ascontiguousarray(v) for v in (w, eta, lam, R, Ri)]
+        registered = [a for a in keep if a.size and _lib.host_register(a)]         # (page-locked as the glue keeps them)
+        assert sb.update_scaling(*keep)
+        ok, aff_b = sb.solve(rhs_x, pb.s0, rhs_z, *args, True)
+        assert ok
+        Kb = kb.KKT().data
+        if exact:
+            np.testing.assert_array_equal(Kb, Ka)
+        else:
+            np.testing.assert_allclose(Kb, Ka, rtol=1e-12, atol=1e-14 * np.abs(Ka).max())
+        ok, com_b = sb.solve(rhs_x, rhs_s, rhs_z, *args, False, reuse_variables=True)
+        assert ok
+        for a in registered:
+            assert _lib.host_unregister(a)
+        for got, want in ((aff_b, aff_a), (com_b, com_a)):
+            for g, v in zip(got, want):
+                g, v = np.asarray(g, dtype=float), np.asarray(v, dtype=float)
+                if exact:
+                    np.testing.assert_array_equal(g, v)
+                else:
+                    np.testing.assert_allclose(g, v, rtol=1e-9, atol=1e-10 * max(np.abs(v).max(), 1.0))
+
+
+@pytest.mark.gpu
+def test_lazy_update_then_startup_calls_read_the_update_status():
+    """The reference's default-start sequence is kkt_update!, then kkt_solve_initial_point! (solver.jl:389-393).  In lazy
+    mode kkt_update! only enqueues; its status record must be read by whatever comes next -- not only by kkt_solve! --
+    or (a) a give-up of the overlap mode leaves a void factor under the initial point and (b) a stale failure word is
+    folded into the first iteration's record (round-3 advisor).  (a): both bounded waits forced to expire, in a child
+    process; the initial point and the first affine step must match the eager sequence of an undisturbed process.
+    (b): an update on a non-interior point (reported as a failure), then a good one, then the initial point and a step."""
+    import os
+    import subprocess
+    import sys
+    from cuclarabel_amd import problems
+    from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+pb = problems.config2(n=6000)
+rng = np.random.default_rng(31)
+x = rng.standard_normal(pb.n)
+rhs_x, rhs_z = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+args = (0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+out = []
+for lazy in (False, True):
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    system = HipKKTSystem(ks)
+    system.init(pb.q, pb.b)
+    system.set_lazy(lazy)
+    assert system.update(pb.s0, pb.z0)
+    ok, x0, s0, z0 = system.solve_initial_point()
+    assert ok
+    ok, step = system.solve(rhs_x, pb.s0, rhs_z, *args, True)
+    assert ok
+    out.append((x0, s0, z0) + tuple(step))
+    print("FALLBACKS", lazy, ks.fallbacks)
+for a, b in zip(out[0], out[1]):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert np.abs(a - b).max() <= 1e-9 * max(np.abs(a).max(), 1e-300), np.abs(a - b).max()
+print("STARTUP OK")
+"""
+    r = subprocess.run([sys.executable, "-c", script.format(root=root)],
+                       env=dict(os.environ, HIPKKT_OV_TEST_LIMIT="0", HIPKKT_TOP_TEST_LIMIT="0"), cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "STARTUP OK" in r.stdout
+    assert "gave up" in r.stderr, r.stderr              # the forced give-ups really happened
+    # (b) a failed enqueued-only update must not haunt the calls after the next, good one
+    pb = problems.small_mixed(seed=43, psds=(2, 3, 6), socs=(3, 4, 6, 15))
+    rng = np.random.default_rng(37)
+    x = rng.standard_normal(pb.n)
+    rhs_x, rhs_z = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+    args = (0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+    ref = HipKKTSystem(HipKKTSolver(pb.P, pb.A, pb.cones))
+    ref.init(pb.q, pb.b)
+    assert ref.update(pb.s0, pb.z0)
+    ok, x0, s0, z0 = ref.solve_initial_point()
+    assert ok
+    system = HipKKTSystem(HipKKTSolver(pb.P, pb.A, pb.cones))
+    system.init(pb.q, pb.b)
+    system.set_lazy(True)
+    assert system.update(-pb.s0, pb.z0)                  # not interior: the failure sits in the unread record
+    assert system.update(pb.s0, pb.z0)
+    ok, x1, s1, z1 = system.solve_initial_point()
+    assert ok
+    for a, b in ((x0, x1), (s0, s1), (z0, z1)):
+        assert np.abs(a - b).max() <= 1e-9 * max(np.abs(a).max(), 1e-300)
+    ok, step = system.solve(rhs_x, pb.s0, rhs_z, *args, True)
+    assert ok and step is not None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("affine", [True, False])
 def test_system_update_cones_equals_the_device_scaling(affine):
     """hipkkt_kkt_system_update_cones (scaling handed over by the caller) against hipkkt_kkt_system_update (scaling
