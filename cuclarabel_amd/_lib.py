@@ -54,7 +54,7 @@ class Profile(C.Structure):
                 ("n_update", C.c_int64), ("n_factor", C.c_int64), ("n_trisolve", C.c_int64),
                 ("n_residual", C.c_int64), ("ir_iterations", C.c_int64),
                 ("dynamic_regularizations", C.c_int64),
-                ("overlap_fallbacks", C.c_int64), ("top_fallbacks", C.c_int64), ("overlap_deferrals", C.c_int64)]
+                ("overlap_fallbacks", C.c_int64), ("top_fallbacks", C.c_int64), ("overlap_deferrals", C.c_int64), ("top_deferrals", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -107,6 +107,7 @@ SYMBOLS = {
     "hipkkt_kkt_system_set_lazy": (C.c_int, [_P, C.c_int]),
     "hipkkt_kkt_system_update_cones": (C.c_int, [_P] * 10),
     "hipkkt_kkt_system_update_scaling": (C.c_int, [_P] * 6),
+    "hipkkt_selftest_handover": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "hipkkt_host_register": (C.c_int, [_P, C.c_int64]),
     "hipkkt_host_unregister": (C.c_int, [_P]),
     "hipkkt_kkt_system_update_host": (C.c_int, [_P, _P, _P]),

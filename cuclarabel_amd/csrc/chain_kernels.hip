@@ -11,16 +11,20 @@
 // products, partial sums -- is that of the per-level kernels, so a chained sweep is bit-identical to a per-level one.
 //
 // FORWARD PROGRESS.  Workgroups are numbered segment by segment in processing order (forward: leaves first; backward:
-// the top level first), so a workgroup waits only for workgroups with a LOWER index.  The hardware dispatches the
-// workgroups of a grid in index order (per XCD: workgroup i goes to XCD i mod 8, each XCD starts its share in order).
-// Take the lowest-index workgroup w that has not finished: everything it waits for has finished; every workgroup
-// before it on its XCD has finished, so w has been started or is the next one its XCD starts, and the slots it needs
-// are held only by kernels that end by themselves -- never by later workgroups of this grid, which are started after
-// w.  So w runs to its end, and by induction the grid drains, whatever its size and whatever else runs on the
-// device (another handle's chained or persistent kernels included: they make progress by the same argument).  No
-// residency requirement, hence no per-device owner.  The in-order start is hardware behaviour, not a language
-// guarantee: every wait is bounded by wall clock (SolveArgs::top_limit, 50 ms) and sets the abort word, upon which
-// the host disables the mode for the handle and repeats the sweep level by level (counted in hipkkt_profile).
+// the top level first), so a workgroup waits only for workgroups with a LOWER index.  The hardware deals the workgroups
+// of a grid to the eight XCDs round-robin (workgroup i to XCD i mod 8) and every XCD starts its share in index order.
+// Take the lowest-index workgroup w that has not finished: everything it waits for has finished; every workgroup before
+// it on ITS XCD has finished, so w has been started or is the next one its XCD starts, and the slots it needs there are
+// held only by OTHER kernels -- never by later workgroups of this grid on that XCD, which are started after w.  If
+// every other kernel on the device ends by itself, w gets its slot and runs to its end, and by induction the grid drains,
+// whatever its size: no residency requirement.  The premise matters: beside ANOTHER handle's waiting kernel (a
+// persistent sweep kernel, an overlapped factorisation, another chained grid) the argument fails -- that kernel's
+// resident workgroups may hold w's XCD while they wait for workgroups of their own that need the CUs this grid's resident
+// workgroups hold (seen in round 4 as 50 ms give-ups).  Hence a chained sweep runs only under the device's token
+// (hipkkt.hip, DevToken: one waiting kernel in flight per device, whichever handle's); a handle without it sweeps level
+// by level.  The in-order start is hardware behaviour, not a language guarantee: every wait is bounded by wall clock
+// (SolveArgs::top_limit, 50 ms) and sets the abort word, upon which the host disables the mode for the handle and
+// repeats the sweep level by level (counted in hipkkt_profile).
 //
 // HAND-OVER CONTRACT (the same one k_top_solve and the factorisation's overlap mode use; pinned by
 // tests/test_gpu_parity.py::test_handover_litmus):

@@ -45,6 +45,31 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 // drains vmcnt, the workgroup meets, ONE lane bumps / stores the counter; consumers poll the counter with relaxed
 // agent-scope loads and read the payload with agent-scope (L1 / L2-bypassing) loads only.  Every spin is bounded by
 // wall clock; on expiry flags[2] is set, everyone leaves, and the host repeats the factorisation level by level.
+//
+// THE MEMORY-ORDERING CONTRACT (shared with k_top_solve / k_top_solve_sliced in solve_kernels.hip and the chained
+// sweep kernels in chain_kernels.hip; there is no release / acquire FENCE at agent scope anywhere in csrc/):
+//   (P1) every payload store is a relaxed agent-scope atomic store: `global_store ... sc1`, performed at the level all
+//        XCDs share, never left dirty in this XCD's L2;
+//   (P2) `s_waitcnt vmcnt(0)` in every storing wave BEFORE the signal: on gfx9 stores count in vmcnt and the counter
+//        only drops when the store has been acknowledged at the level its scope bits name -- after it, the wave's
+//        payload stores are visible device-wide.  This is the instruction that orders payload before signal; without
+//        it the signal (a different address, possibly a different channel) can be performed first;
+//   (P3) workgroup barrier (block-class producers: all waves have passed P2), then ONE relaxed agent-scope atomic on the
+//        signal word;
+//   (C1) the consumer polls the signal word with relaxed agent-scope loads, branches on the value (a wave issues its
+//        memory operations in program order, and the payload loads are issued behind the branch), block-class:
+//        workgroup barrier;
+//   (C2) every payload load is a relaxed agent-scope atomic load (`... sc1`: served from the shared level, not from the
+//        CU's L1 nor from a line this XCD's L2 fetched before the producer's store).
+// Why no fence: an agent-scope release on this multi-XCD part writes the XCD's whole L2 back and an acquire invalidates
+// it (measured in r02: the sweeps 2.8x slower); P1 + C2 make the few words that are handed over coherent one by one
+// instead, and P2 / C1 order them.  tests/test_gpu_parity.py::test_handover_litmus runs exactly this protocol
+// (hipkkt_selftest_handover, below) on workgroup pairs placed on different XCDs: zero stale reads in 10^8 handed-over
+// words with the contract; with plain payload accesses instead of P1 / C2 EVERY word is read stale (the consumer's XCD
+// serves the line it fetched before), which pins P1 / C2 as necessary.  The variant without P2 has not shown a stale
+// word on this part (the memory side performs a wave's stores in issue order in practice); P2 stays because the ISA
+// promises no order between stores to different addresses -- it is the one part of the contract that rests on the
+// architecture manual rather than on an observed failure, and it costs what the drain costs (~0.5 us per hand-over).
 #define OV_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define OV_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 // (who / info: which wait expired first -- 1 a panel for a child's tiles, 2 a tile for its panel's blocks, 3 the gate -- and
@@ -1125,6 +1150,76 @@ void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int nt
     if (a.ov) hipLaunchKernelGGL((k_schur<true, true>), dim3(std::max(1, std::min(ntiles, ov_grid))), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
     else if (ntiles > pipe_tiles && tile_nc >= pipe_nc) hipLaunchKernelGGL((k_schur<false, true>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
     else hipLaunchKernelGGL((k_schur<false, false>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+//  Litmus test of the hand-over contract above (test infrastructure: hipkkt_selftest_handover; nothing in the product
+//  path calls it).  Workgroup 2p produces, workgroup 2p + 1 consumes (consecutive workgroups run on different XCDs);
+//  per round the producer stores `words` payload words (round * 1024 + index), signals, and waits for the consumer's
+//  acknowledgement before the next round; the consumer waits for the signal, reads the payload and counts every word
+//  that is not this round's.  VARIANT 0: the contract.  1: without P2 (no s_waitcnt before the signal).  2: without
+//  P1 / C2 (plain payload stores and loads, the waits kept).  Every spin is bounded; a timeout is counted and ends
+//  the pair.
+// ------------------------------------------------------------------------------------------------------------
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_handover_litmus(double* payload, int* sig, int* ack, int words, int rounds,
+                                                         unsigned long long* mismatches, unsigned long long* timeouts)
+{
+    __shared__ int sh_ok;
+    const int pair = blockIdx.x >> 1, tid = threadIdx.x;
+    const bool producer = (blockIdx.x & 1) == 0;
+    double* pl = payload + (size_t)pair * words;
+    const long long limit = 20000000;                 // 200 ms
+    unsigned long long bad = 0;
+    for (int r = 1; r <= rounds; ++r) {
+        const long long t0 = wall_clock64();
+        if (tid == 0) sh_ok = 1;
+        __syncthreads();
+        if (producer) {
+            for (int w = tid; w < words; w += 256) {
+                const double v = (double)r * 1024.0 + (double)w;
+                if (VARIANT == 2) pl[w] = v; else OV_ST(pl + w, v);
+            }
+            if (VARIANT != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                OV_ST(sig + pair, r);
+                // the consumer's acknowledgement before the payload is overwritten
+                for (;;) {
+                    if (OV_LD(ack + pair) >= r) break;
+                    if (wall_clock64() - t0 > limit) { sh_ok = 0; atomicAdd(timeouts, 1ull); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (!sh_ok) return;
+        } else {
+            if (tid == 0) {
+                for (;;) {
+                    if (OV_LD(sig + pair) >= r) break;
+                    if (wall_clock64() - t0 > limit) { sh_ok = 0; atomicAdd(timeouts, 1ull); break; }
+                }
+            }
+            __syncthreads();
+            if (!sh_ok) return;
+            for (int w = tid; w < words; w += 256) {
+                const double v = VARIANT == 2 ? pl[w] : OV_LD(pl + w);
+                if (v != (double)r * 1024.0 + (double)w) ++bad;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) OV_ST(ack + pair, r);
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+void launch_handover_litmus(int variant, double* payload, int* sig, int* ack, int pairs, int words, int rounds,
+                            unsigned long long* mismatches, unsigned long long* timeouts, hipStream_t st)
+{
+    const dim3 grid(2 * pairs), block(256);
+    if (variant == 0) hipLaunchKernelGGL(k_handover_litmus<0>, grid, block, 0, st, payload, sig, ack, words, rounds, mismatches, timeouts);
+    else if (variant == 1) hipLaunchKernelGGL(k_handover_litmus<1>, grid, block, 0, st, payload, sig, ack, words, rounds, mismatches, timeouts);
+    else hipLaunchKernelGGL(k_handover_litmus<2>, grid, block, 0, st, payload, sig, ack, words, rounds, mismatches, timeouts);
 }
 
 }  // namespace hipkkt

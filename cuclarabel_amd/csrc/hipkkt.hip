@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -86,28 +87,51 @@ static const size_t kWinvEarlyLaunches = std::getenv("HIPKKT_WINV_EARLY") ? (siz
 // grid of the side-stream W formation while the tree is still being factorised: 3/8 of the CUs (96 of 256) unless set
 static const int kSideWinvBlocksEnv = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 0;
 
-// The persistent top-of-tree solve kernel needs all its workgroups resident.  Two such kernels running
-// at the same time on one device (two handles on different streams) could each hold part of the CUs while
-// waiting for workgroups that cannot be scheduled.  So per device only the handles that share ONE stream
-// (hence are serialised) may use it; a handle on another stream takes the launch-per-level path.
-// The kernel's bounded spins + abort word remain as the last line of defence (e.g. another process).
-struct TopOwner { hipStream_t stream = nullptr; int refs = 0; };
-static std::mutex g_top_mu;
-static std::map<int, TopOwner> g_top_owner;
-
-// The factorisation's overlap mode has the same kind of requirement: its forward-progress argument (gate + admission
-// rule, enqueue_factor) assumes that every other kernel on the device ends by itself, which another handle's waiting
-// panel workgroups do not -- two handles' resident, waiting panel workgroups can together hold every CU.  So per device
-// ONE overlapped factorisation is in flight at a time: a handle takes the device's claim for the duration of a
-// factorisation (it may be taken over once the holder's last overlapped factorisation has left both its streams);
-// a handle that finds the claim busy factorises level by level THAT time -- it is not switched out of the mode.
-struct OvOwner {
+// WHAT MAY RUN BESIDE WHAT ON ONE DEVICE, ACROSS HANDLES.  Three mechanisms of this library put kernels on the device
+// whose workgroups WAIT for other workgroups: the factorisation's overlap mode (panel workgroups that hold a CU each
+// while they wait for their children's tiles on ANOTHER stream; tiles behind a gate: enqueue_factor), the persistent
+// top-of-tree sweep kernel (all its workgroups resident: k_top_solve) and the chained sweep launches (a workgroup waits
+// for lower-index workgroups of its own grid: chain_kernels.hip).  Each is safe beside kernels that end by themselves;
+// none is safe beside another handle's waiting kernel, and the overlap mode -- whose waits cross streams -- is not even
+// safe beside another handle's plain cross-stream dependencies.  All three were seen in round 4 as 50 ms give-ups with
+// two and three handles on their own streams:
+//   * handle 0's persistent kernel had part of its workgroups resident, the rest waiting for CUs held by handle 1's
+//     resident panels, which waited for tiles behind their gate, which waited for handle 1's remaining panels, which needed
+//     the CUs handle 0's workgroups sat on;
+//   * a chained grid's workgroups are dealt to the eight XCDs round-robin and each XCD starts its share in order, so the
+//     grid's lowest unfinished workgroup may be the one NOT yet resident on an XCD whose CUs another handle's waiting
+//     workgroups hold, while its own resident workgroups hold the CUs those are waiting for;
+//   * HIP maps a process's streams onto a few hardware queues, and a queue runs its packets in order: handle B's main
+//     stream waiting (an event) for B's W-formation kernel, parked in the queue behind handle A's tile kernel, which waits
+//     for A's panel kernel, which sits in the queue behind B's wait.
+// So per device the operations that are not plain single-stream work are classed and admitted under a mutex:
+//   X  overlapped factorisation (in-kernel waits across streams)    admitted iff every OTHER handle is idle (no M, S, X in flight)
+//                                                                     and has been for 20 ms (it is not in a loop beside this one:
+//                                                                     an X in flight takes the others' M away, which costs a busy
+//                                                                     handle more than the mode gives -- 64 SOCPs on three handles:
+//                                                                     3.7 k problems/s with X admitted on idleness alone, 4.4 k so)
+//   S  sweep through the persistent / chained kernels                admitted iff no other handle has an S or X in flight
+//   M  factorisation with side-stream W formation (no in-kernel wait) admitted iff no other handle has an X in flight
+// "in flight" = enqueued and not yet past the handle's three events (main, tile and W-formation stream); handles that
+// share one stream never conflict (the stream serialises them).  An operation that is not admitted is not switched off:
+// THAT factorisation runs level by level on the main stream alone, THAT sweep level by level -- kernels and packets that
+// depend on earlier work of their own stream only, safe beside anything.  Under contention (bench.py --mode problems:
+// three busy handles) X is rarely admitted and the handles settle on M + one S at a time, which is what round 3 reached
+// with HIPKKT_FACTOR_OVERLAP=0 set by hand.  A handle alone on its device (the common case) pays a mutex and no event;
+// the first time a second handle appears on a device the device is synchronised once, so that no operation without
+// events is in flight.
+enum DevOp { kOpNone = 0, kOpM = 1, kOpS = 2, kOpX = 3 };
+struct DevRec {
     const void* eng = nullptr;
-    bool enqueuing = false;                      // the holder is between taking the claim and recording the two events
-    hipEvent_t done_main = nullptr, done_tiles = nullptr;
+    hipStream_t stream = nullptr;
+    int kind = kOpNone;                          // strongest class among the handle's operations still in flight
+    bool enqueuing = false;                      // between admission and the recording of its events
+    hipEvent_t done_main = nullptr, done_tiles = nullptr, done_side = nullptr;
+    std::chrono::steady_clock::time_point last_seen{};   // the handle's last factorisation / sweep call (admitted or not)
 };
-static std::mutex g_ov_mu;
-static std::map<int, OvOwner> g_ov_owner;
+struct DevState { std::vector<DevRec> recs; };
+static std::mutex g_dev_mu;
+static std::map<int, DevState> g_dev;
 
 // ------------------------------------------------------------------------------------
 //  The numeric engine shared by both API levels
@@ -214,7 +238,13 @@ public:
             reserve_nr(nr);
         }
         if (no_graph || nr > 1 || n_solve_calls++ == 0) {
-            enqueue_solve(d_b, d_x, stream, allow_top && claim_top(), nr, ldb, ldx, allow_top);
+            // the persistent kernel AND the chained launches hold workgroups that wait for other workgroups: class S
+            // (DevOp); not admitted, this sweep goes level by level
+            const bool waits = allow_top && ((!top_disabled && top_launches > 0) || (!chain_disabled && chain_from < launches.size()));
+            const bool tok = waits && claim_dev(kOpS);
+            TokenRelease rel{this, tok};
+            enqueue_solve(d_b, d_x, stream, tok, nr, ldb, ldx, tok);
+            if (tok) { rel.on = false; dev_enqueued(true); }
             return;
         }
         auto key = std::make_pair((const void*)d_b, (const void*)d_x);
@@ -323,7 +353,7 @@ private:
 public:
     ~LDLEngine()
     {
-        release_top();
+        engine_gone();
         for (auto& kv : factor_graphs) (void)hipGraphExecDestroy(kv.second);
         for (auto& kv : solve_graphs) (void)hipGraphExecDestroy(kv.second);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
@@ -333,9 +363,8 @@ public:
         if (ev_side) (void)hipEventDestroy(ev_side);
         if (ov_stream) (void)hipStreamDestroy(ov_stream);
         if (ev_ov_fork) (void)hipEventDestroy(ev_ov_fork);
-        release_ov();
         if (ev_ov_join) (void)hipEventDestroy(ev_ov_join);
-        if (ev_ov_done) (void)hipEventDestroy(ev_ov_done);
+        if (ev_dev_done) (void)hipEventDestroy(ev_dev_done);
     }
 
 private:
@@ -427,7 +456,6 @@ private:
             } else if (!had) {
                 HIP_CHECK(hipEventCreateWithFlags(&ev_ov_fork, hipEventDisableTiming));
                 HIP_CHECK(hipEventCreateWithFlags(&ev_ov_join, hipEventDisableTiming));
-                HIP_CHECK(hipEventCreateWithFlags(&ev_ov_done, hipEventDisableTiming));
             }
             if (ov_stream && !ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
                 std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
@@ -464,13 +492,21 @@ private:
         // much as the factorisation ended earlier).
         const bool want_ov = overlap_wanted();
         const bool use_ov = want_ov && !side && !want_stamps && !ov_disabled && ov_first < launches.size();
-        // the side streams (W formation, Schur tiles) are chosen once per main stream, each probed to run BESIDE it
-        if (!side && !want_stamps) choose_side_streams(st, use_ov);
-        const bool ov_on = use_ov && !ov_disabled && ov_stream != nullptr && claim_ov();
-        struct OvRelease {                       // (the claim's "enqueuing" mark ends with this call, however it ends)
-            LDLEngine* e; bool on;
-            ~OvRelease() { if (on) e->ov_enqueued(false); }
-        } ov_release{this, ov_on};
+        // Whatever this factorisation does on more than ONE stream needs admission (DevOp): the overlap mode (class X:
+        // its kernels wait across streams) or, failing that, the side stream's W formation with its fork / join events
+        // (class M).  Not admitted, it keeps to its main stream, where every packet depends on earlier packets of the same
+        // stream only.
+        static const bool no_overlap = std::getenv("HIPKKT_NO_OVERLAP") != nullptr;
+        const bool side_w = !side && !no_overlap && !want_stamps && late_launches > 0 && late_launches < launches.size();
+        const bool tok_x = use_ov && claim_dev(kOpX);
+        const bool tok = tok_x || (side_w && claim_dev(kOpM));
+        TokenRelease ov_release{this, tok};      // (the "enqueuing" mark ends with this call, however it ends)
+        // the side streams (W formation, Schur tiles) are chosen once per main stream, each probed to run BESIDE it.  The
+        // tile stream only once an overlapped factorisation has been admitted: a stream that exists changes which
+        // hardware queues the process's other streams share (three busy handles, each with an idle tile stream: 3.7 k
+        // problems/s instead of 4.2 k)
+        if (!side && !want_stamps) choose_side_streams(st, tok_x);
+        const bool ov_on = tok_x && !ov_disabled && ov_stream != nullptr;
         // The merged panel kernels of the narrow top (below) wait for tile kernels that are submitted BEHIND them: that
         // needs the two streams on different hardware queues (ov_concurrent: choose_side_streams' probe; seen without it,
         // eight handles in one process: two of them waited for their 50 ms bound).  Without concurrency every level keeps
@@ -532,10 +568,8 @@ private:
         };
         // eager mode: once the tree narrows to its top levels most CUs idle, so the solve matrices
         // W = [T; M] of everything below are formed on a side stream meanwhile (HIPKKT_NO_OVERLAP=1 disables)
-        static const bool no_overlap = std::getenv("HIPKKT_NO_OVERLAP") != nullptr;
         const size_t nl = launches.size();
-        const size_t first_top = (!side && !no_overlap && !want_stamps && late_launches > 0 && late_launches < nl)
-                                     ? nl - late_launches : nl;
+        const size_t first_top = (tok && side_w) ? nl - late_launches : nl;
         bool eager_fork = false;
         int w_done = 0;
         for (size_t q = 0; q < nl; ++q) {
@@ -653,10 +687,9 @@ private:
             // one launch over every supernode, after the tree (all of them independent)
             form_w(d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st, 0);
         }
-        if (ov_on) {
-            HIP_CHECK(hipEventRecord(ev_ov_done, st));       // (with ev_ov_join: this factorisation has left both streams)
+        if (tok) {
             ov_release.on = false;
-            ov_enqueued(true);
+            dev_enqueued(true);                  // (records the event that, with ev_ov_join / ev_join, says this factorisation has left its streams)
         }
         HIP_CHECK(hipGetLastError());
         if (want_stamps) {
@@ -737,14 +770,12 @@ private:
         // narrow top, so that the formation hides behind them
         // Chained launches (chain_kernels.hip): the launches from chain_from on -- the levels with few enough fronts that
         // a launch per level is one front's latency chain, not throughput -- as segments of ONE grid per direction, ordered
-        // by counters in memory instead of kernel boundaries; the wide levels below keep their launches.  Where the
-        // persistent kernel is available (this handle holds the device's claim) it keeps its set -- its 1024-thread
-        // workgroups park a whole front's matrix items before the wait, a hop costs ~4 us against ~4.2 forward / ~6.3
-        // backward in the 512-thread chained kernel -- and only the launches between chain_from and the set are chained
-        // (cfg2: levels 3 and 4, 32 -> 26 us forward).  A handle WITHOUT the claim (another handle on another stream owns
-        // the persistent kernel) chains everything from chain_from to the root: no residency requirement, so any number
-        // of handles may do that side by side (cfg2's sweep pair then costs what the persistent path costs; level by
-        // level it was half as much again).  HIPKKT_CHAIN=0: off; HIPKKT_CHAIN_TOP=0: chain to the root even with the claim.
+        // by counters in memory instead of kernel boundaries; the wide levels below keep their launches.  The persistent
+        // kernel keeps its set -- its 1024-thread workgroups park a whole front's matrix items before the wait, a hop
+        // costs ~4 us against ~4.2 forward / ~6.3 backward in the 512-thread chained kernel -- and the launches between
+        // chain_from and the set are chained (cfg2: levels 3 and 4, 32 -> 26 us forward).  Both need the device's token
+        // (allow_chain / use_top: the caller holds it).  HIPKKT_CHAIN=0: off; HIPKKT_CHAIN_TOP=0: chain to the root
+        // instead of the persistent kernel (measured: cfg2's sweep pair 0.2675 against 0.260 ms).
         static const bool chain_env = !(std::getenv("HIPKKT_CHAIN") && std::atoi(std::getenv("HIPKKT_CHAIN")) == 0);
         static const bool chain_top = !(std::getenv("HIPKKT_CHAIN_TOP") && std::atoi(std::getenv("HIPKKT_CHAIN_TOP")) == 0);
         // (a set with very tall fronts keeps its (front, slice) kernel: such fronts do not fit one workgroup's LDS)
@@ -998,78 +1029,111 @@ private:
     std::vector<int> h_nch;
     DBuf<int64_t> d_recs;        // packed sweep records (kernels.hpp: SolveHdr); empty: the legacy layout
 
-    // ---- the device's overlap-mode claim (OvOwner)
-    bool claim_ov()
+    // ---- admission of this handle's multi-stream / waiting operations on its device (DevOp)
+    struct TokenRelease {
+        LDLEngine* e; bool on;
+        ~TokenRelease() { if (on) e->dev_enqueued(false); }
+    };
+public:
+    void set_device(int d)       // (once, right after construction: the engine joins its device's bookkeeping)
     {
-        std::lock_guard<std::mutex> lk(g_ov_mu);
-        OvOwner& o = g_ov_owner[device_id];
-        if (o.eng != this) {
-            if (o.eng != nullptr) {
-                // another handle holds it: free once its last overlapped factorisation has left its two streams
-                if (o.enqueuing) return false;
-                const bool idle = hipEventQuery(o.done_main) == hipSuccess && hipEventQuery(o.done_tiles) == hipSuccess;
-                (void)hipGetLastError();
-                if (!idle) { ++n_ov_busy; return false; }
+        device_id = d;
+        if (born) return;
+        born = true;
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        DevState& D = g_dev[device_id];
+        DevRec r;
+        r.eng = this;
+        D.recs.push_back(r);
+        if (D.recs.size() == 2) (void)hipDeviceSynchronize();     // from now on operations carry events (see DevOp)
+    }
+private:
+    bool born = false;
+    void engine_gone()
+    {
+        if (!born) return;
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto it = g_dev.find(device_id);
+        if (it == g_dev.end()) return;
+        auto& v = it->second.recs;
+        for (size_t k = 0; k < v.size(); ++k) if (v[k].eng == this) { v.erase(v.begin() + (long)k); break; }
+    }
+    static bool rec_idle(DevRec& r)
+    {
+        if (r.kind == kOpNone) return true;
+        if (r.enqueuing) return false;
+        const bool done = (!r.done_main || hipEventQuery(r.done_main) == hipSuccess) &&
+                          (!r.done_tiles || hipEventQuery(r.done_tiles) == hipSuccess) &&
+                          (!r.done_side || hipEventQuery(r.done_side) == hipSuccess);
+        (void)hipGetLastError();
+        if (done) r.kind = kOpNone;
+        return done;
+    }
+    bool claim_dev(int kind)
+    {
+        if (!born) return true;
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        DevState& D = g_dev[device_id];
+        DevRec* me = nullptr;
+        int busy = kOpNone;
+        bool others_quiet = true;                // no other handle has called in during the last 20 ms
+        const auto now = std::chrono::steady_clock::now();
+        for (DevRec& r : D.recs) {
+            if (r.eng == this) { me = &r; continue; }
+            if (D.recs.size() > 1 && r.stream != stream) {
+                if (!rec_idle(r)) busy = std::max(busy, r.kind);
+                if (now - r.last_seen < std::chrono::milliseconds(20)) others_quiet = false;
             }
-            o.eng = this;
-            o.done_main = ev_ov_done;
-            o.done_tiles = ev_ov_join;
         }
-        o.enqueuing = true;
+        if (!me) return true;
+        me->last_seen = now;
+        const bool ok = kind == kOpX ? (busy == kOpNone && others_quiet) : (kind == kOpS ? busy < kOpS : busy < kOpX);
+        if (!ok) { ++(kind == kOpS ? n_top_busy : n_ov_busy); return false; }
+        if (D.recs.size() > 1) {
+            if (!ev_dev_done) HIP_CHECK(hipEventCreateWithFlags(&ev_dev_done, hipEventDisableTiming));
+            const bool mine_idle = rec_idle(*me);
+            me->kind = std::max(mine_idle ? (int)kOpNone : me->kind, kind);
+            me->done_main = ev_dev_done; me->done_tiles = ev_ov_join; me->done_side = ev_join;
+        }
+        me->stream = stream;
+        me->enqueuing = true;
+        claimed_kind = kind;
         return true;
     }
-    void ov_enqueued(bool)       // the events that mark this factorisation's end are recorded (or the call was abandoned)
+    int claimed_kind = kOpNone;
+    // the operation is enqueued (recorded = true: mark its end on the main stream) or the call was abandoned
+    void dev_enqueued(bool recorded)
     {
-        std::lock_guard<std::mutex> lk(g_ov_mu);
-        OvOwner& o = g_ov_owner[device_id];
-        if (o.eng == this) o.enqueuing = false;
-    }
-    void release_ov()
-    {
-        std::lock_guard<std::mutex> lk(g_ov_mu);
-        auto it = g_ov_owner.find(device_id);
-        if (it != g_ov_owner.end() && it->second.eng == this) it->second = OvOwner{};
+        if (!born) return;
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        DevState& D = g_dev[device_id];
+        for (DevRec& r : D.recs) {
+            if (r.eng != this) continue;
+            if (recorded && D.recs.size() > 1) {
+                if (!ev_dev_done && hipEventCreateWithFlags(&ev_dev_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); r.enqueuing = false; continue; }
+                (void)hipEventRecord(ev_dev_done, stream);
+                r.kind = std::max(r.kind, claimed_kind);       // (a second handle may have appeared since the admission)
+                r.done_main = ev_dev_done; r.done_tiles = ev_ov_join; r.done_side = ev_join;     // (the streams' events may have been created meanwhile)
+            }
+            r.enqueuing = false;
+        }
     }
 
     // ---- persistent-kernel bookkeeping
-    bool top_claimed = false, top_disabled = false;
-    hipStream_t claimed_stream = nullptr;
-
-    bool claim_top()
-    {
-        if (top_disabled || top_launches == 0) return false;
-        if (top_claimed && claimed_stream == stream) return true;
-        release_top();
-        std::lock_guard<std::mutex> lk(g_top_mu);
-        TopOwner& o = g_top_owner[device_id];
-        if (o.refs == 0) o.stream = stream;
-        if (o.stream != stream) return false;
-        o.refs++;
-        top_claimed = true;
-        claimed_stream = stream;
-        return true;
-    }
-    void release_top()
-    {
-        if (!top_claimed) return;
-        std::lock_guard<std::mutex> lk(g_top_mu);
-        TopOwner& o = g_top_owner[device_id];
-        if (o.refs > 0 && o.stream == claimed_stream) o.refs--;
-        top_claimed = false;
-    }
+    bool top_disabled = false;
 
 public:
     // device word set by the persistent kernel when one of its bounded waits expired (nullptr: no such kernel)
     const int* top_abort_word() const { return (top_flags.p && (top_launches > 0 || chain_from < launches.size())) ? top_flags.p + 2 * top_nflag : nullptr; }
     // The caller has synchronised and found the abort word set: clear it and never use the kernel again.
     int64_t n_ov_fallbacks = 0, n_top_fallbacks = 0;      // lifetime counts (hipkkt_profile, hipkkt_ldl_fallbacks)
-    int64_t n_ov_busy = 0;       // factorisations that went level by level because another handle held the device's overlap claim
+    int64_t n_ov_busy = 0;       // factorisations that were not admitted as class X / M (DevOp) and ran on fewer streams
+    int64_t n_top_busy = 0;      // sweeps that were not admitted as class S and went level by level
     void top_gave_up()
     {
         top_disabled = true;
         chain_disabled = true;       // (the chained launches share the abort word: whichever wait expired, both go)
         ++n_top_fallbacks;
-        release_top();
         launch_zero_ints(top_flags.p + 2 * top_nflag, 1, stream);
         if (d_chain.p) launch_zero_ints(d_chain.p, 2 * S.nsuper, stream);       // (an abandoned sweep leaves counters behind)
         std::fprintf(stderr, "[hipkkt] persistent top-of-tree kernel gave up waiting (GPU shared with another "
@@ -1099,7 +1163,6 @@ public:
     {
         ov_disabled = true;
         ++n_ov_fallbacks;
-        release_ov();
         if (std::getenv("HIPKKT_VERBOSE")) {            // which wait expired first (factor_kernels.hip, ov_wait_ge)
             // (the diagnostic words are plain stores behind the abort's CAS: let the tile stream drain first)
             if (ov_stream) (void)hipStreamSynchronize(ov_stream);
@@ -1221,7 +1284,7 @@ private:
     bool ov_concurrent = false;          // the main and the tile stream run side by side (choose_side_streams)
     DBuf<int> d_ov_prog, d_ov_done, d_ov_ntiles, d_ov_sprog, d_ov_sbase, d_ov_started;
     hipStream_t ov_stream = nullptr;
-    hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr, ev_ov_done = nullptr;
+    hipEvent_t ev_ov_fork = nullptr, ev_ov_join = nullptr, ev_dev_done = nullptr;
     bool ov_join_pending = false;    // ev_ov_join recorded, not yet waited for (enqueue_factor)
     size_t nr_cap = 1;           // right-hand sides xp / uvec are sized for
     int top_grid_nr[2] = {-1, -1};   // the persistent kernel's grid for 2 / 4 right-hand sides (asked on first use)
@@ -2612,8 +2675,8 @@ int hipkkt_ldl_create(hipkkt_ldl_t* out, int64_t N, const int64_t* colptr, const
         std::vector<int> ds((size_t)N);
         for (int64_t i = 0; i < N; ++i) ds[i] = dsigns[i] >= 0 ? 1 : -1;
         h->eng.reset(new LDLEngine((int)N, colptr, rowval, base, ds, h->st));
-        h->eng->device_id = h->device;
         h->eng->stream = h->stream;
+        h->eng->set_device(h->device);
         h->Kval.alloc((size_t)h->nnzK);
         HIP_CHECK(hipMemcpy(h->Kval.p, nzval, (size_t)h->nnzK * sizeof(double), hipMemcpyHostToDevice));
         h->b.alloc((size_t)N);
@@ -2805,8 +2868,8 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
             st.user_perm = uperm.data();
         }
         h->eng.reset(new LDLEngine(K.N, K.colptr.data(), rv.data(), 0, K.dsigns, st));
-        h->eng->device_id = h->device;
         h->eng->stream = h->stream;
+        h->eng->set_device(h->device);
         h->st.user_perm = nullptr;
 
         h->Kval.upload(K.nzval);
@@ -4064,6 +4127,30 @@ int hipkkt_kkt_system_update_scaling(hipkkt_kkt_t h, const double* w, const doub
     return guarded([&]() { return sys_after_update(h); });
 }
 
+int hipkkt_selftest_handover(int variant, int pairs, int words, int rounds, int device, int64_t out[2])
+{
+    return guarded([&]() {
+        if (variant < 0 || variant > 2 || pairs <= 0 || pairs > 96 || words <= 0 || rounds <= 0 || !out)
+            throw ArgError("hipkkt_selftest_handover: bad argument");     // (<= 96 pairs: every workgroup resident, whatever else runs)
+        HIP_CHECK(hipSetDevice(device < 0 ? 0 : device));
+        DBuf<double> payload;
+        DBuf<int> words_i;
+        DBuf<int64_t> counts;
+        payload.alloc((size_t)pairs * words);
+        words_i.alloc((size_t)2 * pairs);
+        counts.alloc(2);
+        HIP_CHECK(hipMemset(payload.p, 0, payload.n * sizeof(double)));
+        HIP_CHECK(hipMemset(words_i.p, 0, words_i.n * sizeof(int)));
+        HIP_CHECK(hipMemset(counts.p, 0, 2 * sizeof(int64_t)));
+        launch_handover_litmus(variant, payload.p, words_i.p, words_i.p + pairs, pairs, words, rounds,
+                               reinterpret_cast<unsigned long long*>(counts.p), reinterpret_cast<unsigned long long*>(counts.p) + 1, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(out, counts.p, 2 * sizeof(int64_t), hipMemcpyDeviceToHost));
+        return HIPKKT_OK;
+    });
+}
+
 int hipkkt_host_register(void* ptr, int64_t bytes)
 {
     return guarded([&]() {
@@ -4431,6 +4518,7 @@ int hipkkt_kkt_profile_get(hipkkt_kkt_t h, hipkkt_profile* out)
         out->overlap_fallbacks = h->eng->n_ov_fallbacks;
         out->top_fallbacks = h->eng->n_top_fallbacks;
         out->overlap_deferrals = h->eng->n_ov_busy;
+        out->top_deferrals = h->eng->n_top_busy;
         return HIPKKT_OK;
     });
 }

@@ -270,6 +270,9 @@ void launch_ov_gate(const int* started, int target, int* abort_word, long long l
 // while that one waited -- i.e. the two streams do not share a hardware queue
 void launch_concurrency_probe(int* word2, hipStream_t first, hipStream_t second);
 size_t panel_lds_bytes(int fmax, int panel_max);
+// litmus test of the hand-over contract (factor_kernels.hip): 2 * pairs workgroups, producer / consumer pairs
+void launch_handover_litmus(int variant, double* payload, int* sig, int* ack, int pairs, int words, int rounds,
+                            unsigned long long* mismatches, unsigned long long* timeouts, hipStream_t st);
 // nr = 1, 2 or 4 right-hand sides per launch (column strides in SolveArgs::ld_*); lds = bytes per right-hand side
 // (rs: the launch's packed records; ignored when SolveArgs::recs is null)
 void launch_fwd(const SolveArgs& a, const RecSeg& rs, int begin, int count, int bs, size_t lds, hipStream_t st, int nr = 1);

@@ -107,6 +107,9 @@ typedef struct {
      * argument needs every other kernel on the device to end by itself).  Not a fallback: no stall, nothing is
      * switched off, the next factorisation asks again. */
     int64_t overlap_deferrals;
+    /* ... and sweeps that took the chained kernels instead of the persistent one for the same reason (one kernel with a
+     * residency requirement per device at a time, whichever handle's). */
+    int64_t top_deferrals;
 } hipkkt_profile;
 
 /* -------------------------------------------------------------------- general */
@@ -281,6 +284,14 @@ int hipkkt_kkt_system_solve_host(hipkkt_kkt_t h, double *lhs_x, double *lhs_s, d
                                  double rhs_tau, double rhs_kappa,
                                  const double *var_x, const double *var_s, const double *var_z,
                                  double var_tau, double var_kappa, int steptype);
+
+/* Self-test of the hand-over protocol by which kernels that run side by side pass data (persistent / chained sweep
+ * kernels, the factorisation's overlap mode; contract stated in csrc/factor_kernels.hip): `pairs` producer / consumer
+ * workgroup pairs on different XCDs hand `words` doubles over `rounds` times.  variant 0 = the contract; 1 = without the
+ * producer's s_waitcnt before its signal; 2 = with plain instead of agent-scope payload accesses.  out[0] = payload words
+ * read stale, out[1] = expired waits.  Test infrastructure (tests/test_gpu_parity.py::test_handover_litmus): variant 0
+ * must give (0, 0). */
+int hipkkt_selftest_handover(int variant, int pairs, int words, int rounds, int device, int64_t out[2]);
 
 /* Page-lock a host array the caller keeps for the solver's lifetime (an interior-point method's work vectors:
  * DefaultVariables, the right-hand sides, the cones' w / lambda) so that the copies of the *_host entry points run at

@@ -1,5 +1,5 @@
 """The boundary is a C ABI: a plain C program (tests/c_abi/kkt_from_c.c -- no Python, no torch) builds against
-include/hipkkt.h, links libhipkkt.so and drives level B the way a ccall / cgo / JNI binding would."""
+include/hipkkt.h, links libhipkkt.so and drives levels A, B and C (lazy, host vectors) the way a ccall / cgo / JNI binding would."""
 import os
 import subprocess
 
@@ -28,7 +28,7 @@ def test_header_compiles_and_links_from_plain_c():
 
 
 @pytest.mark.gpu
-def test_level_B_driven_from_plain_c():
+def test_levels_A_B_C_driven_from_plain_c():
     _build()
     p = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr

@@ -415,24 +415,57 @@ def test_two_handles_on_their_own_streams_driven_concurrently():
         assert sol[i].fallbacks == (0, 0), (i, sol[i].fallbacks, sol[i].profile())
 
 
+def test_handover_litmus():
+    """The protocol by which kernels running side by side hand data over (k_top_solve, the chained sweep kernels, the
+    factorisation's overlap mode; contract in csrc/factor_kernels.hip): payload as relaxed agent-scope (sc1) stores,
+    s_waitcnt vmcnt(0), ONE relaxed agent-scope signal; the consumer polls, then reads with relaxed agent-scope loads --
+    no release / acquire fence anywhere.  hipkkt_selftest_handover runs it on producer / consumer workgroup pairs placed
+    on different XCDs: with the contract NO payload word may ever be read stale.  The two weakened variants show what
+    the contract's parts are for: their stale reads are reported, and the plain-access variant is REQUIRED to show them (a
+    litmus test that passed whatever the protocol would not be testing anything): on this part every word read through
+    plain loads from another XCD's producer is stale.  The variant without the s_waitcnt has never shown a stale word here
+    (the memory side performs one wave's stores in order in practice); the instruction stays because nothing in the ISA
+    promises that order across addresses -- the comment in factor_kernels.hip says which guarantee each part rests on."""
+    from cuclarabel_amd import _lib
+    import ctypes as C
+
+    def run(variant, pairs=64, words=4096, rounds=400):
+        out = (C.c_int64 * 2)()
+        rc = _lib.lib().hipkkt_selftest_handover(variant, pairs, words, rounds, 0, out)
+        assert rc == 0, _lib.lib().hipkkt_last_error().decode()
+        return int(out[0]), int(out[1])
+    stale, expired = run(0)
+    assert (stale, expired) == (0, 0), (stale, expired)
+    stale, expired = run(0, pairs=96, words=257, rounds=2000)          # short payloads, many rounds: the signal chases the data
+    assert (stale, expired) == (0, 0), (stale, expired)
+    no_wait = run(1)
+    plain = run(2)
+    print("hand-over litmus: without s_waitcnt %s, with plain accesses %s (stale words, expired waits)" % (no_wait, plain))
+    assert no_wait[1] == 0 and plain[1] == 0
+    assert plain[0] > 0, "plain payload accesses produced no stale read: the litmus test does not discriminate"
+
+
 def test_concurrent_handles_of_mode_problems_take_no_fallback():
     """`bench.py --mode problems` drives three block-diagonal handles concurrently (a stream and a host thread each) with
-    NO environment setting: the library admits one overlapped factorisation per device at a time and hands the sweeps of
-    the handles without the persistent kernel's claim to the chained kernels.  No bounded wait may expire (until round 3
-    every handle took the overlap mode's 50 ms give-up once unless the process set HIPKKT_FACTOR_OVERLAP=0)."""
+    NO environment setting: the library admits one operation whose kernels wait for other workgroups (overlapped
+    factorisation, persistent / chained sweep) per device at a time; a handle that finds the device's token busy runs that
+    operation level by level.  No bounded wait may expire (until round 3 every handle took the overlap mode's 50 ms
+    give-up once unless the process set HIPKKT_FACTOR_OVERLAP=0), in any of several runs: the give-ups this test was
+    written against showed up in about one run in five."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k != "HIPKKT_FACTOR_OVERLAP"}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "problems", "--problems", "24", "--n", "4000",
-                        "--steps", "4", "--warmup", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
-    row = json.loads(r.stdout.strip().splitlines()[-1])
-    assert row["config"]["handles_per_rank"] == 3 and row["config"]["handles_driven"].startswith("concurrently"), row["config"]
-    assert row["config"]["fallbacks"] == [0, 0], row["config"]
-    assert "gave up" not in r.stderr, r.stderr
+    for rep in range(3):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "problems", "--problems", "24", "--n", "4000",
+                            "--steps", "6", "--warmup", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        row = json.loads(r.stdout.strip().splitlines()[-1])
+        assert row["config"]["handles_per_rank"] == 3 and row["config"]["handles_driven"].startswith("concurrently"), row["config"]
+        assert row["config"]["fallbacks"] == [0, 0], (rep, row["config"])
+        assert "gave up" not in r.stderr, r.stderr
 
 
 def test_block_diagonal_batch_equals_the_individual_problems():
