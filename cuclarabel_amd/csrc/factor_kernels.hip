@@ -18,6 +18,7 @@
 // Loads are issued in explicit batches before first use: a one-load-then-use loop serialises
 // on HBM/L2 latency (the first version of these kernels ran 10x slower for that reason).
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include <utility>
 
 namespace hipkkt {
@@ -1145,8 +1146,8 @@ void launch_schur(const FactorArgs& a, const int2* tiles, int tile_begin, int nt
     // (the pipelined chunk loop outside the overlap mode: launches of thousands of tiles whose products are four chunks deep
     //  or more -- the trailing blocks of very large fronts, cfg5's wide levels; on cfg2's wide middle levels, one to three
     //  chunks per tile, its registers cost more than the latency it hides, see k_schur)
-    static const int pipe_tiles = std::getenv("HIPKKT_SCHUR_PIPE_TILES") ? std::atoi(std::getenv("HIPKKT_SCHUR_PIPE_TILES")) : 1600;
-    static const int pipe_nc = std::getenv("HIPKKT_SCHUR_PIPE_NC") ? std::atoi(std::getenv("HIPKKT_SCHUR_PIPE_NC")) : 64;
+    const int pipe_tiles = knobs().schur_pipe_tiles;
+    const int pipe_nc = knobs().schur_pipe_nc;
     if (a.ov) hipLaunchKernelGGL((k_schur<true, true>), dim3(std::max(1, std::min(ntiles, ov_grid))), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
     else if (ntiles > pipe_tiles && tile_nc >= pipe_nc) hipLaunchKernelGGL((k_schur<false, true>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);
     else hipLaunchKernelGGL((k_schur<false, false>), dim3(ntiles), dim3(256), 0, st, a, tiles, tile_begin, ntiles);

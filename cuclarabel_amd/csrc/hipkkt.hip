@@ -22,12 +22,21 @@
 #include "kernels.hpp"
 #include "kkt_assembly.hpp"
 #include "symbolic.hpp"
+#include "knobs.hpp"
 
 namespace hipkkt {
 
 static thread_local std::string g_last_error;
 
 struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// the panel-shape settings of knobs.hpp over SymbolicOptions' defaults
+static void apply_knobs(SymbolicOptions& opt)
+{
+    if (knobs().panel_cap >= 0) opt.panel_cap = knobs().panel_cap;
+    if (knobs().panel_max_cols >= 0) opt.panel_max_cols = knobs().panel_max_cols;
+    if (knobs().panel_slice_below >= 0) opt.panel_slice_below = knobs().panel_slice_below;
+}
 
 #define HIP_CHECK(expr)                                                                          \
     do {                                                                                         \
@@ -82,10 +91,9 @@ struct Launch {
 
 static constexpr size_t kLdsCap = 160 * 1024 - 512;
 static constexpr int kMaxNR = 4;          // right-hand sides the single-column solve path takes in one sweep (1, 2 or 4)
-static const size_t kWinvTailLaunches = std::getenv("HIPKKT_WINV_TAIL") ? (size_t)std::atoi(std::getenv("HIPKKT_WINV_TAIL")) : 4;
-static const size_t kWinvEarlyLaunches = std::getenv("HIPKKT_WINV_EARLY") ? (size_t)std::atoi(std::getenv("HIPKKT_WINV_EARLY")) : 1;
+// (environment settings: knobs.hpp -- one table, read once per process)
 // grid of the side-stream W formation while the tree is still being factorised: 3/8 of the CUs (96 of 256) unless set
-static const int kSideWinvBlocksEnv = std::getenv("HIPKKT_WINV_BLOCKS") ? std::atoi(std::getenv("HIPKKT_WINV_BLOCKS")) : 0;
+
 
 // WHAT MAY RUN BESIDE WHAT ON ONE DEVICE, ACROSS HANDLES.  Three mechanisms of this library put kernels on the device
 // whose workgroups WAIT for other workgroups: the factorisation's overlap mode (panel workgroups that hold a CU each
@@ -151,9 +159,7 @@ public:
         opt.amd_dense_scale = st.amd_dense_scale > 0 ? st.amd_dense_scale : 1.5;
         if (st.nd_leaf_size > 0) opt.nd_leaf_size = st.nd_leaf_size;
         opt.user_perm = st.user_perm;
-        if (const char* pc = std::getenv("HIPKKT_PANEL_CAP")) opt.panel_cap = std::atoll(pc);
-        if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
-        if (const char* pc = std::getenv("HIPKKT_PANEL_SLICE_BELOW")) opt.panel_slice_below = std::atoi(pc);
+        apply_knobs(opt);
         // user_perm arrives in the caller's index base; analyse() applies `base` to it
         analyse(N, colptr, rowval, base, opt, S);
         panel_cap = opt.panel_cap;
@@ -162,7 +168,7 @@ public:
         dyn_delta = st.dynamic_regularization_delta;
         build_schedule();
         upload(dsigns);
-        if (std::getenv("HIPKKT_VERBOSE")) {
+        if (knobs().verbose) {
             int nblock = 0, nsl_fronts = 0, ov_slices = 0;
             for (const Launch& L : launches) if (!L.small) { nblock += L.count; nsl_fronts += L.nsliced; }
             if (overlap_wanted()) for (size_t q = ov_first; q < launches.size(); ++q) ov_slices += launches[q].slice_count;
@@ -177,7 +183,7 @@ public:
                 for (const Launch& L : launches) ntall_all += L.ntall;
                 if (ntall_all) std::fprintf(stderr, "[hipkkt] %d fronts too tall for the block sweep kernels (k_fwd_tall / k_bwd_tall)\n", ntall_all);
             }
-            if (std::atoi(std::getenv("HIPKKT_VERBOSE")) >= 2)
+            if (knobs().verbose >= 2)
                 for (size_t q = 0; q < launches.size(); ++q) {
                     const Launch& L = launches[q];
                     int fmin = 1 << 30, ncmin = 1 << 30;
@@ -203,10 +209,10 @@ public:
     // hipGraphs and replayed (HIPKKT_GRAPH=1), with the T = L11^{-1} kernels on a parallel branch.
     void factor(const double* d_Kval, const double* d_eps)
     {
-        static const bool want_stamps = std::getenv("HIPKKT_STAMPS") != nullptr;
+        const bool want_stamps = knobs().stamps;
         // measured on MI355X/ROCm 7.2: replay is ~25 % slower than eager launches for these ~100-node
         // chains (the work is GPU-latency-bound, not host-bound), so graphs are opt-in
-        static const bool no_graph = std::getenv("HIPKKT_GRAPH") == nullptr;
+        const bool no_graph = !knobs().graph;
         if (want_stamps || no_graph || n_factor_calls++ == 0) {
             enqueue_factor(d_Kval, d_eps, stream, nullptr, want_stamps);
             return;
@@ -232,7 +238,7 @@ public:
     // nr = 1, 2 or 4 right-hand sides in ONE sweep (column c at d_b + c ldb / d_x + c ldx): see supports_nr().
     void solve(const double* d_b, double* d_x, bool allow_top = false, int nr = 1, int64_t ldb = 0, int64_t ldx = 0)
     {
-        static const bool no_graph = std::getenv("HIPKKT_GRAPH") == nullptr;
+        const bool no_graph = !knobs().graph;
         if (nr > 1) {
             if (!supports_nr(nr)) throw ArgError("solve: this structure takes one right-hand side per sweep");
             reserve_nr(nr);
@@ -440,7 +446,7 @@ private:
             // (HIPKKT_OV_CU_MASK=1 confines the tile stream to every other CU.  Measured: on this stack a CU-masked
             // stream slows EVERY stream of the process down as if all of them were masked -- residual 0.032 -> 0.054 ms,
             // sweep 0.29 -> 0.37 ms -- so the default is a plain stream.)
-            static const bool cu_mask = std::getenv("HIPKKT_OV_CU_MASK") != nullptr;
+            const bool cu_mask = knobs().ov_cu_mask;
             hipDeviceProp_t prop;
             HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
             std::vector<uint32_t> mask((size_t)std::max((prop.multiProcessorCount + 31) / 32, 1), 0x55555555u);
@@ -457,7 +463,7 @@ private:
                 HIP_CHECK(hipEventCreateWithFlags(&ev_ov_fork, hipEventDisableTiming));
                 HIP_CHECK(hipEventCreateWithFlags(&ev_ov_join, hipEventDisableTiming));
             }
-            if (ov_stream && !ov_concurrent && std::getenv("HIPKKT_VERBOSE"))
+            if (ov_stream && !ov_concurrent && knobs().verbose)
                 std::fprintf(stderr, "[hipkkt] the main and the tile stream share a hardware queue: no merged panel kernel for this handle\n");
         }
         ensure_capture_streams();
@@ -465,7 +471,7 @@ private:
             std::vector<hipStream_t> beside{st};
             if (ov_stream) beside.push_back(ov_stream);
             cap_side = stream_beside(cap_side, beside, plain, &side_concurrent);
-            if (!side_concurrent && std::getenv("HIPKKT_VERBOSE"))
+            if (!side_concurrent && knobs().verbose)
                 std::fprintf(stderr, "[hipkkt] no stream beside the main stream for the W formation: it will run in submission order\n");
         }
         sides_for = st;
@@ -496,7 +502,7 @@ private:
         // its kernels wait across streams) or, failing that, the side stream's W formation with its fork / join events
         // (class M).  Not admitted, it keeps to its main stream, where every packet depends on earlier packets of the same
         // stream only.
-        static const bool no_overlap = std::getenv("HIPKKT_NO_OVERLAP") != nullptr;
+        const bool no_overlap = knobs().no_overlap;
         const bool side_w = !side && !no_overlap && !want_stamps && late_launches > 0 && late_launches < launches.size();
         const bool tok_x = use_ov && claim_dev(kOpX);
         const bool tok = tok_x || (side_w && claim_dev(kOpM));
@@ -537,7 +543,7 @@ private:
         a.ov_prog = d_ov_prog.p; a.ov_done = d_ov_done.p; a.ov_ntiles = d_ov_ntiles.p; a.ov = 0;
         a.ov_sprog = d_ov_sprog.p; a.ov_sbase = d_ov_sbase.p;
         a.ov_started = d_ov_started.p; a.ov_slot = 0;
-        static const long long ov_limit = std::getenv("HIPKKT_OV_TEST_LIMIT") ? std::atoll(std::getenv("HIPKKT_OV_TEST_LIMIT")) : 5000000;
+        const long long ov_limit = knobs().ov_test_limit;
         a.ov_limit = ov_limit;
         a.stamps = nullptr;
         a.stamp_row = 0;
@@ -584,9 +590,9 @@ private:
             //  formed beside the run.  With the last run's start as the only late fork, cfg3 and cfg5 formed the W of their
             //  widest levels behind the tree and the first sweep waited for it: 0.1 and 0.37 ms per step)
             const bool runs = ov_on && merge_from < nl;
-            const size_t tail_fork = runs ? nl : (nl >= kWinvTailLaunches ? nl - kWinvTailLaunches : 0);
+            const size_t tail_fork = runs ? nl : (nl >= (size_t)std::max(0, knobs().winv_tail) ? nl - (size_t)std::max(0, knobs().winv_tail) : 0);
             const MergeGroup* gq = runs ? group_of(q) : nullptr;
-            static const bool run_forks = !(std::getenv("HIPKKT_WINV_RUN_FORKS") && std::atoi(std::getenv("HIPKKT_WINV_RUN_FORKS")) == 0);
+            const bool run_forks = knobs().winv_run_forks;
             const bool run_first = gq && gq->first == q && (run_forks || q == merge_from);
             // (a fork point inside a merged run moves to the run's first launch: an event recorded behind the run's kernel
             //  would wait for the whole run)
@@ -595,7 +601,7 @@ private:
                 const MergeGroup* g = ov_on ? group_of(want) : nullptr;
                 return g ? g->first : want;
             };
-            const bool fork_here = first_top < nl && (q == fork_at(first_top >= kWinvEarlyLaunches ? first_top - kWinvEarlyLaunches : nl) ||
+            const bool fork_here = first_top < nl && (q == fork_at(first_top >= (size_t)std::max(0, knobs().winv_early) ? first_top - (size_t)std::max(0, knobs().winv_early) : nl) ||
                                                       q == fork_at(first_top) || (q > first_top && (run_first || q == tail_fork)));
             if (fork_here && launches[q].tinv_begin > w_done) {
                 ensure_capture_streams();
@@ -746,18 +752,18 @@ private:
         a.out = d_x;
         a.xp = xp.p;
         a.uvec = uvec.p;
-        static const long long top_limit = std::getenv("HIPKKT_TOP_TEST_LIMIT") ? std::atoll(std::getenv("HIPKKT_TOP_TEST_LIMIT")) : 5000000;
+        const long long top_limit = knobs().top_test_limit;
         a.top_limit = top_limit;
         // diagnostic (HIPKKT_TOP_STAMPS=n): the n-th single-column sweep over the full persistent set records eight time
         // stamps per front and direction, printed per level afterwards (this call then synchronises)
-        static const int stamp_call = std::getenv("HIPKKT_TOP_STAMPS") ? std::atoi(std::getenv("HIPKKT_TOP_STAMPS")) : 0;
+        const int stamp_call = knobs().top_stamps;
         a.top_stamps = nullptr;
         bool stamp_now = false;
         a.ld_b = ldb; a.ld_out = ldx; a.ld_xp = S.N; a.ld_uvec = (int64_t)std::max<size_t>(S.rows.size(), 1);
         a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p; a.add = nullptr;
         a.chain_cnt = nullptr;       // (set below when this sweep chains its lower levels)
         a.recs = d_recs.p ? reinterpret_cast<const char*>(d_recs.p) : nullptr;
-        static const bool no_top = std::getenv("HIPKKT_NO_TOP") != nullptr;
+        const bool no_top = knobs().no_top;
         if (nr > 1 && top_ntask > 0 && (no_top || !use_top || top_disabled || top_sgrid2 <= 0)) {
             // two columns through a set with very tall fronts need its persistent kernel (supports_nr): without it, one
             // column after the other
@@ -776,8 +782,8 @@ private:
         // chain_from and the set are chained (cfg2: levels 3 and 4, 32 -> 26 us forward).  Both need the device's token
         // (allow_chain / use_top: the caller holds it).  HIPKKT_CHAIN=0: off; HIPKKT_CHAIN_TOP=0: chain to the root
         // instead of the persistent kernel (measured: cfg2's sweep pair 0.2675 against 0.260 ms).
-        static const bool chain_env = !(std::getenv("HIPKKT_CHAIN") && std::atoi(std::getenv("HIPKKT_CHAIN")) == 0);
-        static const bool chain_top = !(std::getenv("HIPKKT_CHAIN_TOP") && std::atoi(std::getenv("HIPKKT_CHAIN_TOP")) == 0);
+        const bool chain_env = knobs().chain;
+        const bool chain_top = knobs().chain_top;
         // (a set with very tall fronts keeps its (front, slice) kernel: such fronts do not fit one workgroup's LDS)
         const bool chain_want = chain_env && allow_chain && !chain_disabled && chain_from < nl && chain_lds * (size_t)nr <= 150 * 1024;
         const bool keep_top = chain_want && (chain_top || top_ntask > 0);
@@ -791,7 +797,7 @@ private:
         const bool chain_on = chain_want && chain_from + 2 <= nl - ntl;
         const size_t nper = chain_on ? chain_from : nl - ntl;        // launches [0, nper) go level by level, [nper, nl - ntl) chained
         // a level's block-class launch and the one-wave launch behind it (sched order) go out as one launch
-        static const bool no_merge = std::getenv("HIPKKT_NO_LEVEL_MERGE") != nullptr;
+        const bool no_merge = knobs().no_level_merge;
         auto pair_at = [&](size_t q) {      // launches q (block-class) and q + 1 (one-wave) belong to one level
             return !no_merge && q + 1 < nper && !launches[q].small && launches[q].ntall == 0 && launches[q + 1].small &&
                    launches[q].level == launches[q + 1].level;
@@ -916,7 +922,7 @@ private:
                     }
                 }
             } else {
-                static const int stamp_nr = std::getenv("HIPKKT_TOP_STAMPS_NR") ? std::atoi(std::getenv("HIPKKT_TOP_STAMPS_NR")) : 1;
+                const int stamp_nr = knobs().top_stamps_nr;
                 if (stamp_call > 0 && !chain_on && nr == stamp_nr && ntl == top_launches && ++n_stamp_sweeps == stamp_call) {
                     top_stamps.alloc((size_t)2 * ncount * 8);
                     top_stamps.zero(st);
@@ -1163,7 +1169,7 @@ public:
     {
         ov_disabled = true;
         ++n_ov_fallbacks;
-        if (std::getenv("HIPKKT_VERBOSE")) {            // which wait expired first (factor_kernels.hip, ov_wait_ge)
+        if (knobs().verbose) {            // which wait expired first (factor_kernels.hip, ov_wait_ge)
             // (the diagnostic words are plain stores behind the abort's CAS: let the tile stream drain first)
             if (ov_stream) (void)hipStreamSynchronize(ov_stream);
             int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1219,8 +1225,7 @@ public:
     }
     static bool overlap_wanted()
     {
-        static const bool v = !(std::getenv("HIPKKT_FACTOR_OVERLAP") && std::atoi(std::getenv("HIPKKT_FACTOR_OVERLAP")) == 0);
-        return v;
+        return knobs().factor_overlap;
     }
     bool ov_active() const { return overlap_wanted() && !ov_disabled && ov_first < launches.size(); }
 
@@ -1324,7 +1329,7 @@ private:
     // (HIPKKT_SOLVE_TALL_ROWS=n: fronts of n rows or more count as tall as well -- the tests' way to those paths)
     bool front_is_tall(int s) const
     {
-        static const int tall_rows = std::getenv("HIPKKT_SOLVE_TALL_ROWS") ? std::atoi(std::getenv("HIPKKT_SOLVE_TALL_ROWS")) : 0;
+        const int tall_rows = knobs().solve_tall_rows;
         const int f = front_size(s), nc = S.sn_start[s + 1] - S.sn_start[s];
         return solve_lds_bytes(f, nc) > kLdsCap || (tall_rows > 0 && f >= tall_rows);
     }
@@ -1359,13 +1364,13 @@ private:
             }
             // a handful of one-wave fronts beside a block-class launch is not worth launches of its own (one in the
             // factorisation, two per solve, each ~5-45 us of pure latency): they ride with the block-class fronts
-            static const int merge_small = std::getenv("HIPKKT_MERGE_SMALL") ? std::atoi(std::getenv("HIPKKT_MERGE_SMALL")) : 128;
+            const int merge_small = knobs().merge_small;
             if (!big.empty() && (int)small.size() <= merge_small) {
                 big.insert(big.end(), small.begin(), small.end());
                 small.clear();
             }
-            static const int slice_rows = std::getenv("HIPKKT_SLICE_ROWS") ? std::atoi(std::getenv("HIPKKT_SLICE_ROWS")) : 128;
-            static const bool slice_fit = !(std::getenv("HIPKKT_SLICE_FIT") && std::atoi(std::getenv("HIPKKT_SLICE_FIT")) == 0);
+            const int slice_rows = knobs().slice_rows;
+            const bool slice_fit = knobs().slice_fit;
             int level_slice_rows = slice_rows;
             auto slices_of = [&](int s) {        // row slices the panel kernel needs for this front (1: fits one CU)
                 if (panel_cap <= 0) return 1;
@@ -1473,8 +1478,8 @@ private:
                 }
                 L.fmax = fmax;
                 L.ncmax = ncmax;
-                static const int small_bs_count = std::getenv("HIPKKT_BS128_COUNT") ? std::atoi(std::getenv("HIPKKT_BS128_COUNT")) : 1024;
-                static const int small_bs_f = std::getenv("HIPKKT_BS128_F") ? std::atoi(std::getenv("HIPKKT_BS128_F")) : 128;
+                const int small_bs_count = knobs().bs128_count;
+                const int small_bs_f = knobs().bs128_f;
                 L.solve_bs = (L.count >= small_bs_count && fmax <= small_bs_f) ? 128 : 256;
                 L.tinv_begin = (int)tinv_list.size();
                 L.tinv_ncmax = 1;
@@ -1515,8 +1520,8 @@ private:
     // that front's height for every front --: the legacy layout.
     void build_records(const std::vector<int64_t>& glptr, const std::vector<int>& gsrc)
     {
-        static const bool packed_on = !(std::getenv("HIPKKT_PACKED") && std::atoi(std::getenv("HIPKKT_PACKED")) == 0);
-        static const int64_t max_mb = std::getenv("HIPKKT_PACKED_MAX_MB") ? std::atoll(std::getenv("HIPKKT_PACKED_MAX_MB")) : 4096;
+        const bool packed_on = knobs().packed;
+        const int64_t max_mb = knobs().packed_max_mb;
         for (Launch& L : launches) L.rec = RecSeg{};
         if (!packed_on) return;
         static_assert(sizeof(SolveHdr) == 64, "SolveHdr layout");
@@ -1554,7 +1559,7 @@ private:
         }
         if (total > max_mb * (1 << 20)) {
             for (Launch& L : launches) L.rec = RecSeg{};
-            if (std::getenv("HIPKKT_VERBOSE")) std::fprintf(stderr, "[hipkkt] packed sweep records would take %.0f MB: legacy layout\n", total / 1048576.0);
+            if (knobs().verbose) std::fprintf(stderr, "[hipkkt] packed sweep records would take %.0f MB: legacy layout\n", total / 1048576.0);
             return;
         }
         std::vector<int64_t> store((size_t)(total / 8) + 8, 0);
@@ -1598,14 +1603,14 @@ private:
         }
         store.resize((size_t)(total / 8) + 8);
         d_recs.upload(store);
-        if (std::getenv("HIPKKT_VERBOSE")) std::fprintf(stderr, "[hipkkt] packed sweep records: %.1f MB\n", total / 1048576.0);
+        if (knobs().verbose) std::fprintf(stderr, "[hipkkt] packed sweep records: %.1f MB\n", total / 1048576.0);
     }
 
     void upload(const std::vector<int>& dsigns)
     {
         // leaves with one column and a short row list, pulled by their parents in the many-column sweeps (see the gather
         // lists below; HIPKKT_PULL_LEAVES=0: none)
-        static const bool pull_on = !(std::getenv("HIPKKT_PULL_LEAVES") && std::atoi(std::getenv("HIPKKT_PULL_LEAVES")) == 0);
+        const bool pull_on = knobs().pull_leaves;
         std::vector<char> pulled((size_t)S.nsuper, 0);
         {
             std::vector<char> in_small((size_t)S.nsuper, 0);       // (one-wave launches only: the block kernels do not know the flag)
@@ -1695,11 +1700,11 @@ private:
                 int dev = 0;
                 hipDeviceProp_t prop;
                 if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
-                side_winv_blocks = kSideWinvBlocksEnv > 0 ? kSideWinvBlocksEnv : std::max(8, n_cus * 3 / 8);
+                side_winv_blocks = knobs().winv_blocks > 0 ? knobs().winv_blocks : std::max(8, n_cus * 3 / 8);
             }
             constexpr int kOvMargin = 8;
             // (the environment override is per process, the default per handle: n_cus is this handle's device's)
-            static const int ov_max_env = std::getenv("HIPKKT_OV_MAX_FRONTS") ? std::atoi(std::getenv("HIPKKT_OV_MAX_FRONTS")) : 0;
+            const int ov_max_env = knobs().ov_max_fronts;
             const int ov_max = std::min(ov_max_env > 0 ? ov_max_env : 120 * n_cus / 256, n_cus - 1 - kOvMargin);
             auto panel_wgs = [&](const Launch& L) { return L.count - L.nsliced + L.slice_count; };   // whole panels + row slices
             size_t first = launches.size();
@@ -1715,7 +1720,7 @@ private:
             // 1080 tiles 6.25 / 6.45 ms, 1279 tiles 3.17 / 3.65, 1145 tiles 3.74 / 3.72 | 2310 tiles 18.6 / 17.6,
             // 2428 tiles 9.5 / 8.2, 4253 tiles 10.0 / 7.8, 13 041 tiles 54 / 27, cfg2 with 1 % long-range couplings
             // (24 000 tiles) 143 / 61 ms.  (cfg2's overlapped launches have at most 418 tiles, cfg5's 630.)
-            static const int ov_max_tiles = std::getenv("HIPKKT_OV_MAX_TILES") ? std::atoi(std::getenv("HIPKKT_OV_MAX_TILES")) : 1600;
+            const int ov_max_tiles = knobs().ov_max_tiles;
             bool heavy_tiles = false;
             for (size_t q = first; q < launches.size(); ++q) heavy_tiles = heavy_tiles || launches[q].ntiles > ov_max_tiles;
             ov_first = (!heavy_tiles && launches.size() - first >= 3) ? first : launches.size();
@@ -1726,9 +1731,9 @@ private:
                 // launch in a run has at most ov_merge_wide workgroups (HIPKKT_OV_MERGE_WIDE: the workgroups of a run hold
                 // their CUs from the start of the run, which the tiles of a WIDE level below them would miss), and the first
                 // overlapped launch is in none (its tiles are released by an event).
-                static const int ov_merge_max = std::getenv("HIPKKT_OV_MERGE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE")) : 100;
-                static const int ov_merge_wide = std::getenv("HIPKKT_OV_MERGE_WIDE") ? std::atoi(std::getenv("HIPKKT_OV_MERGE_WIDE")) : 24;
-                static const int ov_merge_groups = std::getenv("HIPKKT_OV_MERGE_GROUPS") ? std::atoi(std::getenv("HIPKKT_OV_MERGE_GROUPS")) : 8;
+                const int ov_merge_max = knobs().ov_merge;
+                const int ov_merge_wide = knobs().ov_merge_wide;
+                const int ov_merge_groups = knobs().ov_merge_groups;
                 ov_groups.clear();
                 ov_group_of.assign(launches.size(), -1);
                 size_t m = launches.size();
@@ -1843,14 +1848,14 @@ private:
             {
                 size_t lds = 0;
                 for (size_t q = launches.size(); q-- > 0 && !launches[q].small;) lds = std::max(lds, launches[q].lds_solve);
-                static const int tall_env = std::getenv("HIPKKT_TOP_TALL") ? std::atoi(std::getenv("HIPKKT_TOP_TALL")) : -1;
+                const int tall_env = knobs().top_tall;
                 top_tall = tall_env != 0;           // the 1024-thread build unless HIPKKT_TOP_TALL=0 (solve_kernels.hip)
-                static const int cap_env = std::getenv("HIPKKT_TOP_CAP") ? std::atoi(std::getenv("HIPKKT_TOP_CAP")) : 1 << 30;
+                const int cap_env = knobs().top_cap;
                 const int cap = std::min(std::min(kTopMaxFronts, cap_env), top_solve_capacity(lds, top_tall));
                 for (size_t q = launches.size(); q-- > 0;) {
                     const Launch& L = launches[q];
                     // (measured on cfg2 with 240 workgroups: x1 0.313, x1.25-1.7 0.307, x2.5 0.319, x6 0.346 ms per solve)
-                    static const double mult = std::getenv("HIPKKT_TOP_MULT") ? std::atof(std::getenv("HIPKKT_TOP_MULT")) : 1.5;
+                    const double mult = knobs().top_mult;
                     if (L.small || L.count > mult * cap) break;
                     top_count += L.count;
                     top_lds = std::max(top_lds, L.lds_solve);
@@ -1867,10 +1872,9 @@ private:
                 // (r03, cfg5: slices of ~80 KB, at most 16, instead of ~120 KB / 8: sweep pair 0.765 -> 0.729 ms; 60 KB / 16 and
                 //  40 KB / 32: 0.74 -- a hop is mostly its fixed latencies by then.  A front is sliced when its W exceeds
                 //  HIPKKT_SOLVE_SLICE_FROM KB, by default 4.5 slices' worth: cfg3's 395 KB fronts are faster whole)
-                static const int slice_kb = std::getenv("HIPKKT_SOLVE_SLICE_KB") ? std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_KB")) : 80;
-                static const int slice_max = std::getenv("HIPKKT_SOLVE_SLICE_MAX") ? std::max(1, std::min(64, std::atoi(std::getenv("HIPKKT_SOLVE_SLICE_MAX")))) : 16;
-                static const int64_t slice_from = std::getenv("HIPKKT_SOLVE_SLICE_FROM") ? std::atoll(std::getenv("HIPKKT_SOLVE_SLICE_FROM")) * 1024
-                                                                                        : (int64_t)slice_kb * 1024 * 9 / 2;
+                const int slice_kb = knobs().solve_slice_kb;
+                const int slice_max = std::max(1, std::min(64, knobs().solve_slice_max));
+                const int64_t slice_from = knobs().solve_slice_from >= 0 ? knobs().solve_slice_from * 1024 : (int64_t)slice_kb * 1024 * 9 / 2;
                 std::vector<int> tp, ts;
                 h_tbase.assign((size_t)top_count + 1, 0);
                 const int b0 = top_launches ? launches[launches.size() - top_launches].begin : 0;
@@ -1923,7 +1927,7 @@ private:
             // levels below are throughput-bound: a launch each costs them little, while their thousands of waiting
             // workgroups would crowd a chained grid), every front of which fits the chained kernels' LDS
             {
-                static const int chain_max = std::getenv("HIPKKT_CHAIN_MAX") ? std::atoi(std::getenv("HIPKKT_CHAIN_MAX")) : 640;
+                const int chain_max = knobs().chain_max;
                 size_t q = launches.size();
                 while (q > 0) {
                     const Launch& L = launches[q - 1];
@@ -1989,7 +1993,7 @@ private:
                     }
             }
             if (S.rows.size() >= ((size_t)1 << 31)) throw std::runtime_error("row structure exceeds int32 indexing");
-            if (std::getenv("HIPKKT_VERBOSE") && std::atoi(std::getenv("HIPKKT_VERBOSE")) >= 2 && top_launches > 0) {
+            if (knobs().verbose >= 2 && top_launches > 0) {
                 // gather-list lengths of the rows of the persistent solve set (what k_top_solve's parked indices must cover)
                 long hist[6] = {0, 0, 0, 0, 0, 0};
                 long fronts_over8 = 0, fronts_over12 = 0, nf = 0;
@@ -2023,7 +2027,7 @@ private:
             // dense block (coalesced loads, no descriptors, no row lookups); its pieces stay out of both lists.
             std::vector<int> dense_child((size_t)S.nsuper, -1);
             std::vector<int64_t> dense_off((size_t)S.nsuper, -1);
-            static const bool dense_on = !(std::getenv("HIPKKT_DENSE_CHILD") && std::atoi(std::getenv("HIPKKT_DENSE_CHILD")) == 0);
+            const bool dense_on = knobs().dense_child;
             int64_t n_dense = 0;
             for (int p = 0; dense_on && p < S.nsuper; ++p) {
                 if (tile_base[p] < 0) continue;                              // block-class parents only
@@ -2042,7 +2046,7 @@ private:
                 }
             }
             d_dense_off.upload(dense_off);
-            if (std::getenv("HIPKKT_VERBOSE")) std::fprintf(stderr, "[hipkkt] dense children: %lld\n", (long long)n_dense);
+            if (knobs().verbose) std::fprintf(stderr, "[hipkkt] dense children: %lld\n", (long long)n_dense);
             std::vector<int64_t> pptr((size_t)S.N + 1, 0);
             for (int c = 0; c < S.nsuper; ++c) {
                 int p = S.sn_parent[c];
@@ -2131,8 +2135,8 @@ private:
             std::memcpy(raw.data(), items.data(), items.size() * sizeof(ExtItem));
             d_items.upload(raw);
             d_wave_cut.upload(wcut);
-            if (const char* vb = std::getenv("HIPKKT_VERBOSE")) {
-                if (std::atoi(vb) >= 2) {            // the extend-add work of the last fronts of the schedule
+            if (knobs().verbose) {
+                if (knobs().verbose >= 2) {            // the extend-add work of the last fronts of the schedule
                     for (size_t q = sched.size() > 12 ? sched.size() - 12 : 0; q < sched.size(); ++q) {
                         const int sn = sched[q];
                         const int64_t* w = wcut.data() + (size_t)sn * 17;
@@ -2211,7 +2215,7 @@ private:
                 // Measured on cfg2 (rocprofv3 --pmc FETCH_SIZE, r03): k_schur's reads 838 -> 525 MB per factorisation with the
                 // wide levels (>= 150 fronts) permuted, factorisation 1.754 / 1.760 -> 1.743 / 1.751 ms; permuting the narrow
                 // levels as well costs time (>= 32: 1.766 / 1.770 -- a handful of fronts' tiles then crowd one XCD).
-                static const int tile_xcd = std::getenv("HIPKKT_TILE_XCD") ? std::atoi(std::getenv("HIPKKT_TILE_XCD")) : 150;
+                const int tile_xcd = knobs().tile_xcd;
                 if (tile_xcd > 0) {
                     std::vector<int64_t> nt2(tiles.size()), nc2(tcut.size(), 0);
                     nt2 = tiles;
@@ -2298,7 +2302,7 @@ private:
                 for (size_t k = 0; k < hcol.size(); ++k) hrow[k] = S.perm[(size_t)hcol[k]];
                 d_glm_ptr.upload(mptr); d_udst_m.upload(udm); d_hp_col.upload(hcol); d_hp_row.upload(hrow); d_hp_lidx.upload(hl);
                 d_pr_ptr.upload(prp); d_pr_slot.upload(prs);
-                if (std::getenv("HIPKKT_VERBOSE"))
+                if (knobs().verbose)
                     std::fprintf(stderr, "[hipkkt] many-column sweeps: %lld of %lld contribution rows pulled from one-column leaves into %d sums\n",
                                  (long long)(hcol.size()), (long long)ptr[(size_t)nloc], n_pull_rows);
             }
@@ -2579,12 +2583,10 @@ int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* row
         SymbolicOptions opt;
         opt.ordering = ordering;
         if (nd_leaf_size > 0) opt.nd_leaf_size = nd_leaf_size;
-        if (const char* pc = std::getenv("HIPKKT_PANEL_CAP")) opt.panel_cap = std::atoll(pc);
-        if (const char* pc = std::getenv("HIPKKT_PANEL_MAX_COLS")) opt.panel_max_cols = std::atoi(pc);
-        if (const char* pc = std::getenv("HIPKKT_PANEL_SLICE_BELOW")) opt.panel_slice_below = std::atoi(pc);
+        apply_knobs(opt);
         Symbolic S;
         analyse((int)N, colptr, rowval, base, opt, S);
-        if (std::getenv("HIPKKT_DUMP_LEVELS")) {          // diagnostic: the shape of every tree level (host only)
+        if (knobs().dump_levels) {          // diagnostic: the shape of every tree level (host only)
             for (size_t l = 0; l < S.levels.size(); ++l) {
                 int cnt = 0, fmax = 0, ncmax = 0, n8 = 0, n64 = 0;
                 int lds3 = 0, lds2 = 0, lds1 = 0;        // panels (f > 64) that would fit 3 / 2 / 1 to a CU's LDS
@@ -2606,7 +2608,7 @@ int hipkkt_symbolic_analyse(int64_t N, const int64_t* colptr, const int64_t* row
                              upd * 8e-6, flops * 1e-6, lds3, lds2, lds1);
             }
         }
-        if (std::getenv("HIPKKT_DUMP_SUBTREES")) {        // diagnostic: what the subtrees below a cut level look like (host only)
+        if (knobs().dump_subtrees) {        // diagnostic: what the subtrees below a cut level look like (host only)
             {
                 std::vector<int> hist(8, 0);
                 int mx = 0;

@@ -1,5 +1,6 @@
 // See kernels.hpp.  Hand-written HIP for gfx950 (CDNA4, wave64).
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include <algorithm>
 
 #include <cmath>
@@ -1808,7 +1809,7 @@ void launch_residual_rm(const SpmvDev& A, const double* B, const double* X, doub
     if (g > kRmBlocks) g = kRmBlocks;
     if (g < 1) g = 1;
     double* bpartial = normb_out ? partial + (size_t)kRmBlocks * KP : nullptr;
-    static const int vmax = std::getenv("HIPKKT_MULTI_VEC") ? std::atoi(std::getenv("HIPKKT_MULTI_VEC")) : 4;
+    const int vmax = knobs().multi_vec;
     if (KP % 64 == 0 && vmax >= 4) hipLaunchKernelGGL(k_residual_rm<4>, dim3(g, KP / 64), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
     else if (KP % 32 == 0) hipLaunchKernelGGL(k_residual_rm<2>, dim3(g, KP / 32), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);
     else hipLaunchKernelGGL(k_residual_rm<1>, dim3(g, KP / 16), dim3(256), 0, st, A, B, X, E, partial, bpartial, KP);

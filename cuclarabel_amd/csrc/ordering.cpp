@@ -10,6 +10,7 @@
 // (SURVEY.md section 7.3 items 1-2).  Orderings differ from SuiteSparse's; parity is defined on the
 // solution of K x = b, never on L.
 #include "symbolic.hpp"
+#include "knobs.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -430,8 +431,8 @@ void nd_order(const Graph& g, int leaf_size, double dense_scale, std::vector<int
         // whole.  (Not the small ones: subgraphs with dense cliques -- cfg5's PSD blocks -- have relatively large level
         // separators and are still better off dissected; with these thresholds the orderings of cfg1-cfg5 are unchanged.
         // HIPKKT_ND_SEP_RATIO / HIPKKT_ND_SEP_MIN move them.)
-        static const double sep_ratio = std::getenv("HIPKKT_ND_SEP_RATIO") ? std::atof(std::getenv("HIPKKT_ND_SEP_RATIO")) : 0.10;
-        static const int sep_min = std::getenv("HIPKKT_ND_SEP_MIN") ? std::atoi(std::getenv("HIPKKT_ND_SEP_MIN")) : 5000;
+        const double sep_ratio = knobs().nd_sep_ratio;
+        const int sep_min = knobs().nd_sep_min;
         if ((double)sep.size() > sep_ratio * (double)sz && sz > sep_min) {
             for (int v : task.nodes) W.part[v] = 0;
             order_block_amd(task.nodes, task.pos_begin);

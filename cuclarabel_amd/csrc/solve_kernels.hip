@@ -15,6 +15,7 @@
 //            workgroup barrier per column); the off-diagonal panel is a dense GEMV streamed from
 //            HBM/L2 with 8 independent loads in flight per lane.
 #include "kernels.hpp"
+#include "knobs.hpp"
 #include "solve_common.hpp"
 #include <algorithm>
 #include <cstdlib>
@@ -2011,7 +2012,7 @@ __global__ __launch_bounds__(256) void k_pull_leaves_m(SolveArgs A, int nrows, i
 void launch_pull_leaves_multi(const SolveArgs& a, int nrows, int KP, hipStream_t st)
 {
     if (nrows <= 0) return;
-    static const int vmax = std::getenv("HIPKKT_MULTI_VEC") ? std::atoi(std::getenv("HIPKKT_MULTI_VEC")) : 4;
+    const int vmax = knobs().multi_vec;
     if (KP % 64 == 0 && vmax >= 4) hipLaunchKernelGGL(k_pull_leaves_m<4>, dim3((nrows + 15) / 16, KP / 64), dim3(256), 0, st, a, nrows, KP);
     else if (KP % 32 == 0) hipLaunchKernelGGL(k_pull_leaves_m<2>, dim3((nrows + 15) / 16, KP / 32), dim3(256), 0, st, a, nrows, KP);
     else hipLaunchKernelGGL(k_pull_leaves_m<1>, dim3((nrows + 15) / 16, KP / 16), dim3(256), 0, st, a, nrows, KP);
@@ -2442,7 +2443,7 @@ void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
         return;
     }
     // many column blocks: smaller workgroups, more fronts in flight (measured: 256 columns 21.4 vs 23.4 ms)
-    static const bool wide = !(std::getenv("HIPKKT_MULTI_CT") && std::atoi(std::getenv("HIPKKT_MULTI_CT")) == 1);
+    const bool wide = knobs().multi_ct != 1;
     if (wide && KP % 32 == 0 && KP >= 256) {         // (measured: 128 columns 6.2 vs 6.4 ms, 512 columns 19.8 vs 19.1)
         const size_t lds = (size_t)((ncmax + 3) & ~3) * 32 * sizeof(double);
         const dim3 grid(8, ((count + 7) / 8) * (KP / 32));
@@ -2462,7 +2463,7 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
         else hipLaunchKernelGGL(k_bwd_wave_m<1>, dim3((count + 3) / 4, (KP + 63) / 64), dim3(256), 0, st, a, begin, count, KP);
         // the launch's pulled leaves (tree level 0 only: they have no children)
         if (leaves) {
-            static const int vmax = std::getenv("HIPKKT_MULTI_VEC") ? std::atoi(std::getenv("HIPKKT_MULTI_VEC")) : 4;
+            const int vmax = knobs().multi_vec;
             if (KP % 64 == 0 && vmax >= 4) hipLaunchKernelGGL(k_bwd_leaf_m<4>, dim3((count + 15) / 16, KP / 64), dim3(256), 0, st, a, begin, count, KP);
             else if (KP % 32 == 0) hipLaunchKernelGGL(k_bwd_leaf_m<2>, dim3((count + 15) / 16, KP / 32), dim3(256), 0, st, a, begin, count, KP);
             else hipLaunchKernelGGL(k_bwd_leaf_m<1>, dim3((count + 15) / 16, KP / 16), dim3(256), 0, st, a, begin, count, KP);
@@ -2471,7 +2472,7 @@ void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int 
     }
     // at most max(8, nt) partial tiles of 16 x 16
     const int nt = (ncmax + 15) >> 4;
-    static const bool wide = !(std::getenv("HIPKKT_MULTI_CT") && std::atoi(std::getenv("HIPKKT_MULTI_CT")) == 1);
+    const bool wide = knobs().multi_ct != 1;
     if (wide && KP % 32 == 0 && KP >= 256) {         // (measured: 128 columns 6.2 vs 6.4 ms, 512 columns 19.8 vs 19.1)
         const size_t lds = (size_t)std::max(8, nt) * 256 * 2 * sizeof(double);
         const dim3 grid(8, ((count + 7) / 8) * (KP / 32));
@@ -2501,7 +2502,7 @@ int top_solve_capacity(size_t lds, bool tall)
     // workgroups per CU and fewer parked items is 7 % slower than that, with as many it spills: 40 % slower.)  MI355X_MICROARCH.md (residency) caps 256-thread blocks at
     // min(API, 8, floor(800 / (ceil(sgpr/16)*16 + 16))) per CU, i.e. 3 x 512 threads at ~106 SGPRs: the
     // register-limited API answer binds.  Keep 6 % spare.
-    if (std::getenv("HIPKKT_VERBOSE")) {
+    if (knobs().verbose) {
         hipFuncAttributes fa;
         if (hipFuncGetAttributes(&fa, fn) == hipSuccess)
             std::fprintf(stderr, "[hipkkt] k_top_solve<%d>: %d registers, %zu B dynamic LDS -> %d workgroup(s) per CU\n", tall ? 1024 : 512,

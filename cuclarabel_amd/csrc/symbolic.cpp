@@ -2,6 +2,7 @@
 // supernodes (+ relaxed amalgamation) -> row structures, assembly maps, level schedule.
 // See symbolic.hpp for what this replaces in the reference.
 #include "symbolic.hpp"
+#include "knobs.hpp"
 #include <cstdlib>
 
 #include <algorithm>
@@ -477,14 +478,14 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
     // the root has a dozen children whose blocks were megabytes apart in postorder, and its assembly spent 10-20 us
     // on what are ~30 scattered first touches (address translation, not bytes).  Offsets stay per supernode;
     // entry [nsuper] holds the total.  (HIPKKT_POSTORDER_LAYOUT=1 keeps the postorder layout, for comparison.)
-    if (!std::getenv("HIPKKT_POSTORDER_LAYOUT")) {
+    if (!knobs().postorder_layout) {
         // CHAINS share two update blocks.  In a chain of panels (a supernode cut into panels, 7b: the child's update block
         // IS its parent's whole front) the block of link i is read by link i + 1 alone -- by its panel and by its tiles --
         // and is dead once link i + 1's tiles are done, which is before link i + 2's tiles start (a stream's kernels run in
         // order; in overlap mode the tiles of a launch start when the previous launch's have finished).  Links alternate
         // between two buffers of the sizes of the first two (the blocks shrink along the chain): a 14 000-row root cut into
         // 148 panels keeps 2 x 1.6 GB instead of 148 blocks, 150 GB.  (HIPKKT_UPD_PINGPONG=0: every block its own.)
-        static const bool pingpong = !(std::getenv("HIPKKT_UPD_PINGPONG") && std::atoi(std::getenv("HIPKKT_UPD_PINGPONG")) == 0);
+        const bool pingpong = knobs().upd_pingpong;
         std::vector<int> pred((size_t)S.nsuper, -1), next((size_t)S.nsuper, -1);
         auto nbof = [&](int s) { return (int64_t)(S.rowptr[s + 1] - S.rowptr[s]); };
         auto fof = [&](int s) { return (int64_t)(S.sn_start[s + 1] - S.sn_start[s]) + nbof(s); };

@@ -352,13 +352,12 @@ def test_update_scaling_forms_the_kkt_values_on_the_device(maker, exact):
         assert ok
         for a in registered:
             assert _lib.host_unregister(a)
+        # (the steps agree to refinement accuracy, not bit for bit: with a second handle alive in the process this handle's
+        #  factorisation may be admitted to a different mode -- overlapped or level by level -- whose sums run in another order)
         for got, want in ((aff_b, aff_a), (com_b, com_a)):
             for g, v in zip(got, want):
                 g, v = np.asarray(g, dtype=float), np.asarray(v, dtype=float)
-                if exact:
-                    np.testing.assert_array_equal(g, v)
-                else:
-                    np.testing.assert_allclose(g, v, rtol=1e-9, atol=1e-10 * max(np.abs(v).max(), 1.0))
+                np.testing.assert_allclose(g, v, rtol=1e-9, atol=1e-10 * max(np.abs(v).max(), 1.0))
 
 
 @pytest.mark.gpu
