@@ -347,7 +347,7 @@ private:
         a.uvec = uvec_m.p;
         a.ld_b = a.ld_out = a.ld_xp = a.ld_uvec = 0;
         a.top_limit = 5000000;       // (the multi-column path has no persistent kernel)
-        a.tk_pos = nullptr; a.tk_sl = nullptr; a.tbase = nullptr; a.xf = nullptr; a.chain_cnt = nullptr; a.recs = nullptr;
+        a.tk_pos = nullptr; a.tk_sl = nullptr; a.tbase = nullptr; a.xf = nullptr; a.chain_cnt = nullptr; a.recs = nullptr; a.tall_ws = nullptr;
         launch_pull_leaves_multi(a, n_pull_rows, KP, stream);        // (the pulled leaves' terms, summed per receiving row)
         for (const Launch& L : launches) launch_fwd_multi(a, L.begin, L.count, L.small, L.ncmax, KP, stream);
         for (size_t q = launches.size(); q-- > 0;) {
@@ -763,6 +763,7 @@ private:
         a.tk_pos = d_tk_pos.p; a.tk_sl = d_tk_sl.p; a.tbase = d_tbase.p; a.xf = xf.p; a.add = nullptr;
         a.chain_cnt = nullptr;       // (set below when this sweep chains its lower levels)
         a.recs = d_recs.p ? reinterpret_cast<const char*>(d_recs.p) : nullptr;
+        a.tall_ws = tall_ws.p;
         const bool no_top = knobs().no_top;
         if (nr > 1 && top_ntask > 0 && (no_top || !use_top || top_disabled || top_sgrid2 <= 0)) {
             // two columns through a set with very tall fronts need its persistent kernel (supports_nr): without it, one
@@ -868,7 +869,7 @@ private:
                 launch_fwd_small(a, L.rec, L.begin, L.count - L.ntiny, L.ntiny, st, L.level == 0, nr);
             } else {
                 launch_fwd(a, L.rec, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
-                launch_fwd_tall(a, L.begin + L.count - L.ntall, L.ntall, st);        // (fronts beyond the block kernels' LDS)
+                launch_fwd_tall(a, L.begin + L.count - L.ntall, L.ntall, L.fmax, st);       // (fronts beyond the block kernels' LDS)
             }
         }
         if (chain_on) {
@@ -1009,7 +1010,7 @@ private:
                 launch_bwd_small(a, L.rec, L.begin, L.count - L.ntiny, L.ntiny, st, nr);
             } else {
                 launch_bwd(a, L.rec, L.begin, L.count - L.ntall, L.solve_bs, L.lds_solve, st, nr);
-                launch_bwd_tall(a, L.begin + L.count - L.ntall, L.ntall, st);
+                launch_bwd_tall(a, L.begin + L.count - L.ntall, L.ntall, L.fmax, S.N, st);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -1034,6 +1035,7 @@ private:
     std::vector<int64_t> h_toff; // (upload: solve-matrix offsets and chained-children counts, kept for build_records)
     std::vector<int> h_nch;
     DBuf<int64_t> d_recs;        // packed sweep records (kernels.hpp: SolveHdr); empty: the legacy layout
+    DBuf<double> tall_ws;        // work space of the tall-front sweep kernels (allocated when the schedule holds such fronts)
 
     // ---- admission of this handle's multi-stream / waiting operations on its device (DevOp)
     struct TokenRelease {
@@ -2311,6 +2313,11 @@ private:
         std::vector<signed char> ps(S.N);
         for (int k = 0; k < S.N; ++k) ps[k] = (signed char)(dsigns[S.perm[k]] >= 0 ? 1 : -1);
         d_psign.upload(ps);
+        {
+            size_t ws = 0;
+            for (const Launch& L : launches) if (L.ntall > 0) ws = std::max(ws, tall_ws_doubles(S.N, L.ntall, L.fmax));
+            if (ws) tall_ws.alloc(ws);
+        }
         fronts.alloc((size_t)S.front_store);
         upd.alloc((size_t)S.update_store);
         Dinv.alloc((size_t)S.N);

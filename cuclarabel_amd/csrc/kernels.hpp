@@ -229,6 +229,7 @@ struct SolveArgs {
     const int* tbase;
     double* xf;
     const double* add;           // many-column sweeps (row-major N x KP): out = solution + add where non-null
+    double* tall_ws;             // work space of the tall-front sweep kernels (k_*_tall_*): N doubles + the blocks' partial sums; or null
     const char* recs;            // packed sweep records (SolveHdr ...), or null: the legacy layout (TreeDev::desc, gl_ptr, ...)
     int* chain_cnt;              // nullable; the chained launches' forward counters (ChainArgs::cnt): a sweep that chains the
                                  // levels below the persistent set leaves the set's fronts' counters at their bottom
@@ -291,8 +292,10 @@ void launch_permute_in(const double* B, int64_t ldb, double* Xp, int KP, const i
 void launch_permute_rows(double* dst, const double* src, int KP, const int* iperm, int N, int dir, hipStream_t st, const double* add = nullptr);
 void launch_permute_out(double* X, int64_t ldx, const double* Xp, int KP, const int* iperm, int N, int nrhs, hipStream_t st);
 void launch_fwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st);
-void launch_fwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st);      // fronts too tall for the block kernels' LDS
-void launch_bwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st);
+// fronts too tall for the block kernels' LDS: their rows spread over workgroups (fmax: tallest of them; SolveArgs::tall_ws)
+void launch_fwd_tall(const SolveArgs& a, int begin, int count, int fmax, hipStream_t st);
+void launch_bwd_tall(const SolveArgs& a, int begin, int count, int fmax, int N, hipStream_t st);
+size_t tall_ws_doubles(int N, int ntall, int fmax);     // doubles SolveArgs::tall_ws needs for a launch with ntall such fronts
 void launch_pull_leaves_multi(const SolveArgs& a, int nrows, int KP, hipStream_t st);
 void launch_bwd_multi(const SolveArgs& a, int begin, int count, bool small, int ncmax, int KP, hipStream_t st, bool leaves = false);
 

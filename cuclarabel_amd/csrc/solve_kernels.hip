@@ -1715,7 +1715,13 @@ static void init_solve_lds()
 // (coalesced over the rows) and are stored straight to the contribution vector; backward, a wave owns columns and
 // walks the rows with its lanes (the ancestors' x gathered on the way), one wave reduction per column.  Single column
 // only; a launch's tall fronts sit at its end (hipkkt.hip, Launch::ntall) and stay out of the persistent kernels.
-__global__ __launch_bounds__(1024) void k_fwd_tall(SolveArgs A, int begin)
+// r04: a tall front's rows are spread over workgroups -- one workgroup walked 25 088 rows x 96 columns per hop of a
+// 261-panel chain (cfg2 with 0.1 % long-range couplings: 519 ms per sweep pair, 15 GB/s).  Forward: k_fwd_tall_top (one
+// workgroup per front: the top nc entries, kept for the rows kernel in SolveArgs::tall_ws) then k_fwd_tall_rows
+// (blockIdx.x = block of BR rows below, blockIdx.y = front).  Backward: k_bwd_tall_part (a block of BR rows each: z for
+// its rows in LDS, a wave per column run, one wave reduction per column and block -> partial sums in tall_ws) then
+// k_bwd_tall_fin (one workgroup per front: the blocks' partial sums in block order -- a fixed order, bit-reproducible).
+__global__ __launch_bounds__(1024) void k_fwd_tall_top(SolveArgs A, int begin)
 {
     __shared__ double ytop[kBdColsSolveMax];
     const int tid = threadIdx.x;
@@ -1730,6 +1736,7 @@ __global__ __launch_bounds__(1024) void k_fwd_tall(SolveArgs A, int begin)
         const int64_t lc = (int64_t)c0 + rp + i;
         for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += A.uvec[T.gl_src[g]];
         ytop[i] = v;
+        A.tall_ws[c0 + i] = v;
     }
     __syncthreads();
     for (int i = tid; i < nc; i += 1024) {
@@ -1737,7 +1744,22 @@ __global__ __launch_bounds__(1024) void k_fwd_tall(SolveArgs A, int begin)
         for (int k = 0; k <= i; ++k) acc = fma(W[i + (int64_t)k * f], ytop[k], acc);       // T is unit lower triangular
         A.xp[c0 + i] = acc;
     }
-    for (int r = nc + tid; r < f; r += 1024) {
+}
+__global__ __launch_bounds__(1024) void k_fwd_tall_rows(SolveArgs A, int begin, int BR)
+{
+    __shared__ double ytop[kBdColsSolveMax];
+    const int tid = threadIdx.x;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + blockIdx.y];
+    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
+    const int64_t rp = fd.rp;
+    const int f = nc + nb;
+    const int r0 = nc + (int)blockIdx.x * BR, r1 = min(f, r0 + BR);
+    if (r0 >= f) return;
+    const double* __restrict__ W = A.tinv + fd.w_off;
+    for (int i = tid; i < nc; i += 1024) ytop[i] = A.tall_ws[c0 + i];
+    __syncthreads();
+    for (int r = r0 + tid; r < r1; r += 1024) {
         const int64_t lc = (int64_t)c0 + rp + r;
         double v = 0.0;
         for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += A.uvec[T.gl_src[g]];
@@ -1746,42 +1768,70 @@ __global__ __launch_bounds__(1024) void k_fwd_tall(SolveArgs A, int begin)
         A.uvec[rp + r - nc] = v - acc;
     }
 }
-__global__ __launch_bounds__(1024) void k_bwd_tall(SolveArgs A, int begin)
+// partial sums of block bx of front ty (launch-local index) for column j: tall_ws[N + ((ty * nblk + bx) * kBdColsSolveMax) + j]
+__global__ __launch_bounds__(1024) void k_bwd_tall_part(SolveArgs A, int begin, int BR, int N)
 {
-    __shared__ double ztop[kBdColsSolveMax], xnew[kBdColsSolveMax];
+    extern __shared__ __attribute__((aligned(16))) double zloc[];       // BR doubles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const FrontDesc fd = T.desc[begin + blockIdx.y];
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
+    const int r0 = (int)blockIdx.x * BR, r1 = min(f, r0 + BR);
+    if (r0 >= f) return;
     const double* __restrict__ W = A.tinv + fd.w_off;
-    for (int j = tid; j < nc; j += 1024) ztop[j] = A.xp[c0 + j] * A.Dinv[c0 + j];
+    for (int r = r0 + tid; r < r1; r += 1024)
+        zloc[r - r0] = (r < nc) ? A.xp[c0 + r] * A.Dinv[c0 + r] : -A.xp[T.rows[rp + r - nc]];
     __syncthreads();
+    double* part = A.tall_ws + N + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBdColsSolveMax;
     for (int j = wv; j < nc; j += 16) {
         double acc = 0.0;
         const double* __restrict__ Wj = W + (int64_t)j * f;
-        for (int r = j + lane; r < f; r += 64) {
-            const double zr = (r < nc) ? ztop[r] : -A.xp[T.rows[rp + r - nc]];
-            acc = fma(Wj[r], zr, acc);
-        }
+        for (int r = max(r0, j) + lane; r < r1; r += 64) acc = fma(Wj[r], zloc[r - r0], acc);
         acc = wave_reduce_sum(acc);
-        if (lane == 0) xnew[j] = acc;
+        if (lane == 0) part[j] = acc;
     }
-    __syncthreads();
-    for (int j = tid; j < nc; j += 1024) {
-        const double v = xnew[j];
+}
+__global__ __launch_bounds__(256) void k_bwd_tall_fin(SolveArgs A, int begin, int BR, int N, int nblk)
+{
+    const int tid = threadIdx.x;
+    const TreeDev& T = A.T;
+    const FrontDesc fd = T.desc[begin + blockIdx.x];
+    const int c0 = fd.c0, nc = fd.nc, f = fd.nc + fd.nb;
+    const int nb_used = (f + BR - 1) / BR;
+    const double* part = A.tall_ws + N + (int64_t)blockIdx.x * nblk * kBdColsSolveMax;
+    for (int j = tid; j < nc; j += 256) {
+        double v = 0.0;
+        for (int bx = j / BR; bx < nb_used; ++bx) v += part[(int64_t)bx * kBdColsSolveMax + j];       // (blocks above row j hold nothing of column j)
         A.xp[c0 + j] = v;
         A.out[T.perm[c0 + j]] = v;
     }
 }
-void launch_fwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st)
+static int tall_block_rows()
 {
-    if (count > 0) hipLaunchKernelGGL(k_fwd_tall, dim3(count), dim3(1024), 0, st, a, begin);
+    const int br = knobs().tall_block_rows;
+    return br < 64 ? 64 : (br > 4096 ? 4096 : (br & ~63));
 }
-void launch_bwd_tall(const SolveArgs& a, int begin, int count, hipStream_t st)
+size_t tall_ws_doubles(int N, int ntall, int fmax)
 {
-    if (count > 0) hipLaunchKernelGGL(k_bwd_tall, dim3(count), dim3(1024), 0, st, a, begin);
+    const int BR = tall_block_rows();
+    return (size_t)N + (size_t)ntall * (size_t)((fmax + BR - 1) / BR) * kBdColsSolveMax;
+}
+void launch_fwd_tall(const SolveArgs& a, int begin, int count, int fmax, hipStream_t st)
+{
+    if (count <= 0) return;
+    const int BR = tall_block_rows();
+    hipLaunchKernelGGL(k_fwd_tall_top, dim3(count), dim3(1024), 0, st, a, begin);
+    hipLaunchKernelGGL(k_fwd_tall_rows, dim3((fmax + BR - 1) / BR, count), dim3(1024), 0, st, a, begin, BR);
+}
+void launch_bwd_tall(const SolveArgs& a, int begin, int count, int fmax, int N, hipStream_t st)
+{
+    if (count <= 0) return;
+    const int BR = tall_block_rows();
+    const int nblk = (fmax + BR - 1) / BR;
+    hipLaunchKernelGGL(k_bwd_tall_part, dim3(nblk, count), dim3(1024), (size_t)BR * sizeof(double), st, a, begin, BR, N);
+    hipLaunchKernelGGL(k_bwd_tall_fin, dim3(count), dim3(256), 0, st, a, begin, BR, N, nblk);
 }
 
 size_t solve_lds_bytes(int fmax, int ncmax)

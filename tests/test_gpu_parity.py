@@ -729,7 +729,12 @@ for _ in range(4):
     assert ok
     # (iterative refinement repairs a sweep or a factor that went slightly wrong, at the price of extra rounds: the
     #  number of rounds must be the oracle's as well)
-    assert ks.last_ir_iterations == o.last_ir_iters, (ks.last_ir_iterations, o.last_ir_iters)
+    # (TEST_ROUNDS_SLACK=1, set by the one caller with a dense block of 1900: at that size the first round's residual can
+    #  land within round-off of the reference's stopping threshold -- never MORE rounds than the scalar elimination, at most
+    #  one fewer: the rule of the full-size tests)
+    import os
+    slack = int(os.environ.get("TEST_ROUNDS_SLACK", "0"))
+    assert o.last_ir_iters - slack <= ks.last_ir_iterations <= o.last_ir_iters, (ks.last_ir_iterations, o.last_ir_iters)
     worst = max(worst, max(np.abs(x - xo).max(), np.abs(z - zo).max()) / max(np.abs(xo).max(), np.abs(zo).max()))
 print("levels", ks.info["nlevels"], "worst", worst)
 assert worst < 1e-9
@@ -998,21 +1003,30 @@ def test_long_range_couplings_at_mid_size():
 
 
 @pytest.mark.parametrize("maker,rows", [("problems.config2(n=6000)", 96), ("problems.config3(nblocks=4, blk=150)", 100),
-                                        ("problems.config5(n=120, npsd=6, psd_dim=8, nsoc=4, soc_dim=12)", 40)])
+                                        ("problems.config5(n=120, npsd=6, psd_dim=8, nsoc=4, soc_dim=12)", 40),
+                                        ("problems.config3(nblocks=1, blk=1900)", 0)])
 @pytest.mark.parametrize("no_top", [False, True])
 def test_fronts_too_tall_for_the_block_sweep_kernels(maker, rows, no_top):
     """Fronts beyond ~10 000 rows do not fit the block sweep kernels' LDS whatever their width (a 14 000-row root of a KKT
-    graph with long-range couplings, a dense block of 12 000): they take k_fwd_tall / k_bwd_tall, one workgroup each with
-    nothing of size f in LDS, at the end of their level's launches; in a persistent set they are (front, slice) tasks.
-    HIPKKT_SOLVE_TALL_ROWS (read at handle creation) sends much smaller fronts the same way -- with and without the
-    persistent kernel; solutions and refinement rounds must match the oracle."""
+    graph with long-range couplings, a dense block of 12 000): in the per-level path they take the k_*_tall_* kernels --
+    nothing of size f in LDS, their rows spread over workgroups (r04: forward a top kernel and a rows kernel, backward
+    per-block partial sums combined in block order) --, in a persistent set they are (front, slice) tasks.
+    HIPKKT_SOLVE_TALL_ROWS (read at handle creation) sends much smaller fronts the same way, HIPKKT_TALL_BLOCK_ROWS = 64
+    cuts them into several row blocks -- with and without the persistent kernel; the last case is tall for real (a dense
+    1900 x 1900 block of P: fronts of 2000-3800 rows, two to four blocks of 1024 rows).  Solutions and refinement rounds
+    must match the oracle."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HIPKKT_SOLVE_TALL_ROWS=str(rows), HIPKKT_VERBOSE="1")
+    env = dict(os.environ, HIPKKT_VERBOSE="1")
+    if rows:
+        env.update(HIPKKT_SOLVE_TALL_ROWS=str(rows), HIPKKT_TALL_BLOCK_ROWS="64")
+    else:
+        env["TEST_ROUNDS_SLACK"] = "1"
     if no_top:
         env["HIPKKT_NO_TOP"] = "1"          # every level through the per-level kernels: the tall ones for these fronts
+        env["HIPKKT_CHAIN"] = "0"
     r = subprocess.run([sys.executable, "-c", _SMALL_GRID_SCRIPT.format(root=root, maker=maker)], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
