@@ -118,11 +118,29 @@ def main():
             assert ok
         return step[3]
 
+    # r04: what integration/HipKKTExt.jl does now -- kkt_update! from the scaling alone (w, eta, lambda: the Hs blocks and the
+    # sparse cones' u / v are formed on the device), the combined kkt_solve! re-using the affine one's variables, every
+    # vector page-locked once (hipkkt_host_register)
+    from cuclarabel_amd import _lib
+    hv = dict(var=[x.copy(), s.copy(), z.copy()], rhs=[[rhs[0].copy(), s.copy(), rhs[2].copy()], [rhs[0].copy(), rhs[1].copy(), rhs[2].copy()]],
+              lhs=[np.zeros(pb.n), np.zeros(pb.m), np.zeros(pb.m)],
+              scal=[np.ascontiguousarray(cone_data[4]), np.ascontiguousarray(cone_data[5]), np.ascontiguousarray(cone_data[6]), np.zeros(0), np.zeros(0)])
+    pinned = [a for a in hv["var"] + hv["rhs"][0] + hv["rhs"][1] + hv["lhs"] + hv["scal"][:3] if a.size and _lib.host_register(a)]
+    upd_h, aff_h, com_h = system.prepared_host(hv["lhs"], hv["rhs"], 0.3, -0.1, hv["var"], tau, kappa, hv["scal"])
+
+    def iteration_c_host_reduced():
+        assert upd_h()
+        for solve in (aff_h, com_h):
+            ok, dtau, dkappa = solve()
+            assert ok
+        return dtau
+
     out = {}
     for name, fn in (("level_C_device_resident", iteration_c), ("level_C_lazy_two_calls", iteration_c_lazy),
                      ("level_C_batched_affine", iteration_c_batched), ("level_C_lazy_host_vectors", iteration_c_host),
+                     ("level_C_lazy_host_vectors_reduced_pinned", iteration_c_host_reduced),
                      ("level_B_host_vectors", iteration_b)):
-        system.set_lazy(name in ("level_C_lazy_two_calls", "level_C_lazy_host_vectors"))
+        system.set_lazy(name in ("level_C_lazy_two_calls", "level_C_lazy_host_vectors", "level_C_lazy_host_vectors_reduced_pinned"))
         fn(); fn()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -134,6 +152,7 @@ def main():
     out["agreement_dtau_batched"] = abs(out["level_C_batched_affine"]["dtau"] - out["level_B_host_vectors"]["dtau"])
     out["agreement_dtau_lazy"] = abs(out["level_C_lazy_two_calls"]["dtau"] - out["level_B_host_vectors"]["dtau"])
     out["agreement_dtau_host"] = abs(out["level_C_lazy_host_vectors"]["dtau"] - out["level_B_host_vectors"]["dtau"])
+    out["agreement_dtau_host_reduced"] = abs(out["level_C_lazy_host_vectors_reduced_pinned"]["dtau"] - out["level_B_host_vectors"]["dtau"])
     print(json.dumps(dict(workload=f"cfg2 n={args.n}: kkt_update! + 2 x kkt_solve! (3 KKT solves with refinement)", **out)))
 
 

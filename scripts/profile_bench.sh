@@ -17,7 +17,7 @@ OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 if [ "$WHAT" = "bench" ]; then
-  ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --sequential-solves"
+  ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --sequential-solves --no-scale-modes"
   python3 $ARGS > $OUT/bench.json 2> $OUT/bench.err
 else
   ARGS="scripts/bench_one_config.py ${WHAT#cfg} 5"
