@@ -634,7 +634,8 @@ def main():
                         raise RuntimeError("refinement-round counts missing (deferred status?)")
                     rounds[0] += int(ir.sum())
                 if world > 1:
-                    gather.post(q0, q1, [LX[q0:q1], LZ[q0:q1]])
+                    # (every block has rows of its own in LX / LZ, untouched until finish(): sent in place, no copy)
+                    gather.post(q0, q1, [LX[q0:q1], LZ[q0:q1]], copy=False)
             if world > 1:
                 gather.finish()
 

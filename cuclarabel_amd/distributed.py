@@ -113,7 +113,6 @@ class BlockedColumnGather:
         self.per = (self.n_columns + self.world - 1) // self.world           # local columns incl. padding
         self.km = len(shard_columns(self.n_columns, self.world, self.rank))
         self.out = [torch.zeros(self.per * self.world, p, dtype=dtype, device=device) for p in self.parts]
-        self._send = [torch.zeros(self.block, p, dtype=dtype, device=device) for p in self.parts]
         self._pending = []
 
     def blocks(self):
@@ -121,9 +120,28 @@ class BlockedColumnGather:
         with fewer columns post zero padding for the ones they do not hold)."""
         return [(q0, min(q0 + self.block, self.per)) for q0 in range(0, self.per, self.block)]
 
-    def post(self, q0, q1, locals_):
+    def _undeal(self, entry):
+        work, tmp, _send, p, q0, q1 = entry
+        nb = q1 - q0
+        self.out[p][q0 * self.world:q1 * self.world] = \
+            tmp.view(self.world, nb, self.parts[p]).transpose(0, 1).reshape(nb * self.world, self.parts[p])
+
+    def post(self, q0, q1, locals_, copy=True):
         """locals_[p]: (>= q1 - q0 rows, parts[p]) tensor whose row j is this rank's local column q0 + j (rows beyond
-        this rank's share are ignored).  Starts the exchange of the block and returns at once."""
+        this rank's share are ignored).  Starts the exchange of the block and returns at once.
+        copy=True (default): the rows are copied into a buffer this object owns before the collective is started, so
+        the caller may overwrite its buffer at once (the natural pattern: one block buffer re-used for the next
+        solve).  copy=False sends the caller's rows in place: they must then stay untouched until finish() -- nothing
+        orders a later write to them behind the collective (round-3 advisor).
+        Blocks whose exchange has completed meanwhile are un-dealt into the result here, so that their receive buffers
+        are freed as the step proceeds instead of all being held until finish()."""
+        still = []
+        for entry in self._pending:
+            if entry[0].is_completed():
+                self._undeal(entry)
+            else:
+                still.append(entry)
+        self._pending = still
         nb = q1 - q0
         have = max(0, min(q1, self.km) - q0)
         for p, loc in enumerate(locals_):
@@ -133,7 +151,9 @@ class BlockedColumnGather:
                 continue
             if have == nb:
                 send = loc[:nb]
-                if not send.is_contiguous():
+                if copy:
+                    send = send.clone(memory_format=torch.contiguous_format)
+                elif not send.is_contiguous():
                     send = send.contiguous()
             else:                                   # the last block of a rank with a short share: pad with zeros
                 send = torch.zeros(nb, self.parts[p], dtype=loc.dtype, device=self.out[p].device)
@@ -145,10 +165,8 @@ class BlockedColumnGather:
 
     def finish(self):
         """Waits for every posted block; returns the gathered (n_columns, parts[p]) tensors, row j = column j."""
-        for work, tmp, _send, p, q0, q1 in self._pending:
-            work.wait()
-            nb = q1 - q0
-            self.out[p][q0 * self.world:q1 * self.world] = \
-                tmp.view(self.world, nb, self.parts[p]).transpose(0, 1).reshape(nb * self.world, self.parts[p])
+        for entry in self._pending:
+            entry[0].wait()
+            self._undeal(entry)
         self._pending = []
         return [o[:self.n_columns] for o in self.out]

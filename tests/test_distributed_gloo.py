@@ -166,8 +166,17 @@ def _worker_blocked(rank, world, port, n_columns, block, q):
             LX[qi] = j + 0.01 * torch.arange(n, dtype=torch.float64)
             LZ[qi] = -j - 0.01 * torch.arange(m, dtype=torch.float64)
         g = BlockedColumnGather(n_columns, (n, m), block)
+        # the natural caller pattern: ONE block buffer, filled, posted, and overwritten for the next block at once -- the
+        # object must have taken its own copy (post's default; round-3 advisor: the rows used to be sent in place)
+        bx = torch.zeros(block, n, dtype=torch.float64)
+        bz = torch.zeros(block, m, dtype=torch.float64)
         for q0, q1 in g.blocks():                  # solve block, post its exchange, go on with the next block
-            g.post(q0, q1, [LX[q0:q1], LZ[q0:q1]])
+            k = max(0, min(q1, len(mine)) - q0)
+            bx[:k] = LX[q0:q0 + k]
+            bz[:k] = LZ[q0:q0 + k]
+            g.post(q0, q1, [bx, bz])
+            bx.fill_(float("nan"))
+            bz.fill_(float("nan"))
         X, Z = g.finish()
         ref = gather_columns(LX, n_columns)        # the one-shot exchange of the same data
         q.put((rank, X.numpy(), Z.numpy(), ref.numpy(), len(g.blocks())))
