@@ -341,8 +341,8 @@ def traffic_summary():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="iter", choices=["iter", "problems", "rhs"],
                     help="iter (default, the headline): cfg2, one instance per rank, weak scaling.  problems: cfg4's "
                          "batch of --problems independent SOCPs (n=10k) dealt to the ranks, block-diagonal handles of "

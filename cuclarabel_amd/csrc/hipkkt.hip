@@ -2316,7 +2316,7 @@ private:
         {
             size_t ws = 0;
             for (const Launch& L : launches) if (L.ntall > 0) ws = std::max(ws, tall_ws_doubles(S.N, L.ntall, L.fmax));
-            if (ws) tall_ws.alloc(ws);
+            if (ws) { tall_ws.alloc(ws); tall_ws.zero(nullptr); HIP_CHECK(hipStreamSynchronize(nullptr)); }     // (its first N doubles: ticket words, zero between sweeps)
         }
         fronts.alloc((size_t)S.front_store);
         upd.alloc((size_t)S.update_store);

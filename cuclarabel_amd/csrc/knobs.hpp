@@ -33,7 +33,7 @@ namespace hipkkt {
     KNOB(int, bs128_count, "HIPKKT_BS128_COUNT", 1024)      /* a level with at least this many fronts ... */                           \
     KNOB(int, bs128_f, "HIPKKT_BS128_F", 128)               /* ... none taller than this sweeps with 128-thread workgroups */          \
     KNOB(int, solve_tall_rows, "HIPKKT_SOLVE_TALL_ROWS", 0) /* fronts of this many rows count as too tall for the block sweep kernels (tests) */ \
-    KNOB(int, tall_block_rows, "HIPKKT_TALL_BLOCK_ROWS", 256) /* rows of such a front per workgroup of the k_*_tall_* sweep kernels (64..4096; 25 088-row root: 1024 35.6, 512 28.6, 256 26.6, 128 28.6 ms per sweep pair) */ \
+    KNOB(int, tall_block_rows, "HIPKKT_TALL_BLOCK_ROWS", 256) /* rows of such a front per workgroup of the k_*_tall sweep kernels (64..4096; 25 088-row root, two kernels per direction: 1024 35.6, 512 28.6, 256 26.6, 128 28.6 ms per sweep pair; fused: 256 22.0) */ \
     FLAG_ON(dense_child, "HIPKKT_DENSE_CHILD")              /* a child whose update block is its parent's whole front is added as a dense block */ \
     KNOB(int, tile_xcd, "HIPKKT_TILE_XCD", 150)             /* launches of at least this many fronts deal a front's tiles to one XCD (0: off) */ \
     FLAG_ON(pull_leaves, "HIPKKT_PULL_LEAVES")              /* many-column sweeps: one-column leaves are pulled by their parents */     \

@@ -1716,36 +1716,16 @@ static void init_solve_lds()
 // walks the rows with its lanes (the ancestors' x gathered on the way), one wave reduction per column.  Single column
 // only; a launch's tall fronts sit at its end (hipkkt.hip, Launch::ntall) and stay out of the persistent kernels.
 // r04: a tall front's rows are spread over workgroups -- one workgroup walked 25 088 rows x 96 columns per hop of a
-// 261-panel chain (cfg2 with 0.1 % long-range couplings: 519 ms per sweep pair, 15 GB/s).  Forward: k_fwd_tall_top (one
-// workgroup per front: the top nc entries, kept for the rows kernel in SolveArgs::tall_ws) then k_fwd_tall_rows
-// (blockIdx.x = block of BR rows below, blockIdx.y = front).  Backward: k_bwd_tall_part (a block of BR rows each: z for
-// its rows in LDS, a wave per column run, one wave reduction per column and block -> partial sums in tall_ws) then
-// k_bwd_tall_fin (one workgroup per front: the blocks' partial sums in block order -- a fixed order, bit-reproducible).
-__global__ __launch_bounds__(1024) void k_fwd_tall_top(SolveArgs A, int begin)
-{
-    __shared__ double ytop[kBdColsSolveMax];
-    const int tid = threadIdx.x;
-    const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
-    const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
-    const int64_t rp = fd.rp;
-    const int f = nc + nb;
-    const double* __restrict__ W = A.tinv + fd.w_off;
-    for (int i = tid; i < nc; i += 1024) {
-        double v = A.b[T.perm[c0 + i]];
-        const int64_t lc = (int64_t)c0 + rp + i;
-        for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += A.uvec[T.gl_src[g]];
-        ytop[i] = v;
-        A.tall_ws[c0 + i] = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < nc; i += 1024) {
-        double acc = 0.0;
-        for (int k = 0; k <= i; ++k) acc = fma(W[i + (int64_t)k * f], ytop[k], acc);       // T is unit lower triangular
-        A.xp[c0 + i] = acc;
-    }
-}
-__global__ __launch_bounds__(1024) void k_fwd_tall_rows(SolveArgs A, int begin, int BR)
+// 261-panel chain (cfg2 with 0.1 % long-range couplings: 519 ms per sweep pair, 15 GB/s) -- and a direction is ONE
+// launch per panel: the sweep of such a chain is a launch per panel and kernel, ~10 us each whatever the work.
+// Forward (k_fwd_tall; blockIdx.y = front): every workgroup gathers the top nc entries itself (the same sums in the same
+// order); workgroup 0 solves them against T, workgroup 1 + i takes block i of BR rows below.  Backward (k_bwd_tall): a
+// block of BR rows each -- z for its rows in LDS, a wave per column run, one wave reduction per column and block ->
+// partial sums in tall_ws -- and the workgroup that finishes a front's LAST block (a ticket word per front: tall_ws's
+// first N doubles seen as ints, zero between sweeps) adds the partial sums up in block order: a fixed order,
+// bit-reproducible.  The partial sums are handed over as in chain_kernels.hip: sc1 stores, s_waitcnt, barrier, one
+// relaxed agent-scope atomic; the reader uses sc1 loads behind the ticket.
+__global__ __launch_bounds__(1024) void k_fwd_tall(SolveArgs A, int begin, int BR)
 {
     __shared__ double ytop[kBdColsSolveMax];
     const int tid = threadIdx.x;
@@ -1754,11 +1734,24 @@ __global__ __launch_bounds__(1024) void k_fwd_tall_rows(SolveArgs A, int begin, 
     const int c0 = fd.c0, nc = fd.nc, nb = fd.nb;
     const int64_t rp = fd.rp;
     const int f = nc + nb;
-    const int r0 = nc + (int)blockIdx.x * BR, r1 = min(f, r0 + BR);
-    if (r0 >= f) return;
+    const int r0 = nc + ((int)blockIdx.x - 1) * BR, r1 = min(f, r0 + BR);
+    if (blockIdx.x > 0 && r0 >= f) return;
     const double* __restrict__ W = A.tinv + fd.w_off;
-    for (int i = tid; i < nc; i += 1024) ytop[i] = A.tall_ws[c0 + i];
+    for (int i = tid; i < nc; i += 1024) {
+        double v = A.b[T.perm[c0 + i]];
+        const int64_t lc = (int64_t)c0 + rp + i;
+        for (int64_t g = T.gl_ptr[lc]; g < T.gl_ptr[lc + 1]; ++g) v += A.uvec[T.gl_src[g]];
+        ytop[i] = v;
+    }
     __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < nc; i += 1024) {
+            double acc = 0.0;
+            for (int k = 0; k <= i; ++k) acc = fma(W[i + (int64_t)k * f], ytop[k], acc);       // T is unit lower triangular
+            A.xp[c0 + i] = acc;
+        }
+        return;
+    }
     for (int r = r0 + tid; r < r1; r += 1024) {
         const int64_t lc = (int64_t)c0 + rp + r;
         double v = 0.0;
@@ -1769,9 +1762,10 @@ __global__ __launch_bounds__(1024) void k_fwd_tall_rows(SolveArgs A, int begin, 
     }
 }
 // partial sums of block bx of front ty (launch-local index) for column j: tall_ws[N + ((ty * nblk + bx) * kBdColsSolveMax) + j]
-__global__ __launch_bounds__(1024) void k_bwd_tall_part(SolveArgs A, int begin, int BR, int N)
+__global__ __launch_bounds__(1024) void k_bwd_tall(SolveArgs A, int begin, int BR, int N)
 {
     extern __shared__ __attribute__((aligned(16))) double zloc[];       // BR doubles
+    __shared__ int sh_last;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const TreeDev& T = A.T;
     const FrontDesc fd = T.desc[begin + blockIdx.y];
@@ -1784,26 +1778,29 @@ __global__ __launch_bounds__(1024) void k_bwd_tall_part(SolveArgs A, int begin, 
     for (int r = r0 + tid; r < r1; r += 1024)
         zloc[r - r0] = (r < nc) ? A.xp[c0 + r] * A.Dinv[c0 + r] : -A.xp[T.rows[rp + r - nc]];
     __syncthreads();
-    double* part = A.tall_ws + N + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBdColsSolveMax;
+    double* front_part = A.tall_ws + N + (int64_t)blockIdx.y * gridDim.x * kBdColsSolveMax;
+    double* part = front_part + (int64_t)blockIdx.x * kBdColsSolveMax;
     for (int j = wv; j < nc; j += 16) {
         double acc = 0.0;
         const double* __restrict__ Wj = W + (int64_t)j * f;
         for (int r = max(r0, j) + lane; r < r1; r += 64) acc = fma(Wj[r], zloc[r - r0], acc);
         acc = wave_reduce_sum(acc);
-        if (lane == 0) part[j] = acc;
+        if (lane == 0) ST_AGENT_F64(part + j, acc);
     }
-}
-__global__ __launch_bounds__(256) void k_bwd_tall_fin(SolveArgs A, int begin, int BR, int N, int nblk)
-{
-    const int tid = threadIdx.x;
-    const TreeDev& T = A.T;
-    const FrontDesc fd = T.desc[begin + blockIdx.x];
-    const int c0 = fd.c0, nc = fd.nc, f = fd.nc + fd.nb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const int nb_used = (f + BR - 1) / BR;
-    const double* part = A.tall_ws + N + (int64_t)blockIdx.x * nblk * kBdColsSolveMax;
-    for (int j = tid; j < nc; j += 256) {
+    int* ticket = reinterpret_cast<int*>(A.tall_ws) + fd.s;
+    if (tid == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = (t == nb_used - 1);
+        if (sh_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (zero again for the next sweep)
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    for (int j = tid; j < nc; j += 1024) {
         double v = 0.0;
-        for (int bx = j / BR; bx < nb_used; ++bx) v += part[(int64_t)bx * kBdColsSolveMax + j];       // (blocks above row j hold nothing of column j)
+        for (int bx = j / BR; bx < nb_used; ++bx) v += LD_AGENT_F64(front_part + (int64_t)bx * kBdColsSolveMax + j);   // (blocks above row j hold nothing of column j)
         A.xp[c0 + j] = v;
         A.out[T.perm[c0 + j]] = v;
     }
@@ -1822,16 +1819,14 @@ void launch_fwd_tall(const SolveArgs& a, int begin, int count, int fmax, hipStre
 {
     if (count <= 0) return;
     const int BR = tall_block_rows();
-    hipLaunchKernelGGL(k_fwd_tall_top, dim3(count), dim3(1024), 0, st, a, begin);
-    hipLaunchKernelGGL(k_fwd_tall_rows, dim3((fmax + BR - 1) / BR, count), dim3(1024), 0, st, a, begin, BR);
+    hipLaunchKernelGGL(k_fwd_tall, dim3(1 + (fmax + BR - 1) / BR, count), dim3(1024), 0, st, a, begin, BR);
 }
 void launch_bwd_tall(const SolveArgs& a, int begin, int count, int fmax, int N, hipStream_t st)
 {
     if (count <= 0) return;
     const int BR = tall_block_rows();
     const int nblk = (fmax + BR - 1) / BR;
-    hipLaunchKernelGGL(k_bwd_tall_part, dim3(nblk, count), dim3(1024), (size_t)BR * sizeof(double), st, a, begin, BR, N);
-    hipLaunchKernelGGL(k_bwd_tall_fin, dim3(count), dim3(256), 0, st, a, begin, BR, N, nblk);
+    hipLaunchKernelGGL(k_bwd_tall, dim3(nblk, count), dim3(1024), (size_t)BR * sizeof(double), st, a, begin, BR, N);
 }
 
 size_t solve_lds_bytes(int fmax, int ncmax)
