@@ -118,6 +118,7 @@ SYMBOLS = {
                                      C.c_int32, C.c_double, C.c_double, _P, _P, _P, C.c_int, C.c_int]),
     "hipkkt_scale_matrix_values": (C.c_int, [C.c_int64, C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_int, C.c_int]),
     "hipkkt_kkt_mul_Hs": (C.c_int, [_P, _P, _P]),
+    "hipkkt_kkt_speculative_rounds": (C.c_int, [_P, C.c_int]),
     "hipkkt_kkt_get_pattern": (C.c_int, [_P, _P, _P]),
     "hipkkt_kkt_get_values": (C.c_int, [_P, _P]),
     "hipkkt_kkt_get_maps": (C.c_int, [_P] * 9),

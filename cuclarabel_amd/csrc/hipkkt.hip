@@ -2468,14 +2468,15 @@ struct hipkkt_kkt_s {
     // refinement on the device (k_ir_round): state slots (4 doubles per round), a 5-double read-back record, the
     // sticky deferred-status record (8 doubles)
     DBuf<double> irbuf;
-    double *ir_state = nullptr, *ir_readback = nullptr, *ir_sticky = nullptr, *ir_norms = nullptr;
+    double *ir_state = nullptr, *ir_readback = nullptr, *ir_sticky = nullptr, *ir_norms = nullptr, *sys_out_dev = nullptr;
     int ir_stride = 0;
     int r_spec = 1;                  // refinement rounds enqueued ahead of the first read-back (= what the previous solve took)
+    int spec_low_calls = 0;          // status records in a row whose solves took fewer rounds than were enqueued (kkt_eval_sticky)
     bool deferred = false;           // hipkkt_kkt_set_deferred_status
     // level C (DefaultKKTSystem on the device, kktsystem.jl:21-215)
     DBuf<double> lam;                                        // scaled point, m
-    DBuf<double> sq, snegq, sb, sx1, sz1, sx2, sz2, sworkx, sworkz, sconic, spa, spb, spc;
-    DBuf<double> sys_partial, sys_dots, sys_cached, sys_in, sys_out;
+    DBuf<double> sq, snegq, sb, sx2, sz2, sworkx, sworkz, sconic, spa, spb, spc;
+    DBuf<double> sys_partial, sys_dots, sys_cached, sys_in;
     bool sys_ready = false;
     bool sys_lazy = false;           // hipkkt_kkt_system_set_lazy: kkt_update! leaves (x2, z2) = K \ (-q, b) to the affine kkt_solve!
     bool sys_const_pending = false;  // ... and that solve is still due
@@ -2978,20 +2979,21 @@ int hipkkt_kkt_create(hipkkt_kkt_t* out, int64_t n, int64_t m, const int64_t* Pc
         h->cur_dx = h->dx.p;
         h->rx.alloc((size_t)K.n); h->rz.alloc((size_t)K.m);
         h->sbuf.alloc((size_t)K.m); h->zbuf.alloc((size_t)K.m); h->ybuf.alloc((size_t)K.m);
-        h->partial.alloc((size_t)std::max(2, kMaxNR) * (2 * kNormParts + 1) + 8);
+        h->partial.alloc(2 * ((size_t)std::max(2, kMaxNR) * (2 * kNormParts + 1) + 8));      // (two halves: kkt_partials)
         h->scal.alloc(16);               // [0] eps, [1] norme, [2] normb, [3] abort, [4] speculative norme, [8..11] update status
         HIP_CHECK(hipMemset(h->scal.p, 0, 16 * sizeof(double)));
         h->pin.reset(new PinnedScalars);
         {
             h->ir_stride = 4 * (std::max(h->st.iterative_refinement_max_iter, 0) + 2);
             const size_t nstate = (size_t)h->ir_stride * kMaxNR;
-            const size_t total = nstate + 5 * kMaxNR + 4 + 8 + 3 * kMaxNR;
+            const size_t total = nstate + 5 * kMaxNR + 4 + 8 + 4 + 3 * kMaxNR;
             h->irbuf.alloc(total);
             HIP_CHECK(hipMemset(h->irbuf.p, 0, total * sizeof(double)));
             h->ir_state = h->irbuf.p;
             h->ir_readback = h->irbuf.p + nstate;
             h->ir_sticky = h->ir_readback + 5 * kMaxNR + 4;
-            h->ir_norms = h->ir_sticky + 8;             // several columns: norme0[kMaxNR], normb[kMaxNR], cand[kMaxNR]
+            h->sys_out_dev = h->ir_sticky + 8;          // {dtau, dkappa, tau_num, tau_den} of kkt_solve!: read back with the record in ONE copy
+            h->ir_norms = h->sys_out_dev + 4;           // several columns: norme0[kMaxNR], normb[kMaxNR], cand[kMaxNR]
         }
         // cones
         {
@@ -3232,12 +3234,19 @@ static SpmvDev kkt_spmv(hipkkt_kkt_t h)
 
 // e = b - K xi for nr columns (ld N); ||e_c||_inf -> norm_out[c], optionally ||b_c||_inf -> normb_out[c]; scal[3] carries
 // the persistent solve kernel's abort word along.  Nothing is read back here.
-static void kkt_enqueue_refine_error(hipkkt_kkt_t h, const double* xi, double* norm_out, double* normb_out, int nr)
+// The norms' second stage: a finishing kernel behind the residual, or -- kkt_partials_mode -- left to k_ir_round, which
+// reduces the partial maxima itself (kernels.hpp: IrPartials).  The first residual of a solve leaves its partials in the
+// first half of h->partial, the candidates' residuals in the second half (both are read by the same k_ir_round).
+static bool kkt_partials_mode(hipkkt_kkt_t h, int nr) { return residual_partials_ok(kkt_spmv(h), nr); }
+static double* kkt_partials(hipkkt_kkt_t h, bool candidate) { return h->partial.p + (candidate ? h->partial.n / 2 : 0); }
+static void kkt_enqueue_refine_error(hipkkt_kkt_t h, const double* xi, double* norm_out, double* normb_out, int nr, bool candidate)
 {
     const SpmvDev A = kkt_spmv(h);
+    const bool unfinished = kkt_partials_mode(h, nr);
     int pr = h->prof.begin(3, h->stream);
-    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, h->partial.p, norm_out, h->stream, nr, nr > 1 ? (int64_t)h->K.N : 0,
-                    h->eng->top_abort_word(), h->scal.p + 3, normb_out);
+    // (||b|| rides along with the FIRST residual only; its slot is still named so that the b partials are written)
+    launch_residual(A, h->Kval.p, h->b.p, xi, h->e.p, kkt_partials(h, candidate), unfinished ? nullptr : norm_out, h->stream, nr,
+                    nr > 1 ? (int64_t)h->K.N : 0, h->eng->top_abort_word(), h->scal.p + 3, normb_out);
     h->prof.end(pr, h->stream);
 }
 static void kkt_trisolve(hipkkt_kkt_t h, const double* rhs, double* out, bool allow_top = true, int nr = 1)
@@ -3266,17 +3275,26 @@ static void kkt_launch_ir(hipkkt_kkt_t h, int r, bool first, bool readback, bool
     const hipkkt_settings& st = h->st;
     const IrNorms nm = kkt_ir_norms(h, nr);
     const double* abortw = h->eng->top_abort_word() ? h->scal.p + 3 : nullptr;
+    IrPartials Q;
+    const bool unfinished = kkt_partials_mode(h, nr);
+    if (unfinished) {
+        Q.np = residual_grid(kkt_spmv(h)) + 1;
+        Q.e0 = kkt_partials(h, false);
+        Q.b0 = Q.e0 + (size_t)nr * Q.np;
+        Q.cand = r > 0 ? kkt_partials(h, true) : nullptr;
+        Q.flag_in = h->eng->top_abort_word();
+    }
     launch_ir_round(h->ir_state, h->ir_stride, r, first, nm.norme0, nm.normb, nm.cand, abortw, h->x.p, h->dx.p, h->K.N, nr,
                     st.iterative_refinement_abstol, st.iterative_refinement_reltol, st.iterative_refinement_stop_ratio,
                     std::max(st.iterative_refinement_max_iter, 0), readback ? h->ir_readback : nullptr,
-                    (fold && nr == 1) ? h->ir_sticky : nullptr, h->stream);
-    if (fold && nr > 1) launch_ir_fold(h->ir_state, h->ir_stride, r, nr, abortw, h->ir_sticky, h->stream);
+                    (fold && (nr == 1 || unfinished)) ? h->ir_sticky : nullptr, h->stream, Q);
+    if (fold && nr > 1 && !unfinished) launch_ir_fold(h->ir_state, h->ir_stride, r, nr, abortw, h->ir_sticky, h->stream);
 }
 static void kkt_enqueue_round(hipkkt_kkt_t h, int r, bool first, bool readback, bool fold, int nr)
 {
     kkt_trisolve(h, h->e.p, h->dx.p, true, nr);                                   // dx = K^{-1} e
     launch_axpby_sum(h->dx.p, h->dx.p, h->x.p, (int64_t)h->K.N * nr, h->stream);  // prospective solution x + dx
-    kkt_enqueue_refine_error(h, h->dx.p, kkt_ir_norms(h, nr).cand, nullptr, nr);  // e <- b - K (x + dx), its norm -> cand
+    kkt_enqueue_refine_error(h, h->dx.p, kkt_ir_norms(h, nr).cand, nullptr, nr, true);  // e <- b - K (x + dx), its norm -> cand
     kkt_launch_ir(h, r, first, readback, fold, nr);
 }
 // nr = 1, 2 or 4 right-hand sides (columns of h->b, N apart) share every sweep; each column goes through the
@@ -3303,7 +3321,7 @@ static int kkt_solve_core(hipkkt_kkt_t h, bool may_defer = false, int nr = 1, in
     int R = std::min(max_iter, std::max(h->r_spec, deferred ? 1 : 0));
     const IrNorms nm = kkt_ir_norms(h, nr);
     kkt_trisolve(h, h->b.p, h->x.p, true, nr);        // (deferred mode reads the persistent kernel's abort word at the status query)
-    kkt_enqueue_refine_error(h, h->x.p, nm.norme0, nm.normb, nr);     // e = b - K x, ||e||, ||b||
+    kkt_enqueue_refine_error(h, h->x.p, nm.norme0, nm.normb, nr, false);     // e = b - K x, ||e||, ||b||
     if (R == 0) kkt_launch_ir(h, 0, true, !deferred, deferred, nr);
     for (int r = 1; r <= R; ++r) kkt_enqueue_round(h, r, r == 1, r == R && !deferred, r == R && deferred, nr);
     if (deferred) { h->last_ir = -1; return HIPKKT_OK; }
@@ -3350,6 +3368,13 @@ int hipkkt_kkt_solve_dev(hipkkt_kkt_t h, double* d_lhsx, double* d_lhsz)
     });
 }
 
+int hipkkt_kkt_speculative_rounds(hipkkt_kkt_t h, int set)
+{
+    if (!h) return -1;
+    if (set >= 0) { h->r_spec = std::min(set, std::max(h->st.iterative_refinement_max_iter, 0)); h->spec_low_calls = 0; }
+    return h->r_spec;
+}
+
 int hipkkt_kkt_set_deferred_status(hipkkt_kkt_t h, int defer)
 {
     return guarded([&]() {
@@ -3388,7 +3413,16 @@ static int kkt_eval_sticky(hipkkt_kkt_t h, const double* s, bool* gave_up_out = 
         if (s[0] != 0.0) return HIPKKT_NUMERIC_FAILURE;
         if (s[1] != 0.0) {                                              // some solve would have gone on refining
             h->r_spec = std::min(max_iter, h->r_spec + 1);
+            h->spec_low_calls = 0;
             return HIPKKT_REFINEMENT_INCOMPLETE;
+        }
+        // The speculation depth comes down again: one solve that took two rounds (a borderline accept / stop decision)
+        // would otherwise cost every later solve of the run a wasted sweep pair (seen once as 3.77 instead of 3.36 ms per
+        // step).  Eight records in a row whose solves could all have done with one round fewer: one round fewer.
+        if (s[6] > 0.0 && h->r_spec > 1 && s[3] <= s[6] * (double)(h->r_spec - 1)) {
+            if (++h->spec_low_calls >= 8) { --h->r_spec; h->spec_low_calls = 0; }
+        } else if (s[6] > 0.0) {
+            h->spec_low_calls = 0;
         }
         return HIPKKT_OK;
 }
@@ -3748,9 +3782,9 @@ int hipkkt_kkt_system_init(hipkkt_kkt_t h, const double* q, const double* b)
         HIP_CHECK(hipSetDevice(h->device));
         const size_t n = (size_t)h->K.n, m = (size_t)h->K.m;
         h->sq.alloc(n); h->snegq.alloc(n); h->sb.alloc(m);
-        h->sx1.alloc(n); h->sx2.alloc(n); h->sworkx.alloc(n); h->spa.alloc(n); h->spb.alloc(n); h->spc.alloc(n);
-        h->sz1.alloc(m); h->sz2.alloc(m); h->sworkz.alloc(m); h->sconic.alloc(m);
-        h->sys_partial.alloc(8 * 64); h->sys_dots.alloc(8); h->sys_cached.alloc(4); h->sys_in.alloc(4); h->sys_out.alloc(4);
+        h->sx2.alloc(n); h->sworkx.alloc(n); h->spa.alloc(n); h->spb.alloc(n); h->spc.alloc(n);
+        h->sz2.alloc(m); h->sworkz.alloc(m); h->sconic.alloc(m);
+        h->sys_partial.alloc(8 * 64); h->sys_dots.alloc(8); h->sys_cached.alloc(4); h->sys_in.alloc(4); 
         if (n) HIP_CHECK(hipMemcpyAsync(h->sq.p, q, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (m) HIP_CHECK(hipMemcpyAsync(h->sb.p, b, m * sizeof(double), hipMemcpyHostToDevice, h->stream));
         launch_neg_copy(h->snegq.p, h->sq.p, (int)n, h->stream);
@@ -3878,14 +3912,15 @@ int hipkkt_kkt_system_solve_initial_point(hipkkt_kkt_t h, double* d_x, double* d
 // the part of kkt_solve! behind the solve for (x1, z1) (kktsystem.jl:175-212): dtau, (dx, dz), ds, dkappa
 // with_const: (x2, z2) is new as well (it came out of the same 2-column solve): its terms of tau_den are formed here too
 // addend: Delta_s constant term (sconic, or variables.s itself for the affine step)
-static void sys_finish_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z, double* lhs_tau_kappa,
-                            double rhs_tau, double rhs_kappa, const double* d_var_x, double var_tau, double var_kappa,
-                            bool with_const = false, const double* addend = nullptr)
+// (x1, z1): the solve's solution where the sweeps left it (h->x: no copy); it is consumed before the next solve
+static void sys_finish_step(hipkkt_kkt_t h, const double* x1, const double* z1, double* d_lhs_x, double* d_lhs_s, double* d_lhs_z,
+                            double* lhs_tau_kappa, double rhs_tau, double rhs_kappa, const double* d_var_x, double var_tau,
+                            double var_kappa, bool with_const = false, const double* addend = nullptr, const Publish& pub = Publish{})
 {
     const int n = h->K.n, m = h->K.m;
     hipStream_t st = h->stream;
     // P x1 and P (xi - x2), xi = x / tau, in one pass (xi - x2 kept in workx for its dot product)
-    launch_P_spmv2(sys_spmv(h), h->Kval.p, h->sx1.p, d_var_x, h->sx2.p, var_tau, h->spa.p, h->spb.p, h->sworkx.p,
+    launch_P_spmv2(sys_spmv(h), h->Kval.p, x1, d_var_x, h->sx2.p, var_tau, h->spa.p, h->spb.p, h->sworkx.p,
                    with_const ? h->spc.p : nullptr, n, st);
     DotPairs P{};
     P.npairs = with_const ? 7 : 4;
@@ -3894,18 +3929,18 @@ static void sys_finish_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, do
         P.a[5] = h->sb.p; P.b[5] = h->sz2.p; P.len[5] = m;
         P.a[6] = h->sx2.p; P.b[6] = h->spc.p; P.len[6] = n;
     }
-    P.a[0] = h->sq.p; P.b[0] = h->sx1.p; P.len[0] = n;
-    P.a[1] = h->sb.p; P.b[1] = h->sz1.p; P.len[1] = m;
+    P.a[0] = h->sq.p; P.b[0] = x1; P.len[0] = n;
+    P.a[1] = h->sb.p; P.b[1] = z1; P.len[1] = m;
     P.a[2] = d_var_x; P.b[2] = h->spa.p; P.len[2] = n;
     P.a[3] = h->sworkx.p; P.b[3] = h->spb.p; P.len[3] = n;
-    launch_dots4_scalars(P, h->sys_partial.p, h->sys_cached.p, rhs_tau, rhs_kappa, var_tau, var_kappa, h->sys_out.p, st);
-    // (dx, dz) = (x1, z1) + dtau (x2, z2)                                 (:200-203)
-    launch_sys_step(d_lhs_x, d_lhs_z, h->sx1.p, h->sz1.p, h->sx2.p, h->sz2.p, h->sys_out.p, n, m, st);
+    // ... the scalars (:185-196, :206) and (dx, dz) = (x1, z1) + dtau (x2, z2)   (:200-203)
+    launch_dots_sys_step(P, h->sys_partial.p, h->sys_cached.p, rhs_tau, rhs_kappa, var_tau, var_kappa, h->sys_out_dev, d_lhs_x, d_lhs_z,
+                         x1, z1, h->sx2.p, h->sz2.p, n, m, st);
     // ds = -(Hs dz + const)                                               (:206-212)
-    launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st, addend ? addend : h->sconic.p);
+    launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st, addend ? addend : h->sconic.p, pub);
     if (!lhs_tau_kappa) return;                      // (the caller reads sys_out back with its own status record)
     // (dtau, dkappa) through the handle's pinned block: a copy into pageable memory would be staged
-    HIP_CHECK(hipMemcpyAsync(h->pin->h + 48, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h->pin->h + 48, h->sys_out_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     lhs_tau_kappa[0] = h->pin->h[48];
     lhs_tau_kappa[1] = h->pin->h[49];
@@ -3984,17 +4019,18 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
             launch_pack_rhs_affine(h->b.p, h->snegq.p, h->sb.p, d_rhs_x, d_var_s, d_rhs_z, n, m, h->K.p, 2, st);
             int rc = kkt_solve_core(h, false, 2, nullptr, defer);
             if (rc != HIPKKT_OK) return rc;
-            launch_unpack_lhs2(h->sx2.p, h->sz2.p, h->sx1.p, h->sz1.p, h->x.p, n, m, (int64_t)N, st);
+            launch_unpack_lhs(h->sx2.p, h->sz2.p, h->x.p, n, m, st);          // (x2, z2) outlives this solve: a copy of column 0
         } else {
             // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
             if (affine) launch_pack_rhs_affine(h->b.p, nullptr, nullptr, d_rhs_x, d_var_s, d_rhs_z, n, m, h->K.p, 1, st);
             else launch_pack_rhs(h->b.p, d_rhs_x, h->sworkz.p, n, m, h->K.p, st);
             int rc = kkt_solve_core(h, false, 1, nullptr, defer);
             if (rc != HIPKKT_OK) return rc;
-            launch_unpack_lhs(h->sx1.p, h->sz1.p, h->x.p, n, m, st);
         }
-        sys_finish_step(h, d_lhs_x, d_lhs_s, d_lhs_z, defer ? nullptr : lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa,
-                        pair, affine ? d_var_s : nullptr);
+        const double* x1 = h->x.p + (pair ? N : 0);
+        // (deferred: the status record and (dtau, dkappa) behind it reach the host with the call's last kernel)
+        sys_finish_step(h, x1, x1 + n, d_lhs_x, d_lhs_s, d_lhs_z, defer ? nullptr : lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa,
+                        pair, affine ? d_var_s : nullptr, defer ? Publish{h->pin->h + 40, h->ir_sticky, 10, 8} : Publish{});
         return HIPKKT_OK;
     };
     if (h->sys_lazy && h->st.iterative_refinement_enable) {
@@ -4005,10 +4041,7 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
         h->sys_update_unread = false;
         int rc = run(true);
         if (rc != HIPKKT_OK) return rc;
-        HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(h->pin->h + 48, h->sys_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-        launch_zero_ints((int*)h->ir_sticky, 16, st);
-        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipStreamSynchronize(st));           // (pin->h[40..49]: the record, then dtau, dkappa -- published by run's last kernel)
         bool gave_up = false;
         rc = kkt_eval_sticky(h, h->pin->h + 40, &gave_up, true);
         h->last_ir = (int64_t)h->pin->h[43];           // this call's refinement rounds, summed over its columns (as the synchronous path reports)

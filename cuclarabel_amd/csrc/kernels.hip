@@ -289,14 +289,18 @@ __global__ void k_finish_norm(const double* __restrict__ partial, int nparts, do
         if (threadIdx.x == 0) bout[blockIdx.x] = w;
     }
 }
+int residual_grid(const SpmvDev& A)
+{
+    const int rows_per_block = 256 / A.lanes_per_row;
+    int g = (A.N + rows_per_block - 1) / rows_per_block;
+    if (g > kNormParts) g = kNormParts;
+    return g < 1 ? 1 : g;
+}
 void launch_residual(const SpmvDev& A, const double* K, const double* b, const double* x, double* e,
                      double* partial, double* norm_out, hipStream_t st, int nrhs, int64_t ld, const int* flag_in,
                      double* flag_out, double* normb_out)
 {
-    int rows_per_block = 256 / A.lanes_per_row;
-    int g = (A.N + rows_per_block - 1) / rows_per_block;
-    if (g > kNormParts) g = kNormParts;
-    if (g < 1) g = 1;
+    const int g = residual_grid(A);
     // ||b||_inf in the same pass (no long rows: every row's b is read here anyway); partial then holds nrhs * (g + 1)
     // residual partials followed by nrhs * g partials of b, at most kResidualPartial(nrhs) doubles
     double* bpartial = (normb_out && nrhs <= kMaxNormbCols && A.nlong == 0) ? partial + (size_t)nrhs * (g + 1) : nullptr;
@@ -313,6 +317,8 @@ void launch_residual(const SpmvDev& A, const double* K, const double* b, const d
         hipLaunchKernelGGL(k_residual_long_chunks, dim3(A.nchunks, nrhs), dim3(256), 0, st, A, K, x, ld);
         hipLaunchKernelGGL(k_residual_long_finish, dim3(1, nrhs), dim3(256), 0, st, A, b, e, partial, ld, g);
     }
+    // norm_out == nullptr: the caller's next kernel reduces the partials itself (residual_partials_ok; k_ir_round)
+    if (!norm_out) return;
     hipLaunchKernelGGL(k_finish_norm, dim3(nrhs), dim3(256), 0, st, partial, g + 1, norm_out, flag_in, flag_out,
                        (const double*)bpartial, g, normb_out);
     if (normb_out && !bpartial) launch_norm_inf(b, A.N, partial, normb_out, st, nrhs, ld);
@@ -397,23 +403,6 @@ void launch_pack_rhs_affine(double* b, const double* negq, const double* bb, con
 {
     hipLaunchKernelGGL(k_pack_rhs_affine, dim3(grid_for(n + m + p, 256), ncol), dim3(256), 0, st, b, negq, bb, rhs_x, s, rhs_z,
                        n, m, p, ncol);
-}
-// getlhs! for two columns at once: (x2, z2) <- column 0, (x1, z1) <- column 1
-__global__ void k_unpack_lhs2(double* __restrict__ x2, double* __restrict__ z2, double* __restrict__ x1,
-                              double* __restrict__ z1, const double* __restrict__ x, int n, int m, int64_t N)
-{
-    const double* __restrict__ src = x + (int64_t)blockIdx.y * N;
-    double* __restrict__ ox = blockIdx.y == 0 ? x2 : x1;
-    double* __restrict__ oz = blockIdx.y == 0 ? z2 : z1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x) {
-        if (i < n) ox[i] = src[i];
-        else oz[i - n] = src[i];
-    }
-}
-void launch_unpack_lhs2(double* x2, double* z2, double* x1, double* z1, const double* x, int n, int m, int64_t N, hipStream_t st)
-{
-    if (n + m <= 0) return;
-    hipLaunchKernelGGL(k_unpack_lhs2, dim3(grid_for(n + m, 256), 2), dim3(256), 0, st, x2, z2, x1, z1, x, n, m, N);
 }
 __global__ void k_accept_columns(double* __restrict__ x, const double* __restrict__ cand, double* __restrict__ e,
                                  const double* __restrict__ e2, const int* __restrict__ mask, int N)
@@ -503,22 +492,71 @@ __device__ inline void ir_initial(double norme0, double normb, double abstol, do
 // grid.y = right-hand side column c: its state at state + c * state_stride, norms norme0[c], normb[c], cand[c], vectors
 // x + c * ld, dx + c * ld, read-back record at readback + 5 c.  The sticky record is folded by column 0 only when
 // there is a single column (several columns: k_ir_fold).
-__global__ void k_ir_round(double* __restrict__ state, int state_stride, int r, int first, const double* __restrict__ norme0,
-                           const double* __restrict__ normb, const double* __restrict__ cand_norm,
+// The residual kernels' partial maxima may come un-finished (IrPartials; launch_residual with norm_out = nullptr): every
+// workgroup of this kernel then takes the maximum over them itself -- a maximum does not depend on the order, so all
+// workgroups decide alike -- instead of a one-workgroup kernel behind every residual (~5-8 us each on the solve's chain
+// of dependent launches).  The grid is small (kIrBlocks) so that the partials are read a hundred times, not a thousand.
+// the maxima of up to three arrays of partials at once (null: 0), in every thread: one round of loads, one pair of barriers
+__device__ inline void block_max3_of(const double* __restrict__ p0, int n0, const double* __restrict__ p1, int n1,
+                                     const double* __restrict__ p2, int n2, double (&out)[3], double (*sh)[4])
+{
+    double v[3] = {0.0, 0.0, 0.0};
+    // (every load of the three arrays issued before the first maximum: one memory round trip, not one per array and trip)
+    constexpr int kTrips = (kNormParts + 1 + 255) / 256;
+    double t[3][kTrips];
+#pragma unroll
+    for (int k = 0; k < kTrips; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        t[0][k] = (p0 && i < n0) ? p0[i] : 0.0;
+        t[1][k] = (p1 && i < n1) ? p1[i] : 0.0;
+        t[2][k] = (p2 && i < n2) ? p2[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kTrips; ++k) { v[0] = fmax(v[0], t[0][k]); v[1] = fmax(v[1], t[1][k]); v[2] = fmax(v[2], t[2][k]); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] = fmax(v[k], __shfl_down(v[k], o, 64));
+        if (lane == 0) sh[k][wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = fmax(fmax(sh[k][0], sh[k][1]), fmax(sh[k][2], sh[k][3]));
+}
+__global__ __launch_bounds__(256) void k_ir_round(double* __restrict__ state, int state_stride, int r, int first, double* __restrict__ norme0,
+                           double* __restrict__ normb, const double* __restrict__ cand_norm,
                            const double* __restrict__ abort_word, double* __restrict__ x, const double* __restrict__ dx,
                            int n, int64_t ld, double abstol, double reltol, double stop_ratio, int max_iter,
-                           double* __restrict__ readback, double* __restrict__ sticky)
+                           double* __restrict__ readback, double* __restrict__ sticky, IrPartials Q, int several)
 {
+    __shared__ double sh[3][4];
     const int c = blockIdx.y;
     state += (int64_t)c * state_stride;
     x += c * ld;
     dx += c * ld;
     double active, rounds, bad, norme;
-    if (r == 0 || first) ir_initial(norme0[c], normb[c], abstol, reltol, max_iter, active, rounds, bad, norme);
-    else { active = state[4 * (r - 1)]; rounds = state[4 * (r - 1) + 1]; bad = state[4 * (r - 1) + 2]; norme = state[4 * (r - 1) + 3]; }
+    double nb = 0.0, cand_v = 0.0;
+    const bool initial = r == 0 || first;
+    double mx[3] = {0.0, 0.0, 0.0};
+    if (Q.e0 || Q.cand)
+        block_max3_of((initial && Q.e0) ? Q.e0 + (int64_t)c * Q.np : nullptr, Q.np, (initial && Q.e0) ? Q.b0 + (int64_t)c * (Q.np - 1) : nullptr,
+                      Q.np - 1, (r > 0 && Q.cand) ? Q.cand + (int64_t)c * Q.np : nullptr, Q.np, mx, sh);
+    if (initial) {
+        double ne0;
+        if (Q.e0) {
+            ne0 = mx[0]; nb = mx[1];
+            if (blockIdx.x == 0 && threadIdx.x == 0) { norme0[c] = ne0; normb[c] = nb; }       // (later rounds read them)
+        } else { ne0 = norme0[c]; nb = normb[c]; }
+        ir_initial(ne0, nb, abstol, reltol, max_iter, active, rounds, bad, norme);
+    } else {
+        active = state[4 * (r - 1)]; rounds = state[4 * (r - 1) + 1]; bad = state[4 * (r - 1) + 2]; norme = state[4 * (r - 1) + 3];
+        nb = normb[c];
+    }
+    if (r > 0) cand_v = Q.cand ? mx[2] : cand_norm[c];
     bool accept = false;
     if (r > 0 && active != 0.0) {
-        const double cand = cand_norm[c];
+        const double cand = cand_v;
         rounds += 1.0;
         if (!isfinite(cand)) {                      // :429: return is_success = false
             bad = 1.0; active = 0.0;
@@ -528,14 +566,22 @@ __global__ void k_ir_round(double* __restrict__ state, int state_stride, int r, 
             else accept = true;
             if (accept) norme = cand;
             // the head of the next iteration (:407-417): tolerance met, or max_iter rounds done
-            if (active != 0.0 && (r >= max_iter || norme <= abstol + reltol * normb[c])) active = 0.0;
+            if (active != 0.0 && (r >= max_iter || norme <= abstol + reltol * nb)) active = 0.0;
         }
     }
-    if (accept)
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = dx[i];
+    if (accept) {
+        const int stride = gridDim.x * blockDim.x;
+        for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {       // (four loads in flight)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (i0 + u * stride < n) ? dx[i0 + u * stride] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + u * stride < n) x[i0 + u * stride] = v[u];
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         state[4 * r] = active; state[4 * r + 1] = rounds; state[4 * r + 2] = bad; state[4 * r + 3] = norme;
-        const double aborted = abort_word ? abort_word[0] : 0.0;
+        const double aborted = Q.flag_in ? (Q.flag_in[0] ? 1.0 : 0.0) : (abort_word ? abort_word[0] : 0.0);
         if (readback) {
             double* rb = readback + 5 * c;
             rb[0] = active; rb[1] = rounds; rb[2] = bad; rb[3] = norme; rb[4] = aborted;
@@ -544,18 +590,25 @@ __global__ void k_ir_round(double* __restrict__ state, int state_stride, int r, 
             if (bad != 0.0) sticky[0] = 1.0;
             if (active != 0.0) sticky[1] = 1.0;
             if (aborted != 0.0) sticky[2] = 1.0;
-            sticky[3] += rounds;
-            sticky[6] += 1.0;
+            if (several) {                          // (every column's workgroup 0 adds its own: whole numbers, any order)
+                (void)__hip_atomic_fetch_add(sticky + 3, rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(sticky + 6, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                sticky[3] += rounds;
+                sticky[6] += 1.0;
+            }
         }
     }
 }
-void launch_ir_round(double* state, int state_stride, int r, bool first, const double* norme0, const double* normb,
+void launch_ir_round(double* state, int state_stride, int r, bool first, double* norme0, double* normb,
                      const double* cand, const double* abort_word, double* x, const double* dx, int n, int nr, double abstol,
-                     double reltol, double stop_ratio, int max_iter, double* readback, double* sticky, hipStream_t st)
+                     double reltol, double stop_ratio, int max_iter, double* readback, double* sticky, hipStream_t st,
+                     const IrPartials& Q)
 {
-    const int g = r == 0 ? 1 : grid_for(n, 256);
+    constexpr int kIrBlocks = 304;
+    const int g = r == 0 ? 1 : grid_for(n, 256, Q.e0 || Q.cand ? kIrBlocks : 4096);
     hipLaunchKernelGGL(k_ir_round, dim3(g, nr), dim3(256), 0, st, state, state_stride, r, first ? 1 : 0, norme0, normb, cand,
-                       abort_word, x, dx, n, (int64_t)n, abstol, reltol, stop_ratio, max_iter, readback, sticky);
+                       abort_word, x, dx, n, (int64_t)n, abstol, reltol, stop_ratio, max_iter, readback, sticky, Q, nr > 1 ? 1 : 0);
 }
 // several columns: their final states (slot r of each) joined into the sticky record by one thread
 __global__ void k_ir_fold(const double* __restrict__ state, int state_stride, int r, int nr, const double* __restrict__ abort_word,
@@ -624,10 +677,14 @@ void launch_check_finite(const double* v, int n, int* flag, hipStream_t st)
 //                                                     coneops_socone.jl:75-192
 //    PSD (side <= 48)  A = R R' via Cholesky + Jacobi eigen, Hs = A (x)_s A   coneops_psdtrianglecone.jl:78-161
 // =====================================================================================
-__global__ void k_cone_elementwise(ConeDev C, ConeState S, const double* __restrict__ s,
-                                   const double* __restrict__ z, int m)
+// An elementwise kernel and its one-wave-per-second-order-cone companion touch disjoint rows, so they go out as ONE
+// launch (k_cone_scaling, k_mul_Hs, k_sys_offset below): workgroups [0, ge) run the elementwise body over a grid of ge,
+// the ones behind them take four cones each, a wave per cone.  On the step's chain of dependent launches a kernel
+// boundary is ~5 us whatever the work.
+__device__ inline void cone_elementwise_body(const ConeDev& C, const ConeState& S, const double* __restrict__ s,
+                                             const double* __restrict__ z, int m, int bx, int nb)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    for (int i = bx * 256 + threadIdx.x; i < m; i += nb * 256) {
         const int c = C.elem_cone[i];
         const int kind = C.kind[c];
         if (kind == 0) {
@@ -651,12 +708,11 @@ __device__ inline double wave_sum(double v)
 }
 
 // one wave per second-order cone
-__global__ __launch_bounds__(64) void k_cone_soc(ConeDev C, ConeState S, const double* __restrict__ s,
-                                                 const double* __restrict__ z)
+__device__ inline void cone_soc_body(const ConeDev& C, const ConeState& S, const double* __restrict__ s,
+                                     const double* __restrict__ z, int ci, int lane)
 {
-    const int c = C.soc_list[blockIdx.x];
+    const int c = C.soc_list[ci];
     const int off = C.off[c], n = C.numel[c];
-    const int lane = threadIdx.x;
     const double* sc = s + off;
     const double* zc = z + off;
     double* w = S.w + off;
@@ -702,7 +758,7 @@ __global__ __launch_bounds__(64) void k_cone_soc(ConeDev C, ConeState S, const d
         for (int i = 1 + lane; i < n; i += 64) lam[i] = (a * sc[i] + b * zc[i]) * inv * sz;
         if (lane == 0) lam[0] = gamma * sz;
     }
-    __syncthreads();      // w[] written above is re-read below by other lanes of this wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // w[] written above is re-read below by other lanes of this wave
     const double eta2 = eta * eta;
     double* Hs = S.Hs + C.boff[c];
     const int sidx = C.sidx[c];
@@ -736,6 +792,14 @@ __global__ __launch_bounds__(64) void k_cone_soc(ConeDev C, ConeState S, const d
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_cone_scaling(ConeDev C, ConeState S, const double* __restrict__ s,
+                                                      const double* __restrict__ z, int m, int ge)
+{
+    if ((int)blockIdx.x < ge) { cone_elementwise_body(C, S, s, z, m, blockIdx.x, ge); return; }
+    const int ci = ((int)blockIdx.x - ge) * 4 + (int)(threadIdx.x >> 6);
+    if (ci < C.nsoc) cone_soc_body(C, S, s, z, ci, threadIdx.x & 63);
 }
 
 // -------------------------------------------------------------------------------------
@@ -979,8 +1043,8 @@ __global__ __launch_bounds__(256) void k_mul_Hs_psd(ConeDev C, ConeState S, doub
 void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, const double* z, int m,
                          hipStream_t st)
 {
-    if (m > 0) hipLaunchKernelGGL(k_cone_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, s, z, m);
-    if (C.nsoc > 0) hipLaunchKernelGGL(k_cone_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, s, z);
+    const int ge = m > 0 ? grid_for(m, 256) : 0, gs = (C.nsoc + 3) / 4;
+    if (ge + gs > 0) hipLaunchKernelGGL(k_cone_scaling, dim3(ge + gs), dim3(256), 0, st, C, S, s, z, m, ge);
     if (C.npsd > 0) {
         static PerDeviceOnce once;
         once.run([]() { return set_max_lds(k_cone_psd, 150 * 1024); });
@@ -991,10 +1055,10 @@ void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, 
 
 // y = W'W x : zero -> 0, NN -> w*(w*x), SOC -> eta^2 (2 w (w'x) - J x)   (mul_Hs!); with an addend: y = -(W'W x + addend),
 // the Delta_s recovery of kkt_solve! (kktsystem.jl:206-212) in the same pass
-__global__ void k_mul_Hs_elementwise(ConeDev C, ConeState S, double* __restrict__ y, const double* __restrict__ x, int m,
-                                     const double* __restrict__ addend)
+__device__ inline void mul_Hs_elementwise_body(const ConeDev& C, const ConeState& S, double* __restrict__ y,
+                                               const double* __restrict__ x, int m, const double* __restrict__ addend, int bx, int nb)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    for (int i = bx * 256 + threadIdx.x; i < m; i += nb * 256) {
         const int kind = C.kind[C.elem_cone[i]];
         double v;
         if (kind == 0) v = 0.0;
@@ -1003,11 +1067,11 @@ __global__ void k_mul_Hs_elementwise(ConeDev C, ConeState S, double* __restrict_
         y[i] = addend ? -(v + addend[i]) : v;
     }
 }
-__global__ __launch_bounds__(64) void k_mul_Hs_soc(ConeDev C, ConeState S, double* __restrict__ y,
-                                                   const double* __restrict__ x, const double* __restrict__ addend)
+__device__ inline void mul_Hs_soc_body(const ConeDev& C, const ConeState& S, double* __restrict__ y,
+                                       const double* __restrict__ x, const double* __restrict__ addend, int ci, int lane)
 {
-    const int c = C.soc_list[blockIdx.x];
-    const int off = C.off[c], n = C.numel[c], lane = threadIdx.x;
+    const int c = C.soc_list[ci];
+    const int off = C.off[c], n = C.numel[c];
     const double* w = S.w + off;
     double dot = 0.0;
     for (int i = lane; i < n; i += 64) dot += w[i] * x[off + i];
@@ -1018,6 +1082,25 @@ __global__ __launch_bounds__(64) void k_mul_Hs_soc(ConeDev C, ConeState S, doubl
         const double v = ((i == 0 ? -xi : xi) + dot * w[i]) * e2;
         y[off + i] = addend ? -(v + addend[off + i]) : v;
     }
+}
+__device__ inline void publish_record(const Publish& P)
+{
+    for (int i = 0; i < P.n; ++i) P.dst[i] = P.rec[i];
+    for (int i = 0; i < P.nzero; ++i) P.rec[i] = 0.0;
+}
+__global__ void k_publish(Publish P) { if (blockIdx.x == 0 && threadIdx.x == 0) publish_record(P); }
+void launch_publish(const Publish& p, hipStream_t st)
+{
+    if (p.dst) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, p);
+}
+__global__ __launch_bounds__(256) void k_mul_Hs(ConeDev C, ConeState S, double* __restrict__ y, const double* __restrict__ x,
+                                                int m, const double* __restrict__ addend, int ge, Publish P)
+{
+    // (the record was completed by earlier kernels of the stream and is not touched by this one)
+    if (P.dst && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) publish_record(P);
+    if ((int)blockIdx.x < ge) { mul_Hs_elementwise_body(C, S, y, x, m, addend, blockIdx.x, ge); return; }
+    const int ci = ((int)blockIdx.x - ge) * 4 + (int)(threadIdx.x >> 6);
+    if (ci < C.nsoc) mul_Hs_soc_body(C, S, y, x, addend, ci, threadIdx.x & 63);
 }
 // A = R R' per PSD cone, from a caller-supplied R (hipkkt_kkt_system_update_cones); one workgroup per cone
 __global__ __launch_bounds__(256) void k_psd_A_from_R(ConeDev C, ConeState S)
@@ -1131,14 +1214,17 @@ void launch_cone_from_scaling(const ConeDev& C, const ConeState& S, int m, hipSt
         hipLaunchKernelGGL(k_psd_hs_from_A, dim3(C.npsd), dim3(256), lds, st, C, S);
     }
 }
-void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend)
+void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend,
+                   const Publish& pub)
 {
-    if (m > 0) hipLaunchKernelGGL(k_mul_Hs_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, y, x, m, addend);
-    if (C.nsoc > 0) hipLaunchKernelGGL(k_mul_Hs_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, y, x, addend);
+    const int ge = m > 0 ? grid_for(m, 256) : 0, gs = (C.nsoc + 3) / 4;
+    const bool ride = ge + gs > 0 && C.npsd == 0;          // (the publication rides with the LAST kernel of the call)
+    if (ge + gs > 0) hipLaunchKernelGGL(k_mul_Hs, dim3(ge + gs), dim3(256), 0, st, C, S, y, x, m, addend, ge, ride ? pub : Publish{});
     if (C.npsd > 0) {
         const size_t lds = (size_t)3 * C.psd_kmax * C.psd_kmax * sizeof(double);
         hipLaunchKernelGGL(k_mul_Hs_psd, dim3(C.npsd), dim3(256), lds, st, C, S, y, x, addend);
     }
+    if (!ride) launch_publish(pub, st);
 }
 
 }  // namespace hipkkt
@@ -1149,11 +1235,12 @@ void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double
 // =====================================================================================
 namespace hipkkt {
 
-__global__ void k_sys_offset_elementwise(ConeDev C, ConeState S, double* __restrict__ konst, double* __restrict__ workz,
-                                         const double* __restrict__ ds, const double* __restrict__ z,
-                                         const double* __restrict__ rhs_z, int m, int affine)
+__device__ inline void sys_offset_elementwise_body(const ConeDev& C, const ConeState& S, double* __restrict__ konst,
+                                                   double* __restrict__ workz, const double* __restrict__ ds,
+                                                   const double* __restrict__ z, const double* __restrict__ rhs_z, int m,
+                                                   int affine, int bx, int nb)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    for (int i = bx * 256 + threadIdx.x; i < m; i += nb * 256) {
         double o;
         if (affine) {
             o = ds[i];                                  // Delta_s_const_term = variables.s (kktsystem.jl:157-158)
@@ -1169,13 +1256,12 @@ __global__ void k_sys_offset_elementwise(ConeDev C, ConeState S, double* __restr
 }
 
 // out = W'(lambda \ ds) in the reference's more stable form (coneops_socone.jl:241-268); one wave per cone
-__global__ __launch_bounds__(64) void k_sys_offset_soc(ConeDev C, ConeState S, double* __restrict__ konst,
-                                                       double* __restrict__ workz, const double* __restrict__ ds,
-                                                       const double* __restrict__ z, const double* __restrict__ rhs_z)
+__device__ inline void sys_offset_soc_body(const ConeDev& C, const ConeState& S, double* __restrict__ konst,
+                                           double* __restrict__ workz, const double* __restrict__ ds,
+                                           const double* __restrict__ z, const double* __restrict__ rhs_z, int ci, int lane)
 {
-    const int c = C.soc_list[blockIdx.x];
+    const int c = C.soc_list[ci];
     const int off = C.off[c], n = C.numel[c];
-    const int lane = threadIdx.x;
     const double* dsc = ds + off;
     const double* zc = z + off;
     const double* w = S.w + off;
@@ -1249,6 +1335,14 @@ __global__ __launch_bounds__(256) void k_sys_offset_psd(ConeDev C, ConeState S, 
     }
 }
 
+__global__ __launch_bounds__(256) void k_sys_offset(ConeDev C, ConeState S, double* __restrict__ konst, double* __restrict__ workz,
+                                                    const double* __restrict__ ds, const double* __restrict__ z,
+                                                    const double* __restrict__ rhs_z, int m, int affine, int ge)
+{
+    if ((int)blockIdx.x < ge) { sys_offset_elementwise_body(C, S, konst, workz, ds, z, rhs_z, m, affine, blockIdx.x, ge); return; }
+    const int ci = ((int)blockIdx.x - ge) * 4 + (int)(threadIdx.x >> 6);
+    if (ci < C.nsoc) sys_offset_soc_body(C, S, konst, workz, ds, z, rhs_z, ci, threadIdx.x & 63);
+}
 bool launch_sys_offset(const ConeDev& C, const ConeState& S, double* konst, double* workz, const double* ds,
                        const double* z, const double* rhs_z, int m, bool affine, hipStream_t st)
 {
@@ -1259,10 +1353,8 @@ bool launch_sys_offset(const ConeDev& C, const ConeState& S, double* konst, doub
         const size_t lds = (size_t)3 * C.psd_kmax * C.psd_kmax * sizeof(double);
         hipLaunchKernelGGL(k_sys_offset_psd, dim3(C.npsd), dim3(256), lds, st, C, S, konst, workz, ds, rhs_z);
     }
-    hipLaunchKernelGGL(k_sys_offset_elementwise, dim3(grid_for(m, 256)), dim3(256), 0, st, C, S, konst, workz, ds, z,
-                       rhs_z, m, affine ? 1 : 0);
-    if (!affine && C.nsoc > 0)
-        hipLaunchKernelGGL(k_sys_offset_soc, dim3(C.nsoc), dim3(64), 0, st, C, S, konst, workz, ds, z, rhs_z);
+    const int ge = grid_for(m, 256), gs = affine ? 0 : (C.nsoc + 3) / 4;
+    hipLaunchKernelGGL(k_sys_offset, dim3(ge + gs), dim3(256), 0, st, C, S, konst, workz, ds, z, rhs_z, m, affine ? 1 : 0, ge);
     return true;
 }
 
@@ -1403,39 +1495,6 @@ void launch_sys_scalars(const double* dots, const double* cached, const double* 
 {
     hipLaunchKernelGGL(k_sys_scalars, dim3(1), dim3(64), 0, st, dots, cached, scal_in, out);
 }
-// the second stage of the four dot products and the scalars of kkt_solve! in one single-workgroup kernel; the
-// caller's scalars come by value (a 32-byte copy from pageable host memory would drain the stream first)
-__global__ __launch_bounds__(64) void k_dots_finish_scalars(const double* __restrict__ partial, double* __restrict__ cached,
-                                                            double rhs_tau, double rhs_kappa, double tau, double kappa,
-                                                            double* __restrict__ out, int npairs)
-{
-    // npairs = 7: pairs 4..6 are the x2-only terms {q.x2, b.z2, x2.(P x2)}; they are stored to `cached` for the
-    // iteration's later solves (what sys_cache_constant_terms does as a pass of its own)
-    __shared__ double d[8];
-    const int p = threadIdx.x;
-    if (p < npairs) {
-        double acc = 0.0;
-        for (int i = 0; i < kDotBlocks; ++i) acc += partial[p * kDotBlocks + i];      // (the order of k_dots_finish)
-        d[p] = acc;
-    }
-    __syncthreads();
-    if (p != 0) return;
-    if (npairs == 7) { cached[0] = d[4]; cached[1] = d[5]; cached[2] = d[6]; }
-    const double tau_num = rhs_tau - rhs_kappa / tau + d[0] + d[1] + 2.0 * (d[2] / tau);
-    double tau_den = kappa / tau - cached[0] - cached[1];
-    tau_den += d[3] - cached[2];
-    const double dtau = tau_num / tau_den;
-    out[0] = dtau;
-    out[1] = -(rhs_kappa + kappa * dtau) / tau;
-    out[2] = tau_num;
-    out[3] = tau_den;
-}
-void launch_dots4_scalars(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
-                          double kappa, double* out, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_dots, dim3(kDotBlocks, P.npairs), dim3(256), 0, st, P, partial);
-    hipLaunchKernelGGL(k_dots_finish_scalars, dim3(1), dim3(64), 0, st, partial, cached, rhs_tau, rhs_kappa, tau, kappa, out, P.npairs);
-}
 // (dx, dz) = (x1, z1) + dtau (x2, z2) in one launch (kktsystem.jl:200-203); dtau = scal[0] on the device
 __global__ void k_sys_step(double* __restrict__ dx, double* __restrict__ dz, const double* __restrict__ x1,
                            const double* __restrict__ z1, const double* __restrict__ x2, const double* __restrict__ z2,
@@ -1452,6 +1511,57 @@ void launch_sys_step(double* dx, double* dz, const double* x1, const double* z1,
 {
     if (n + m <= 0) return;
     hipLaunchKernelGGL(k_sys_step, dim3(grid_for(n + m, 256)), dim3(256), 0, st, dx, dz, x1, z1, x2, z2, scal, n, m);
+}
+// The second stage of the dot products (k_dots' partial sums), the scalars of kkt_solve! and the step in ONE launch:
+// every workgroup adds the partial sums up itself -- npairs x 64 doubles from L2, the same order everywhere, so every
+// workgroup holds the same dtau -- instead of a one-workgroup kernel in between (~5 us on the step's chain of dependent
+// launches).  Workgroup 0 stores {dtau, dkappa, tau_num, tau_den} and, with npairs = 7, the x2-only terms.
+__global__ __launch_bounds__(256) void k_sys_step_scalars(double* __restrict__ dx, double* __restrict__ dz, const double* __restrict__ x1,
+                                                          const double* __restrict__ z1, const double* __restrict__ x2,
+                                                          const double* __restrict__ z2, const double* __restrict__ partial,
+                                                          double* __restrict__ cached, double rhs_tau, double rhs_kappa, double tau,
+                                                          double kappa, double* __restrict__ out, int npairs, int n, int m)
+{
+    __shared__ double d[8];
+    __shared__ double sh_dtau;
+    const int p = threadIdx.x;
+    if (p < npairs) {
+        double acc = 0.0;
+        for (int i = 0; i < kDotBlocks; ++i) acc += partial[p * kDotBlocks + i];      // (the order of k_dots_finish)
+        d[p] = acc;
+    }
+    __syncthreads();
+    if (p == 0) {
+        // npairs = 7: pairs 4..6 are the x2-only terms {q.x2, b.z2, x2.(P x2)}, kept in `cached` for the iteration's later
+        // solves; otherwise they come from there (kktsystem.jl:185-196; xi = x / tau, so xi.(P x1) = d[2] / tau)
+        const double c0 = npairs == 7 ? d[4] : cached[0], c1 = npairs == 7 ? d[5] : cached[1], c2 = npairs == 7 ? d[6] : cached[2];
+        const double tau_num = rhs_tau - rhs_kappa / tau + d[0] + d[1] + 2.0 * (d[2] / tau);
+        double tau_den = kappa / tau - c0 - c1;
+        tau_den += d[3] - c2;
+        const double dtau = tau_num / tau_den;
+        sh_dtau = dtau;
+        if (blockIdx.x == 0) {
+            if (npairs == 7) { cached[0] = c0; cached[1] = c1; cached[2] = c2; }
+            out[0] = dtau;
+            out[1] = -(rhs_kappa + kappa * dtau) / tau;          // :206
+            out[2] = tau_num;
+            out[3] = tau_den;
+        }
+    }
+    __syncthreads();
+    const double dtau = sh_dtau;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x) {
+        if (i < n) dx[i] = x1[i] + dtau * x2[i];
+        else dz[i - n] = z1[i - n] + dtau * z2[i - n];
+    }
+}
+void launch_dots_sys_step(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
+                          double kappa, double* out, double* dx, double* dz, const double* x1, const double* z1, const double* x2,
+                          const double* z2, int n, int m, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dots, dim3(kDotBlocks, P.npairs), dim3(256), 0, st, P, partial);
+    hipLaunchKernelGGL(k_sys_step_scalars, dim3(grid_for(std::max(n + m, 1), 256)), dim3(256), 0, st, dx, dz, x1, z1, x2, z2,
+                       (const double*)partial, cached, rhs_tau, rhs_kappa, tau, kappa, out, P.npairs, n, m);
 }
 
 __global__ void k_neg_sum(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int n)

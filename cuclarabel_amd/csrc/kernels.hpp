@@ -400,11 +400,20 @@ void launch_unpack_lhs(double* lhsx, double* lhsz, const double* x, int n, int m
 // The refinement loop's accept / stop rule (kktsolver_directldl.jl:389-449) evaluated on the device after round r
 // (kernels.hip, k_ir_round), for nr right-hand side columns at once (column c: state + c state_stride, norme0[c],
 // normb[c], cand[c], x + c n, dx + c n, readback + 5 c).  state holds 4 doubles per round {active, rounds, bad, norme};
-// readback (nullable): 5 doubles {state of round r, abort} per column for ONE copy to the host; sticky (nullable, one
-// column only): the deferred-status record {bad, more, abort, rounds, #dyn. regularisations, eps, solves}.
-void launch_ir_round(double* state, int state_stride, int r, bool first, const double* norme0, const double* normb,
+// readback (nullable): 5 doubles {state of round r, abort} per column for ONE copy to the host; sticky (nullable): the
+// deferred-status record {bad, more, abort, rounds, #dyn. regularisations, eps, solves} (several columns: each adds its own).
+// IrPartials: the residual kernels' partial maxima left un-finished (launch_residual with norm_out = nullptr, allowed when
+// residual_partials_ok): column c's np = residual_grid + 1 partials of ||e0|| at e0 + c np, its np - 1 of ||b|| at
+// b0 + c (np - 1), of the candidate's ||e|| at cand + c np -- the kernel takes the maxima itself and stores ||e0||, ||b||
+// to norme0 / normb for later rounds.  flag_in: the sweeps' abort word (instead of abort_word, its copy as a double).
+// Null pointers: the norms come finished in norme0 / normb / cand.
+struct IrPartials { const double* e0 = nullptr; const double* b0 = nullptr; const double* cand = nullptr; int np = 0; const int* flag_in = nullptr; };
+void launch_ir_round(double* state, int state_stride, int r, bool first, double* norme0, double* normb,
                      const double* cand, const double* abort_word, double* x, const double* dx, int n, int nr, double abstol,
-                     double reltol, double stop_ratio, int max_iter, double* readback, double* sticky, hipStream_t st);
+                     double reltol, double stop_ratio, int max_iter, double* readback, double* sticky, hipStream_t st,
+                     const IrPartials& Q = IrPartials{});
+int residual_grid(const SpmvDev& A);     // workgroups (= partials per column, less the long rows' one) of the residual kernel
+inline bool residual_partials_ok(const SpmvDev& A, int nrhs) { return A.nlong == 0 && nrhs <= kMaxNormbCols; }
 void launch_ir_fold(const double* state, int state_stride, int r, int nr, const double* abort_word, double* sticky, hipStream_t st);
 void launch_fold_update_status(double* sticky, const double* st4, hipStream_t st);
 void launch_fold_flag(double* sticky, const int* flag, hipStream_t st);
@@ -459,7 +468,13 @@ constexpr int kPsdMaxDim = 48;   // largest PSD side handled by the in-LDS scali
 void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, const double* z, int m,
                          hipStream_t st);
 // addend != null: y = -(W'W x + addend) (the Delta_s recovery of kkt_solve!, kktsystem.jl:206-212)
-void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend = nullptr);
+// Publish: a call's status record handed to the host by the call's LAST kernel instead of a copy and a zeroing launch
+// behind it (~5 us each): n doubles from rec to dst -- page-locked host memory the device can write -- then the first
+// nzero doubles of rec set to zero for the next call.  The host reads dst after synchronising with the stream.
+struct Publish { double* dst = nullptr; double* rec = nullptr; int n = 0, nzero = 0; };
+void launch_publish(const Publish& p, hipStream_t st);            // ... as a kernel of its own
+void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend = nullptr,
+                   const Publish& pub = Publish{});
 void launch_psd_A_from_R(const ConeDev& C, const ConeState& S, hipStream_t st);    // psdA = psdR psdR' per PSD cone
 // Hs blocks, sparse second-order-cone u / v / eta^2 (and psdA) from the scaling already in S (w, eta, psdR): get_Hs! on the device
 void launch_cone_from_scaling(const ConeDev& C, const ConeState& S, int m, hipStream_t st);
@@ -487,13 +502,16 @@ void launch_neg_sum(double* y, const double* a, const double* b, int n, hipStrea
 // (pc nullable: P x2 too; P.npairs = 4, or 7 with the x2-only pairs {q.x2, b.z2, x2.(P x2)} behind them, which are then stored to `cached`)
 void launch_P_spmv2(const SpmvDev& A, const double* Kval, const double* x1, const double* x, const double* x2, double tau,
                     double* pa, double* pb, double* xm_out, double* pc, int n, hipStream_t st);
-void launch_dots4_scalars(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
-                          double kappa, double* out, hipStream_t st);
 void launch_pack_rhs_affine(double* b, const double* negq, const double* bb, const double* rhs_x, const double* s,
                             const double* rhs_z, int n, int m, int p, int ncol, hipStream_t st);
-void launch_unpack_lhs2(double* x2, double* z2, double* x1, double* z1, const double* x, int n, int m, int64_t N, hipStream_t st);
 void launch_sys_step(double* dx, double* dz, const double* x1, const double* z1, const double* x2, const double* z2,
                      const double* scal, int n, int m, hipStream_t st);
+// the dot products of P, the scalars of kkt_solve! (P.npairs = 4, or 7 with the x2-only pairs {q.x2, b.z2, x2.(P x2)} behind
+// them, which are then stored to `cached`) and the step, the scalars formed inside the step kernel (every workgroup adds
+// the partial sums up itself): two launches
+void launch_dots_sys_step(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
+                          double kappa, double* out, double* dx, double* dz, const double* x1, const double* z1, const double* x2,
+                          const double* z2, int n, int m, hipStream_t st);
 void launch_neg_copy(double* y, const double* a, int n, hipStream_t st);                    // y = -a
 
 

@@ -238,6 +238,10 @@ class HipKKTSolver:
     def last_ir_iterations(self):
         return int(_lib.lib().hipkkt_kkt_last_ir_iterations(self._h))
 
+    def speculative_rounds(self, set=-1):
+        """(tests) refinement rounds a solve enqueues ahead of its first status read-back; `set` >= 0 replaces it first"""
+        return int(_lib.lib().hipkkt_kkt_speculative_rounds(self._h, int(set)))
+
     def set_stream(self, stream_ptr):
         check(_lib.lib().hipkkt_kkt_set_stream(self._h, C.c_void_p(stream_ptr)), "hipkkt_kkt_set_stream")
 

@@ -343,6 +343,10 @@ int hipkkt_kkt_get_scaling(hipkkt_kkt_t h, double *lambda, double *psd_R, double
 int hipkkt_kkt_get_scaling_w(hipkkt_kkt_t h, double *w, double *eta);
 double hipkkt_kkt_last_regularizer(hipkkt_kkt_t h);
 int64_t hipkkt_kkt_last_ir_iterations(hipkkt_kkt_t h);
+/* (tests) the refinement rounds a solve enqueues ahead of its first status read-back -- what the previous solves took
+ * (kktsolver_directldl.jl:397-449 decides round by round; here the rounds are enqueued speculatively and the reference's
+ * accept / stop rule runs on the device).  set >= 0 replaces it first; returns the value in force, < 0 on a null handle. */
+int hipkkt_kkt_speculative_rounds(hipkkt_kkt_t h, int set);
 
 /* run on the caller's stream (e.g. torch's current stream) instead of the handle's own */
 int hipkkt_kkt_set_stream(hipkkt_kkt_t h, void *hip_stream);

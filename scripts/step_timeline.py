@@ -11,7 +11,7 @@ f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 seq = [(r['Kernel_Name'].replace('hipkkt::', '').replace('void ', '').split('(')[0], int(r['Start_Timestamp']), int(r['End_Timestamp']),
         int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)) for r in rows]
-idx = [i for i, s in enumerate(seq) if s[0].startswith('k_cone_elementwise')]
+idx = [i for i, s in enumerate(seq) if s[0].startswith(('k_cone_elementwise', 'k_cone_scaling'))]
 i0, i1 = idx[which], idx[which + 1]
 t0, prev_end = seq[i0][1], seq[i0][1]
 for s in seq[i0:i1]:

@@ -471,3 +471,47 @@ def test_system_update_cones_equals_the_device_scaling(affine):
         assert ok
         for a, bb in zip(step_a, step_b):
             np.testing.assert_allclose(a, bb, rtol=1e-9, atol=1e-9 * max(1.0, float(np.max(np.abs(a)))))
+
+
+@pytest.mark.gpu
+def test_speculative_refinement_depth_comes_down_again():
+    """A solve enqueues as many refinement rounds ahead of its status read-back as the previous solves took; the
+    reference's accept / stop rule (kktsolver_directldl.jl:397-449) runs on the device, so rounds beyond the ones the rule
+    takes change nothing but cost a sweep pair each.  One solve that takes two rounds must not leave every later solve
+    of the run with two enqueued: the depth comes down after eight status records in a row whose solves could have
+    done with one fewer -- with bit-identical steps either way."""
+    from cuclarabel_amd import problems
+    from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+    pb = problems.config2(n=4000)
+    rng = np.random.default_rng(53)
+    x = rng.standard_normal(pb.n)
+    rhs_x, rhs_z, rhs_s = rng.standard_normal(pb.n), rng.standard_normal(pb.m), rng.standard_normal(pb.m)
+    args = (0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+    ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+    system = HipKKTSystem(ks)
+    system.init(pb.q, pb.b)
+    system.set_lazy(True)
+
+    def step():
+        assert system.update(pb.s0, pb.z0)
+        ok, aff = system.solve(rhs_x, pb.s0, rhs_z, *args, True)
+        assert ok
+        ok, comb = system.solve(rhs_x, rhs_s, rhs_z, *args, False)
+        assert ok
+        return [np.asarray(v, dtype=float) for v in tuple(aff) + tuple(comb)]
+
+    base = step()
+    assert ks.last_ir_iterations <= 1
+    depth0 = ks.speculative_rounds()
+    assert depth0 <= 1
+    assert ks.speculative_rounds(2) == 2
+    deep = step()
+    for a, b in zip(base, deep):
+        assert np.array_equal(a, b)                      # the extra round is computed and not accepted
+    for _ in range(5):
+        step()                                           # two status records per step
+    assert ks.speculative_rounds() == 1
+    again = step()
+    for a, b in zip(base, again):
+        assert np.array_equal(a, b)
+    assert ks.fallbacks == (0, 0)
