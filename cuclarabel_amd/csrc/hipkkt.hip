@@ -366,6 +366,7 @@ public:
         if (cap_side) (void)hipStreamDestroy(cap_side);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_join2) (void)hipEventDestroy(ev_join2);
         if (ev_side) (void)hipEventDestroy(ev_side);
         if (ov_stream) (void)hipStreamDestroy(ov_stream);
         if (ev_ov_fork) (void)hipEventDestroy(ev_ov_fork);
@@ -376,7 +377,7 @@ public:
 private:
     std::map<std::pair<const void*, const void*>, hipGraphExec_t> factor_graphs, solve_graphs;
     hipStream_t cap_stream = nullptr, cap_side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_side = nullptr;
     long n_factor_calls = 0, n_solve_calls = 0;
 
     void ensure_capture_streams()
@@ -386,6 +387,7 @@ private:
         HIP_CHECK(hipStreamCreateWithFlags(&cap_side, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
     }
 
@@ -649,14 +651,7 @@ private:
                 }
                 launch_schur(a, (const int2*)d_tiles.p, L.tile_begin, L.ntiles, ov_stream, L.ntiles);
                 a.ov = 0;
-                if (q + 1 == nl) {
-                    // The tile stream is joined by the NEXT factorisation, not by this one's tail: every tile has been counted
-                    // by its parent's panel (a root has no tiles), so when the main stream's last panel kernel ends all
-                    // tile data has long been stored; what is left on the tile stream are workgroups on their way out.
-                    // A cross-stream wait here cost ~17 us between the last panel and the status kernel, every step.
-                    HIP_CHECK(hipEventRecord(ev_ov_join, ov_stream));
-                    ov_join_pending = true;
-                }
+                // (the tile stream's join event: behind the loop -- the last W formation may ride on that stream)
                 continue;
             }
             if (L.small) {
@@ -679,19 +674,33 @@ private:
             HIP_CHECK(hipEventRecord(ev_join, side));
             HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
         } else if (eager_fork) {
-            // the solve matrices of the top fronts are formed on the side stream as well, behind the tree: the next
+            // the solve matrices of the top fronts are formed on a side stream as well, behind the tree: the next
             // sweep only needs them when it reaches the top of the tree (enqueue_solve waits for ev_join there), so
-            // their formation hides behind the sweep's bottom levels instead of ending the factorisation
+            // their formation hides behind the sweep's bottom levels instead of ending the factorisation.
+            // In the overlap mode it rides on the TILE stream, which has nothing left to do by now (a root has no tiles):
+            // on the W stream it queued behind the previous fork's formation -- 170 us on a bounded grid, started when the
+            // last run of panels started -- and the first sweep's persistent kernel waited ~50 us for it every step.
             const int done = w_done;
+            hipStream_t last_on = ov_on ? ov_stream : cap_side;
             HIP_CHECK(hipStreamWaitEvent(st, ev_side, 0));
             HIP_CHECK(hipEventRecord(ev_fork, st));
-            HIP_CHECK(hipStreamWaitEvent(cap_side, ev_fork, 0));
-            form_w(d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, cap_side, 0);
+            HIP_CHECK(hipStreamWaitEvent(last_on, ev_fork, 0));
+            form_w(d_tinv_list.p + done, (int)tinv_list.size() - done, tinv_ncmax, last_on, 0);
             HIP_CHECK(hipEventRecord(ev_join, cap_side));
+            if (ov_on) { HIP_CHECK(hipEventRecord(ev_join2, ov_stream)); w2_pending = true; }
             w_pending = true;
         } else {
             // one launch over every supernode, after the tree (all of them independent)
             form_w(d_tinv_list.p, (int)tinv_list.size(), tinv_ncmax, st, 0);
+        }
+        if (ov_on) {
+            // The tile stream is joined by the NEXT factorisation, not by this one's tail: every tile has been counted
+            // by its parent's panel (a root has no tiles), so when the main stream's last panel kernel ends all
+            // tile data has long been stored; what is left on the tile stream are workgroups on their way out (and the
+            // last W formation, which the sweeps wait for by ev_join2).  A cross-stream wait here cost ~17 us between the
+            // last panel and the status kernel, every step.
+            HIP_CHECK(hipEventRecord(ev_ov_join, ov_stream));
+            ov_join_pending = true;
         }
         if (tok) {
             ov_release.on = false;
@@ -1017,12 +1026,14 @@ private:
     }
 
     // the side stream may still be forming the top fronts' solve matrices (enqueue_factor)
-    bool w_pending = false;
+    bool w_pending = false, w2_pending = false;     // (w2: the last formation rode on the tile stream: ev_join2)
     void wait_w(hipStream_t st)
     {
         if (!w_pending) return;
         HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+        if (w2_pending) HIP_CHECK(hipStreamWaitEvent(st, ev_join2, 0));
         w_pending = false;
+        w2_pending = false;
     }
 
     // ---- chained launches (chain_kernels.hip)
