@@ -2482,6 +2482,8 @@ struct hipkkt_kkt_s {
     double *ir_state = nullptr, *ir_readback = nullptr, *ir_sticky = nullptr, *ir_norms = nullptr, *sys_out_dev = nullptr;
     int ir_stride = 0;
     int r_spec = 1;                  // refinement rounds enqueued ahead of the first read-back (= what the previous solve took)
+    bool publish_ok = true;          // the status record reaches the host by the call's last kernel (kernels.hpp: Publish); false: by a copy
+    long long publish_seq = 0;
     int spec_low_calls = 0;          // status records in a row whose solves took fewer rounds than were enqueued (kkt_eval_sticky)
     bool deferred = false;           // hipkkt_kkt_set_deferred_status
     // level C (DefaultKKTSystem on the device, kktsystem.jl:21-215)
@@ -4041,7 +4043,8 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
         const double* x1 = h->x.p + (pair ? N : 0);
         // (deferred: the status record and (dtau, dkappa) behind it reach the host with the call's last kernel)
         sys_finish_step(h, x1, x1 + n, d_lhs_x, d_lhs_s, d_lhs_z, defer ? nullptr : lhs_tau_kappa, rhs_tau, rhs_kappa, d_var_x, var_tau, var_kappa,
-                        pair, affine ? d_var_s : nullptr, defer ? Publish{h->pin->h + 40, h->ir_sticky, 10, 8} : Publish{});
+                        pair, affine ? d_var_s : nullptr,
+                        (defer && h->publish_ok) ? Publish{h->pin->h + 40, h->ir_sticky, 10, 8, (double)++h->publish_seq} : Publish{});
         return HIPKKT_OK;
     };
     if (h->sys_lazy && h->st.iterative_refinement_enable) {
@@ -4052,7 +4055,25 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
         h->sys_update_unread = false;
         int rc = run(true);
         if (rc != HIPKKT_OK) return rc;
-        HIP_CHECK(hipStreamSynchronize(st));           // (pin->h[40..49]: the record, then dtau, dkappa -- published by run's last kernel)
+        if (h->publish_ok) {
+            HIP_CHECK(hipStreamSynchronize(st));       // (pin->h[40..49]: the record, then dtau, dkappa -- published by run's last kernel)
+            if (h->pin->h[50] != (double)h->publish_seq || knobs().test_publish_fail) {
+                // The device's stores to the page-locked block did not arrive (never seen; a mapping this code has not been
+                // run on): the record -- zeroed on the device by the kernel that published it -- is lost for this call, so
+                // the call is repeated with the synchronous sequence, its update included; copies from now on.
+                h->publish_ok = false;
+                if (knobs().verbose) std::fprintf(stderr, "[hipkkt] status record not published to host memory: copying it from now on\n");
+                if (update_unread) {
+                    rc = kkt_update_device(h);
+                    if (rc != HIPKKT_OK) return rc;
+                }
+                return run(false);
+            }
+        } else {
+            HIP_CHECK(hipMemcpyAsync(h->pin->h + 40, h->ir_sticky, 10 * sizeof(double), hipMemcpyDeviceToHost, st));   // (the record, then dtau, dkappa)
+            launch_zero_ints((int*)h->ir_sticky, 16, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
         bool gave_up = false;
         rc = kkt_eval_sticky(h, h->pin->h + 40, &gave_up, true);
         h->last_ir = (int64_t)h->pin->h[43];           // this call's refinement rounds, summed over its columns (as the synchronous path reports)

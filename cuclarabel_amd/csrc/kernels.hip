@@ -1086,6 +1086,7 @@ __device__ inline void mul_Hs_soc_body(const ConeDev& C, const ConeState& S, dou
 __device__ inline void publish_record(const Publish& P)
 {
     for (int i = 0; i < P.n; ++i) P.dst[i] = P.rec[i];
+    P.dst[P.n] = P.seq;
     for (int i = 0; i < P.nzero; ++i) P.rec[i] = 0.0;
 }
 __global__ void k_publish(Publish P) { if (blockIdx.x == 0 && threadIdx.x == 0) publish_record(P); }

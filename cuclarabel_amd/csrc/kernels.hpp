@@ -471,7 +471,9 @@ void launch_cone_scaling(const ConeDev& C, const ConeState& S, const double* s, 
 // Publish: a call's status record handed to the host by the call's LAST kernel instead of a copy and a zeroing launch
 // behind it (~5 us each): n doubles from rec to dst -- page-locked host memory the device can write -- then the first
 // nzero doubles of rec set to zero for the next call.  The host reads dst after synchronising with the stream.
-struct Publish { double* dst = nullptr; double* rec = nullptr; int n = 0, nzero = 0; };
+// seq: written behind the record (dst[n]); the host checks it against the number it passed -- a device store to host memory
+// that did not arrive (a mapping this code has not been run on) is then seen, not read as an all-zero "no error" record.
+struct Publish { double* dst = nullptr; double* rec = nullptr; int n = 0, nzero = 0; double seq = 0.0; };
 void launch_publish(const Publish& p, hipStream_t st);            // ... as a kernel of its own
 void launch_mul_Hs(const ConeDev& C, const ConeState& S, double* y, const double* x, int m, hipStream_t st, const double* addend = nullptr,
                    const Publish& pub = Publish{});

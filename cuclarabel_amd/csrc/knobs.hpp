@@ -69,6 +69,7 @@ namespace hipkkt {
     FLAG_ON(chain, "HIPKKT_CHAIN")                          /* chained launches (chain_kernels.hip) */                                 \
     FLAG_ON(chain_top, "HIPKKT_CHAIN_TOP")                  /* ... below the persistent kernel's set; 0: up to the root instead of it */ \
     KNOB(int, chain_max, "HIPKKT_CHAIN_MAX", 640)           /* widest chained launch in workgroups */                                  \
+    FLAG_SET(test_publish_fail, "HIPKKT_TEST_PUBLISH_FAIL") /* tests: a handle's first published status record counts as not arrived (level C falls back to copies) */ \
     KNOB(int, multi_vec, "HIPKKT_MULTI_VEC", 4)             /* many-column kernels: columns per lane (1, 2, 4) */                       \
     KNOB(int, multi_ct, "HIPKKT_MULTI_CT", 0)               /* 1: 16 instead of 32 columns per block-kernel workgroup */
 

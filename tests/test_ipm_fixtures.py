@@ -515,3 +515,57 @@ def test_speculative_refinement_depth_comes_down_again():
     for a, b in zip(base, again):
         assert np.array_equal(a, b)
     assert ks.fallbacks == (0, 0)
+
+
+@pytest.mark.gpu
+def test_status_record_that_does_not_reach_the_host_is_noticed():
+    """In lazy mode a kkt_solve!'s status record and (dtau, dkappa) are written into page-locked host memory by the
+    call's last kernel, with a sequence number behind them.  If the number the host reads is not the one it passed --
+    forced here for the first record of the handle -- the call is repeated with the synchronous sequence (its update
+    included) and the handle copies its records from then on: same steps as an undisturbed process, no silent
+    "all zeros = no error" record."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver, HipKKTSystem
+pb = problems.config2(n=3000)
+rng = np.random.default_rng(61)
+x = rng.standard_normal(pb.n)
+rhs_x, rhs_z, rhs_s = rng.standard_normal(pb.n), rng.standard_normal(pb.m), rng.standard_normal(pb.m)
+args = (0.4, -0.2, x, pb.s0, pb.z0, 1.3, 0.7)
+ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+system = HipKKTSystem(ks)
+system.init(pb.q, pb.b)
+system.set_lazy(True)
+out = []
+for it in range(3):
+    assert system.update(pb.s0, pb.z0)
+    ok, aff = system.solve(rhs_x, pb.s0, rhs_z, *args, True)
+    assert ok
+    ok, comb = system.solve(rhs_x, rhs_s, rhs_z, *args, False)
+    assert ok
+    out.append([np.asarray(v, dtype=float) for v in tuple(aff) + tuple(comb)])
+for o in out[1:]:
+    for a, b in zip(out[0], o):
+        assert np.array_equal(a, b)
+np.save(sys.argv[1], np.concatenate([v.ravel() for v in out[0]]))
+print("FALLBACKS", ks.fallbacks)
+"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for tag, env in (("plain", {}), ("forced", {"HIPKKT_TEST_PUBLISH_FAIL": "1", "HIPKKT_VERBOSE": "1"})):
+            path = os.path.join(tmp, tag + ".npy")
+            r = subprocess.run([sys.executable, "-c", script.format(root=root), path], env=dict(os.environ, **env), cwd=root,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert "FALLBACKS (0, 0)" in r.stdout
+            assert ("not published" in r.stderr) == (tag == "forced"), r.stderr
+            res[tag] = np.load(path)
+        assert np.array_equal(res["plain"], res["forced"])
