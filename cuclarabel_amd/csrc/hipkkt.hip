@@ -3932,15 +3932,19 @@ static void sys_finish_step(hipkkt_kkt_t h, const double* x1, const double* z1, 
 {
     const int n = h->K.n, m = h->K.m;
     hipStream_t st = h->stream;
+    // (x2, z2): the handle's copy -- or, fresh out of this call's 2-column solve, column 0 where the sweeps left it; the copy
+    // that the iteration's later solves read is then written by the step kernel on its way
+    const double* x2 = with_const ? h->x.p : h->sx2.p;
+    const double* z2 = with_const ? h->x.p + n : h->sz2.p;
     // P x1 and P (xi - x2), xi = x / tau, in one pass (xi - x2 kept in workx for its dot product)
-    launch_P_spmv2(sys_spmv(h), h->Kval.p, x1, d_var_x, h->sx2.p, var_tau, h->spa.p, h->spb.p, h->sworkx.p,
+    launch_P_spmv2(sys_spmv(h), h->Kval.p, x1, d_var_x, x2, var_tau, h->spa.p, h->spb.p, h->sworkx.p,
                    with_const ? h->spc.p : nullptr, n, st);
     DotPairs P{};
     P.npairs = with_const ? 7 : 4;
     if (with_const) {
-        P.a[4] = h->sq.p; P.b[4] = h->sx2.p; P.len[4] = n;
-        P.a[5] = h->sb.p; P.b[5] = h->sz2.p; P.len[5] = m;
-        P.a[6] = h->sx2.p; P.b[6] = h->spc.p; P.len[6] = n;
+        P.a[4] = h->sq.p; P.b[4] = x2; P.len[4] = n;
+        P.a[5] = h->sb.p; P.b[5] = z2; P.len[5] = m;
+        P.a[6] = x2; P.b[6] = h->spc.p; P.len[6] = n;
     }
     P.a[0] = h->sq.p; P.b[0] = x1; P.len[0] = n;
     P.a[1] = h->sb.p; P.b[1] = z1; P.len[1] = m;
@@ -3948,7 +3952,7 @@ static void sys_finish_step(hipkkt_kkt_t h, const double* x1, const double* z1, 
     P.a[3] = h->sworkx.p; P.b[3] = h->spb.p; P.len[3] = n;
     // ... the scalars (:185-196, :206) and (dx, dz) = (x1, z1) + dtau (x2, z2)   (:200-203)
     launch_dots_sys_step(P, h->sys_partial.p, h->sys_cached.p, rhs_tau, rhs_kappa, var_tau, var_kappa, h->sys_out_dev, d_lhs_x, d_lhs_z,
-                         x1, z1, h->sx2.p, h->sz2.p, n, m, st);
+                         x1, z1, x2, z2, n, m, st, with_const ? h->sx2.p : nullptr, with_const ? h->sz2.p : nullptr);
     // ds = -(Hs dz + const)                                               (:206-212)
     launch_mul_Hs(h->cone_dev(), h->cone_state(), d_lhs_s, d_lhs_z, m, st, addend ? addend : h->sconic.p, pub);
     if (!lhs_tau_kappa) return;                      // (the caller reads sys_out back with its own status record)
@@ -4032,7 +4036,7 @@ static int sys_solve_step(hipkkt_kkt_t h, double* d_lhs_x, double* d_lhs_s, doub
             launch_pack_rhs_affine(h->b.p, h->snegq.p, h->sb.p, d_rhs_x, d_var_s, d_rhs_z, n, m, h->K.p, 2, st);
             int rc = kkt_solve_core(h, false, 2, nullptr, defer);
             if (rc != HIPKKT_OK) return rc;
-            launch_unpack_lhs(h->sx2.p, h->sz2.p, h->x.p, n, m, st);          // (x2, z2) outlives this solve: a copy of column 0
+            // ((x2, z2) = column 0 outlives this solve: sys_finish_step copies it on its way)
         } else {
             // (x1, z1) = K \ (rhs.x, const - rhs.z)                              (:170-173)
             if (affine) launch_pack_rhs_affine(h->b.p, nullptr, nullptr, d_rhs_x, d_var_s, d_rhs_z, n, m, h->K.p, 1, st);

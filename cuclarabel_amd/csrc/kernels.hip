@@ -1521,8 +1521,10 @@ __global__ __launch_bounds__(256) void k_sys_step_scalars(double* __restrict__ d
                                                           const double* __restrict__ z1, const double* __restrict__ x2,
                                                           const double* __restrict__ z2, const double* __restrict__ partial,
                                                           double* __restrict__ cached, double rhs_tau, double rhs_kappa, double tau,
-                                                          double kappa, double* __restrict__ out, int npairs, int n, int m)
+                                                          double kappa, double* __restrict__ out, int npairs, int n, int m,
+                                                          double* __restrict__ keep_x2, double* __restrict__ keep_z2)
 {
+    // keep_x2 / keep_z2 (nullable): (x2, z2) came out of this call's own 2-column solve and outlives it: copied on the way
     __shared__ double d[8];
     __shared__ double sh_dtau;
     const int p = threadIdx.x;
@@ -1552,17 +1554,24 @@ __global__ __launch_bounds__(256) void k_sys_step_scalars(double* __restrict__ d
     __syncthreads();
     const double dtau = sh_dtau;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x) {
-        if (i < n) dx[i] = x1[i] + dtau * x2[i];
-        else dz[i - n] = z1[i - n] + dtau * z2[i - n];
+        if (i < n) {
+            const double v = x2[i];
+            dx[i] = x1[i] + dtau * v;
+            if (keep_x2) keep_x2[i] = v;
+        } else {
+            const double v = z2[i - n];
+            dz[i - n] = z1[i - n] + dtau * v;
+            if (keep_z2) keep_z2[i - n] = v;
+        }
     }
 }
 void launch_dots_sys_step(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
                           double kappa, double* out, double* dx, double* dz, const double* x1, const double* z1, const double* x2,
-                          const double* z2, int n, int m, hipStream_t st)
+                          const double* z2, int n, int m, hipStream_t st, double* keep_x2, double* keep_z2)
 {
     hipLaunchKernelGGL(k_dots, dim3(kDotBlocks, P.npairs), dim3(256), 0, st, P, partial);
     hipLaunchKernelGGL(k_sys_step_scalars, dim3(grid_for(std::max(n + m, 1), 256)), dim3(256), 0, st, dx, dz, x1, z1, x2, z2,
-                       (const double*)partial, cached, rhs_tau, rhs_kappa, tau, kappa, out, P.npairs, n, m);
+                       (const double*)partial, cached, rhs_tau, rhs_kappa, tau, kappa, out, P.npairs, n, m, keep_x2, keep_z2);
 }
 
 __global__ void k_neg_sum(double* __restrict__ y, const double* __restrict__ a, const double* __restrict__ b, int n)

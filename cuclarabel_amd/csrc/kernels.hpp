@@ -513,7 +513,8 @@ void launch_sys_step(double* dx, double* dz, const double* x1, const double* z1,
 // the partial sums up itself): two launches
 void launch_dots_sys_step(const DotPairs& P, double* partial, double* cached, double rhs_tau, double rhs_kappa, double tau,
                           double kappa, double* out, double* dx, double* dz, const double* x1, const double* z1, const double* x2,
-                          const double* z2, int n, int m, hipStream_t st);
+                          const double* z2, int n, int m, hipStream_t st, double* keep_x2 = nullptr, double* keep_z2 = nullptr);
+// (keep_x2 / keep_z2: (x2, z2) copied there on the way -- it came out of this call's own solve and outlives the call)
 void launch_neg_copy(double* y, const double* a, int n, hipStream_t st);                    // y = -a
 
 
