@@ -45,6 +45,7 @@ namespace hipkkt {
     KNOB(int, winv_tail, "HIPKKT_WINV_TAIL", 4)             /* fork points of the W-formation stream: launches before the root ... */   \
     KNOB(int, winv_early, "HIPKKT_WINV_EARLY", 1)           /* ... and before the narrow top */                                        \
     KNOB(int, winv_blocks, "HIPKKT_WINV_BLOCKS", 0)         /* grid of the side-stream W kernel (0: 3/8 of the CUs) */                  \
+    FLAG_ON(winv_split, "HIPKKT_WINV_SPLIT")                /* bounded W formation: narrow supernodes on 128-thread workgroups, four times as many */ \
     FLAG_ON(winv_run_forks, "HIPKKT_WINV_RUN_FORKS")        /* W formation forked at every merged run's first launch */                \
     FLAG_ON(factor_overlap, "HIPKKT_FACTOR_OVERLAP")        /* overlap mode: the narrow top's Schur tiles beside its panels */         \
     FLAG_SET(ov_cu_mask, "HIPKKT_OV_CU_MASK")               /* CU-masked tile stream (measured and dropped) */                         \

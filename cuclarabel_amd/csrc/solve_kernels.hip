@@ -1498,11 +1498,13 @@ __global__ __launch_bounds__(BS, 4) void k_top_solve_sliced(SolveArgs A, int beg
 //      no exchange between the two.
 // Then M = L21 * T, a wave per strip of 16 rows against T in LDS (A operands of a strip fetched ahead of the products).
 constexpr int kWinvThreads = 512;
+constexpr int kWinvSmallThreads = 128, kWinvSmallNc = 32;     // narrow supernodes: k_winv's small build (below)
+template <int NT>
 __device__ inline void winv_one(const TreeDev& T, const double* __restrict__ fronts, double* __restrict__ wst, int s,
                                 double* smem)
 {
     typedef double d4_t __attribute__((ext_vector_type(4)));
-    constexpr int NT = kWinvThreads, NWV = NT / 64;
+    constexpr int NWV = NT / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wvi = tid >> 6;
     const int ml = lane & 15, mk = lane >> 4;
@@ -1657,12 +1659,21 @@ __device__ inline void winv_one(const TreeDev& T, const double* __restrict__ fro
 }
 
 // count supernodes, any grid: a small grid keeps this off most CUs when it runs beside the tree's critical path
-__global__ __launch_bounds__(kWinvThreads) void k_winv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ wst,
-                                              const int* __restrict__ list, int count)
+// SEL 0: every supernode of the list; 1: those of at most kWinvSmallNc columns (the 128-thread build: a front of a dozen
+// columns and a hundred rows keeps a fraction of 512 threads busy, and the bulk of a tree's block-class fronts are such --
+// four times the workgroups in flight on the same threads); 2: the wider ones.
+template <int NT, int SEL>
+__global__ __launch_bounds__(NT) void k_winv(TreeDev T, const double* __restrict__ fronts, double* __restrict__ wst,
+                                             const int* __restrict__ list, int count)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        winv_one(T, fronts, wst, list[it], smem);
+        const int s = list[it];
+        if (SEL != 0) {
+            const bool small = T.sn_start[s + 1] - T.sn_start[s] <= kWinvSmallNc;
+            if (small != (SEL == 1)) continue;
+        }
+        winv_one<NT>(T, fronts, wst, s, smem);
         __syncthreads();               // LDS is reused by the next supernode
     }
 }
@@ -1698,7 +1709,8 @@ static void init_solve_lds()
         HIPKKT_SET_NR(2)
         HIPKKT_SET_NR(4)
 #undef HIPKKT_SET_NR
-        set(k_winv, 160 * 1024);
+        set(k_winv<kWinvThreads, 0>, 160 * 1024);
+        set(k_winv<kWinvThreads, 2>, 160 * 1024);
         set(k_top_solve<512, 7, 7, 1>, 150 * 1024);
         set(k_top_solve_sliced<1024, 1>, 150 * 1024);
         set(k_top_solve_sliced<1024, 2>, 150 * 1024);
@@ -2615,7 +2627,17 @@ void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int
     init_solve_lds();
     const size_t lds = (size_t)ncmax * (ncmax | 1) * sizeof(double);
     const int grid = (max_blocks > 0 && max_blocks < count) ? max_blocks : count;
-    hipLaunchKernelGGL(k_winv, dim3(grid), dim3(kWinvThreads), lds, st, T, fronts, tinv, list, count);
+    if (max_blocks > 0 && max_blocks < count && knobs().winv_split) {
+        // a bounded grid beside the tree's critical path: the wide supernodes first (the long ones), then the narrow ones on
+        // four times as many, four times smaller workgroups
+        hipLaunchKernelGGL((k_winv<kWinvThreads, 2>), dim3(grid), dim3(kWinvThreads), lds, st, T, fronts, tinv, list, count);
+        const int nc_s = ncmax < kWinvSmallNc ? ncmax : kWinvSmallNc;
+        const size_t lds_s = (size_t)nc_s * (nc_s | 1) * sizeof(double);
+        const int grid_s = std::min(count, max_blocks * (kWinvThreads / kWinvSmallThreads));
+        hipLaunchKernelGGL((k_winv<kWinvSmallThreads, 1>), dim3(grid_s), dim3(kWinvSmallThreads), lds_s, st, T, fronts, tinv, list, count);
+        return;
+    }
+    hipLaunchKernelGGL((k_winv<kWinvThreads, 0>), dim3(grid), dim3(kWinvThreads), lds, st, T, fronts, tinv, list, count);
 }
 
 }  // namespace hipkkt
