@@ -572,7 +572,9 @@ private:
 #endif
         // (every W formation of this factorisation goes through form_w)
         auto form_w = [&](const int* list, int count, int ncmax, hipStream_t on, int max_blocks) {
-            if (!skip_w) launch_tinv(a.T, fronts.p, tinv.p, list, count, ncmax, on, max_blocks);
+            const size_t i0 = (size_t)(list - d_tinv_list.p);
+            const int nsmall = i0 + (size_t)count < tinv_small_prefix.size() ? tinv_small_prefix[i0 + (size_t)count] - tinv_small_prefix[i0] : 0;
+            if (!skip_w) launch_tinv(a.T, fronts.p, tinv.p, list, count, ncmax, on, max_blocks, nsmall);
         };
         // eager mode: once the tree narrows to its top levels most CUs idle, so the solve matrices
         // W = [T; M] of everything below are formed on a side stream meanwhile (HIPKKT_NO_OVERLAP=1 disables)
@@ -1259,7 +1261,7 @@ private:
     int n_skipw_calls = 0;
 #endif
     DBuf<int> d_tinv_list;
-    std::vector<int> tinv_list;
+    std::vector<int> tinv_list, tinv_small_prefix;
     int tinv_ncmax = 1;
     DBuf<int> flags;
     DBuf<int64_t> stamps;
@@ -1964,6 +1966,11 @@ private:
             tinv.alloc((size_t)toff[S.nsuper]);
             HIP_CHECK(hipMemset(tinv.p, 0, std::max<size_t>(tinv.n, 1) * sizeof(double)));
             d_tinv_list.upload(tinv_list);
+            tinv_small_prefix.assign(tinv_list.size() + 1, 0);      // (how many narrow supernodes a stretch of the list holds: launch_tinv)
+            for (size_t k = 0; k < tinv_list.size(); ++k) {
+                const int s = tinv_list[k];
+                tinv_small_prefix[k + 1] = tinv_small_prefix[k] + (S.sn_start[s + 1] - S.sn_start[s] <= winv_small_nc() ? 1 : 0);
+            }
         }
         {
             std::vector<int64_t> cut_ptr(S.nsuper + 1, 0);

@@ -250,9 +250,12 @@ void launch_top_solve(const SolveArgs& a, int begin, int count, int grid, size_t
 int top_solve_sliced_capacity(size_t lds, int nr = 1);
 void launch_top_solve_sliced(const SolveArgs& a, int begin, int pos0, int task0, int task1, int grid, size_t lds, int* flags, int nflag,
                              int epoch, hipStream_t st, int nr = 1);
-// max_blocks > 0: at most that many workgroups (each walks several supernodes)
+// max_blocks > 0: at most that many workgroups (each walks several supernodes); nsmall: how many of the list's supernodes
+// have at most winv_small_nc() columns -- enough of them and they go to a launch of their own, four times as many 128-thread
+// workgroups (solve_kernels.hip: k_winv)
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
-                 hipStream_t st, int max_blocks = 0);
+                 hipStream_t st, int max_blocks = 0, int nsmall = 0);
+int winv_small_nc();
 
 // factorisation of one level: small fronts (one wave each), panels (one workgroup each), then the
 // update blocks tiled over many workgroups

@@ -2620,14 +2620,17 @@ void launch_top_solve_sliced(const SolveArgs& a, int begin, int pos0, int task0,
         hipLaunchKernelGGL((k_top_solve_sliced<1024, 1>), dim3(std::min(grid, ntask)), dim3(1024), lds, st, a, begin, pos0, task0, task1,
                            flags, epoch, nflag);
 }
+int winv_small_nc() { return kWinvSmallNc; }
 void launch_tinv(const TreeDev& T, const double* fronts, double* tinv, const int* list, int count, int ncmax,
-                 hipStream_t st, int max_blocks)
+                 hipStream_t st, int max_blocks, int nsmall)
 {
     if (count <= 0) return;
     init_solve_lds();
     const size_t lds = (size_t)ncmax * (ncmax | 1) * sizeof(double);
     const int grid = (max_blocks > 0 && max_blocks < count) ? max_blocks : count;
-    if (max_blocks > 0 && max_blocks < count && knobs().winv_split) {
+    // (the narrow supernodes on their own grid only where they fill it once at least: a structure of wide fronts -- cfg5 --
+    //  would pay the second launch and its four-times-wider grid beside the panels for nothing: factorisation 4.24 -> 4.31 ms)
+    if (max_blocks > 0 && max_blocks < count && knobs().winv_split && nsmall >= max_blocks * (kWinvThreads / kWinvSmallThreads)) {
         // a bounded grid beside the tree's critical path: the wide supernodes first (the long ones), then the narrow ones on
         // four times as many, four times smaller workgroups
         hipLaunchKernelGGL((k_winv<kWinvThreads, 2>), dim3(grid), dim3(kWinvThreads), lds, st, T, fronts, tinv, list, count);
