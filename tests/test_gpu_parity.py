@@ -1516,3 +1516,49 @@ print("MANY HANDLES OK")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "MANY HANDLES OK" in r.stdout and "gave up" not in r.stderr, r.stderr
     assert "share a hardware queue" not in r.stderr and "no stream beside" not in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_w_formation_on_two_grids_gives_the_same_solve_matrices():
+    """Beside the tree the solve matrices W = [L11^-1; L21 L11^-1] are formed on a bounded grid, the narrow supernodes (at most
+    32 columns) on a launch of their own with 128-thread workgroups where a fork's list holds enough of them
+    (solve_kernels.hip: k_winv<128, 1> / k_winv<512, 2>).  A supernode's arithmetic does not depend on the workgroup size:
+    the solutions must be bit-identical with the split on and off (HIPKKT_WINV_SPLIT), on a problem large enough for the
+    split to be taken (a tiny bounded grid makes every fork's list long enough)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems
+from cuclarabel_amd.kktsolver import HipKKTSolver
+pb = problems.config2(n=20000)
+ks = HipKKTSolver(pb.P, pb.A, pb.cones)
+rng = np.random.default_rng(23)
+out = []
+for it in range(2):
+    assert ks.kktsolver_update_from_sz(pb.s0, pb.z0)
+    for _ in range(2):
+        rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
+        ks.kktsolver_setrhs(rx, rz)
+        x, z = np.zeros(pb.n), np.zeros(pb.m)
+        assert ks.kktsolver_solve(x, z)
+        out += [x, z]
+assert ks.fallbacks == (0, 0)
+np.save(sys.argv[1], np.concatenate(out))
+"""
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for tag, env in (("split", {"HIPKKT_WINV_SPLIT": "1", "HIPKKT_WINV_BLOCKS": "8"}),
+                         ("one", {"HIPKKT_WINV_SPLIT": "0", "HIPKKT_WINV_BLOCKS": "8"})):
+            path = os.path.join(tmp, tag + ".npy")
+            r = subprocess.run([sys.executable, "-c", script.format(root=root), path], env=dict(os.environ, **env), cwd=root,
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout + r.stderr
+            res[tag] = np.load(path)
+        assert np.isfinite(res["split"]).all()
+        assert np.array_equal(res["split"], res["one"])
