@@ -1887,6 +1887,9 @@ private:
                 // (r03, cfg5: slices of ~80 KB, at most 16, instead of ~120 KB / 8: sweep pair 0.765 -> 0.729 ms; 60 KB / 16 and
                 //  40 KB / 32: 0.74 -- a hop is mostly its fixed latencies by then.  A front is sliced when its W exceeds
                 //  HIPKKT_SOLVE_SLICE_FROM KB, by default 4.5 slices' worth: cfg3's 395 KB fronts are faster whole)
+                // (r04: at most 64 slices instead of 16 -- cfg5's 1.2 MB fronts take 15 either way, the long-range cfg2
+                //  variant's 14 154-row panels (11 MB each, 148 of them in a chain) were streamed in 680 KB pieces: sweep pair
+                //  4.98 -> 3.85 ms, unit 89.5 -> 81.7 ms; 96 and 128 slices: the same)
                 const int slice_kb = knobs().solve_slice_kb;
                 const int slice_max = std::max(1, std::min(64, knobs().solve_slice_max));
                 const int64_t slice_from = knobs().solve_slice_from >= 0 ? knobs().solve_slice_from * 1024 : (int64_t)slice_kb * 1024 * 9 / 2;

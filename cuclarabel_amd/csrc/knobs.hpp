@@ -65,7 +65,7 @@ namespace hipkkt {
     KNOB(long long, top_test_limit, "HIPKKT_TOP_TEST_LIMIT", 5000000) /* bound of the persistent / chained kernels' waits in 10 ns ticks (tests: 0) */ \
     FLAG_SET(no_level_merge, "HIPKKT_NO_LEVEL_MERGE")       /* a level's block-class and one-wave launches stay two launches */        \
     KNOB(int, solve_slice_kb, "HIPKKT_SOLVE_SLICE_KB", 80)  /* (front, slice) kernel: slice size ... */                                \
-    KNOB(int, solve_slice_max, "HIPKKT_SOLVE_SLICE_MAX", 16) /* ... slices per front (1..64) ... */                                    \
+    KNOB(int, solve_slice_max, "HIPKKT_SOLVE_SLICE_MAX", 64) /* ... slices per front (1..64; 16 until r04: a 14 154-row front's 11 MB want more) ... */                                    \
     KNOB(long long, solve_slice_from, "HIPKKT_SOLVE_SLICE_FROM", -1) /* ... and the W size in KB from which a front is sliced (-1: 4.5 slices' worth) */ \
     FLAG_ON(chain, "HIPKKT_CHAIN")                          /* chained launches (chain_kernels.hip) */                                 \
     FLAG_ON(chain_top, "HIPKKT_CHAIN_TOP")                  /* ... below the persistent kernel's set; 0: up to the root instead of it */ \
