@@ -364,17 +364,44 @@ void nd_order(const Graph& g, int leaf_size, double dense_scale, std::vector<int
         int root = task.nodes[0];
         bfs_levels(W, pid, root, task.nodes, order, lvl_ptr);
         if ((int)order.size() < sz) {
-            // disconnected: split off the reached component, order components independently
-            std::vector<int> comp(order.begin(), order.end()), rest;
-            for (int v : comp) W.part[v] = -2;
-            for (int v : task.nodes) if (W.part[v] == pid) rest.push_back(v);
-            for (int v : comp) W.part[v] = 0;
-            for (int v : rest) W.part[v] = 0;
-            Task a, b;
-            a.nodes = std::move(comp); a.pos_begin = task.pos_begin;
-            b.nodes = std::move(rest); b.pos_begin = task.pos_begin + (int)a.nodes.size();
-            stack.push_back(std::move(a));
-            stack.push_back(std::move(b));
+            // disconnected: every component becomes a task of its own, found in ONE pass over the task's nodes (peeling
+            // them off one at a time is quadratic in their number: a separable problem of 60 000 two-node components
+            // took 7.7 s).  The permutation is the one the one-at-a-time split produced: components are discovered from
+            // the first unvisited node in task order and listed breadth first, and the trailing components that
+            // together fit a leaf go to AMD as ONE block in task order (the old split's last remainder).
+            std::vector<Task> comps;
+            int pos = task.pos_begin;
+            for (int v0 : task.nodes) {
+                if (W.part[v0] != pid) continue;
+                Task c;
+                c.pos_begin = pos;
+                c.nodes.push_back(v0);
+                W.part[v0] = -2;
+                W.level[v0] = (int)comps.size();
+                for (size_t h = 0; h < c.nodes.size(); ++h) {
+                    const int v = c.nodes[h];
+                    for (int64_t q = g.ptr[v]; q < g.ptr[v + 1]; ++q) {
+                        const int u = g.idx[q];
+                        if (W.part[u] == pid) { W.part[u] = -2; W.level[u] = (int)comps.size(); c.nodes.push_back(u); }
+                    }
+                }
+                pos += (int)c.nodes.size();
+                comps.push_back(std::move(c));
+            }
+            // first component of the remainder that is small enough to be a leaf as a whole (never the first one:
+            // the old split always peeled one component before looking at what was left)
+            int tail = (int)comps.size(), tail_sz = 0;
+            while (tail > 1 && tail_sz + (int)comps[tail - 1].nodes.size() <= leaf_size) tail_sz += (int)comps[--tail].nodes.size();
+            if (tail < (int)comps.size()) {
+                Task t;
+                t.pos_begin = comps[tail].pos_begin;
+                t.nodes.reserve(tail_sz);
+                for (int v : task.nodes) if (W.level[v] >= tail) t.nodes.push_back(v);
+                comps.resize(tail);
+                comps.push_back(std::move(t));
+            }
+            for (int v : task.nodes) W.part[v] = 0;
+            for (auto& c : comps) stack.push_back(std::move(c));
             continue;
         }
         for (int sweep = 0; sweep < 3; ++sweep) {

@@ -219,3 +219,167 @@ def block_diagonal(pbs, name=None):
     return Problem(name or f"blockdiag_{len(pbs)}x_{pbs[0].name}", _triu_csc(P), cat("q"), _csc(A), cat("b"),
                    [c for pb in pbs for c in pb.cones], cat("s0"), cat("z0"), cat("x0"),
                    dict(blocks=[(pb.n, pb.m) for pb in pbs]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Structure zoo: sparsity patterns OUTSIDE the five BASELINE configurations (whose KKT graphs are banded, block-
+# dense or block-banded).  The schedule's thresholds were fitted on those five; these generators give the parity
+# tests and scripts/bench_zoo.py elimination trees of other shapes -- mesh separators that grow with the subgraph,
+# a root front that dominates, hubs, forests of unequal trees, trees with no top at all, LPs with P = 0.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _laplacian(dims):
+    """Graph Laplacian of a regular grid (5-point in 2-D, 7-point in 3-D) as the Kronecker sum of path Laplacians."""
+    def path(k):
+        d = np.full(k, 2.0)
+        d[0] = d[-1] = 1.0
+        return sp.diags([-np.ones(k - 1), d, -np.ones(k - 1)], [-1, 0, 1], format="csr")
+    L = sp.csr_matrix((1, 1))
+    for k in dims:
+        L = sp.kron(L, sp.identity(k)) + sp.kron(sp.identity(L.shape[0]), path(k))
+    return L.tocsc()
+
+
+def zoo_grid(dims=(96, 96), seed=2001, soc_dim=8):
+    """Mesh QP: P = grid Laplacian + 0.1 I (2-D or 3-D), bounds -x <= b as NN(n), and one SOC(soc_dim) per run of
+    soc_dim - 1 consecutive variables.  Nested dissection of a mesh: separators of ~sqrt(n) (2-D) or ~n^(2/3) (3-D)
+    nodes at the root, shrinking by sqrt(2) per level -- unlike cfg2's constant-width separators."""
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(dims))
+    P = _laplacian(dims) + 0.1 * sp.identity(n)
+    nsoc = n // (soc_dim - 1)
+    rows, cols, vals = [], [], []
+    for j in range(nsoc):                              # SOC j: (t; x_run) with t a constant slack row (empty row of A)
+        r0 = n + j * soc_dim
+        run = np.arange(j * (soc_dim - 1), (j + 1) * (soc_dim - 1))
+        rows.append(r0 + 1 + np.arange(soc_dim - 1))
+        cols.append(run)
+        vals.append(-np.ones(soc_dim - 1))
+    A_soc = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows) - n, np.concatenate(cols))),
+                          shape=(nsoc * soc_dim, n))
+    A = sp.vstack([-sp.identity(n), A_soc], format="csc")
+    cones = [NonnegativeConeT(n)] + [SecondOrderConeT(soc_dim) for _ in range(nsoc)]
+    return _finish("zoo_grid_" + "x".join(map(str, dims)), P, A, cones, rng, seed=seed)
+
+
+def zoo_chain(n=40_000, seed=2002):
+    """Total-variation-like QP on a path: P tridiagonal, A = first differences (NN) -- every separator is ONE node,
+    so the elimination tree is as deep and as thin as nested dissection can make it."""
+    rng = np.random.default_rng(seed)
+    P = sp.diags([-0.4 * np.ones(n - 1), np.ones(n) + rng.uniform(0, 1, n), -0.4 * np.ones(n - 1)], [-1, 0, 1])
+    D = sp.diags([-np.ones(n - 1), np.ones(n - 1)], [0, 1], shape=(n - 1, n))
+    A = sp.vstack([D, -D], format="csc")
+    return _finish(f"zoo_chain_n{n}", P, A, [NonnegativeConeT(2 * (n - 1))], rng, seed=seed)
+
+
+def zoo_arrow(n=20_000, dense_rows=6, seed=2003):
+    """cfg2-like local couplings plus `dense_rows` equality rows that touch EVERY variable (budget / moment
+    constraints): their multipliers are hubs of the KKT graph and must end up at the root."""
+    rng = np.random.default_rng(seed)
+    P = sp.diags(rng.uniform(0.1, 1.0, size=n))
+    A_loc = _local_window_A(n, n, 3, rng, halfwidth=20)
+    A_dense = sp.csc_matrix(rng.standard_normal((dense_rows, n)))
+    A = sp.vstack([A_dense, A_loc], format="csc")
+    return _finish(f"zoo_arrow_n{n}_k{dense_rows}", P, A, [ZeroConeT(dense_rows), NonnegativeConeT(n)], rng, seed=seed)
+
+
+def zoo_powerlaw(n=8000, seed=2004):
+    """Scale-free coupling: each row of A picks 3 columns with probability ~ 1/rank -- a few hub variables of
+    degree in the thousands, a long tail of degree-one variables."""
+    rng = np.random.default_rng(seed)
+    m = 2 * n
+    p = 1.0 / np.arange(1, n + 1)
+    p /= p.sum()
+    cols = rng.choice(n, size=3 * m, p=p)
+    rows = np.repeat(np.arange(m), 3)
+    A = sp.coo_matrix((rng.standard_normal(3 * m), (rows, cols)), shape=(m, n))
+    P = sp.diags(rng.uniform(0.1, 1.0, size=n))
+    cones = [NonnegativeConeT(n)] + [SecondOrderConeT(50) for _ in range(n // 50)]
+    return _finish(f"zoo_powerlaw_n{n}", P, A, cones, rng, seed=seed)
+
+
+def zoo_big_soc(n=12_000, soc_dim=4000, nsoc=3, seed=2005):
+    """A few very large second-order cones (sparse expansion: two extra KKT columns of soc_dim entries each,
+    `coneops_socone.jl:125-192`) over local couplings."""
+    rng = np.random.default_rng(seed)
+    m = nsoc * soc_dim
+    P = sp.diags(rng.uniform(0.1, 1.0, size=n))
+    A = _local_window_A(m, n, 3, rng, halfwidth=30)
+    return _finish(f"zoo_bigsoc_{nsoc}x{soc_dim}", P, A, [SecondOrderConeT(soc_dim) for _ in range(nsoc)], rng, seed=seed)
+
+
+def zoo_forest(seed=2006, ntiny=400):
+    """One block-diagonal problem of very unequal parts: a cfg2 at n = 4000, a dense 150-variable QP and `ntiny`
+    problems of 6 variables -- a forest whose trees end at every level."""
+    parts = [config2(seed=seed, n=4000), small_mixed(seed=seed + 1, n=150, nn=200, socs=(20, 30), psds=(), zero=0, density=1.0)]
+    parts += [small_mixed(seed=seed + 2 + j, n=6, nn=5, socs=(3,), psds=(), zero=0, density=0.5) for j in range(ntiny)]
+    return block_diagonal(parts, name=f"zoo_forest_{ntiny}")
+
+
+def zoo_diag(n=30_000, seed=2007):
+    """Separable problem: P diagonal, A = -I, NN(n).  K permutes to n independent 2 x 2 blocks: every supernode is
+    a root, the tree has no top for the persistent kernels to take."""
+    rng = np.random.default_rng(seed)
+    P = sp.diags(rng.uniform(0.1, 1.0, size=n))
+    return _finish(f"zoo_diag_n{n}", P, -sp.identity(n), [NonnegativeConeT(n)], rng, seed=seed)
+
+
+def zoo_dense(n=350, m=500, seed=2008):
+    """Fully dense P and A: the whole KKT matrix is ONE front (a chain of panels), no tree at all."""
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n))
+    P = sp.csc_matrix(G @ G.T / n + 0.1 * np.eye(n))
+    A = sp.csc_matrix(rng.standard_normal((m, n)))
+    return _finish(f"zoo_dense_n{n}", P, A, [NonnegativeConeT(m - 60), SecondOrderConeT(60)], rng, seed=seed)
+
+
+def zoo_lp_transport(nsrc=120, ndst=150, seed=2009):
+    """Transportation LP: P = 0 (the (1,1) block of K is the static regulariser alone), flow conservation as a
+    Zero cone over a bipartite incidence matrix, x >= 0 as NN."""
+    rng = np.random.default_rng(seed)
+    n = nsrc * ndst
+    i, j = np.divmod(np.arange(n), ndst)
+    A_eq = sp.coo_matrix((np.ones(2 * n), (np.concatenate([i, nsrc + j]), np.concatenate([np.arange(n)] * 2))),
+                         shape=(nsrc + ndst, n)).tocsr()[:-1]      # the last balance row is implied by the others
+    A = sp.vstack([A_eq, -sp.identity(n)], format="csc")
+    P = sp.csc_matrix((n, n))
+    return _finish(f"zoo_lp_transport_{nsrc}x{ndst}", P, A, [ZeroConeT(nsrc + ndst - 1), NonnegativeConeT(n)], rng, seed=seed)
+
+
+def zoo_equality_heavy(n=15_000, seed=2010):
+    """Half as many equality rows as variables (Zero cone: -eps pivots on a third of the diagonal) over a banded P."""
+    rng = np.random.default_rng(seed)
+    meq = n // 2
+    P = sp.diags([0.2 * np.ones(n - 2), np.ones(n) + rng.uniform(0, 1, n), 0.2 * np.ones(n - 2)], [-2, 0, 2])
+    A = sp.vstack([_local_window_A(meq, n, 3, rng, halfwidth=10), -sp.identity(n)], format="csc")
+    return _finish(f"zoo_equality_n{n}", P, A, [ZeroConeT(meq), NonnegativeConeT(n)], rng, seed=seed)
+
+
+ZOO = [
+    ("grid2d_160", lambda: zoo_grid((160, 160))),
+    ("grid3d_24", lambda: zoo_grid((24, 24, 24), seed=2011)),
+    ("chain_150k", lambda: zoo_chain(n=150_000)),
+    ("arrow_6", lambda: zoo_arrow(n=60_000)),
+    ("powerlaw_20k", lambda: zoo_powerlaw(n=20_000)),
+    ("big_soc_4000", lambda: zoo_big_soc(n=30_000, soc_dim=4000, nsoc=8)),
+    ("forest_400", lambda: zoo_forest()),
+    ("diag_100k", lambda: zoo_diag(n=100_000)),
+    ("dense_600", lambda: zoo_dense(n=600, m=900)),
+    ("lp_transport", lambda: zoo_lp_transport(200, 260)),
+    ("equality_heavy", lambda: zoo_equality_heavy(n=60_000)),
+]
+
+# the same shapes small enough for the CPU suite (oracle against scipy)
+ZOO_SMALL = [
+    ("grid2d_24", lambda: zoo_grid((24, 24))),
+    ("grid3d_8", lambda: zoo_grid((8, 8, 8), seed=2011)),
+    ("chain_2k", lambda: zoo_chain(n=2000)),
+    ("arrow_3", lambda: zoo_arrow(n=1500, dense_rows=3)),
+    ("powerlaw_1k", lambda: zoo_powerlaw(n=1000)),
+    ("big_soc_600", lambda: zoo_big_soc(n=1500, soc_dim=600, nsoc=2)),
+    ("forest_30", lambda: zoo_forest(ntiny=30)),
+    ("diag_2k", lambda: zoo_diag(n=2000)),
+    ("dense_80", lambda: zoo_dense(n=80, m=120)),
+    ("lp_transport_small", lambda: zoo_lp_transport(20, 30)),
+    ("equality_2k", lambda: zoo_equality_heavy(n=2000)),
+]
