@@ -26,6 +26,9 @@ namespace hipkkt {
     KNOB(int, panel_slice_below, "HIPKKT_PANEL_SLICE_BELOW", -1) /* a front whose unsliced panel would be narrower than this is cut into row slices (-1: 64) */ \
     FLAG_SET(postorder_layout, "HIPKKT_POSTORDER_LAYOUT")   /* stores in supernode order instead of level order */                    \
     FLAG_ON(upd_pingpong, "HIPKKT_UPD_PINGPONG")            /* chains of panels share two update blocks */                            \
+    KNOB(int, bundle_kids, "HIPKKT_BUNDLE_KIDS", 200)       /* a one-wave supernode (f <= 64) left with more children than this has them bundled into sibling supernodes (0: no bundles at all) */ \
+    KNOB(int, bundle_kids_panel, "HIPKKT_BUNDLE_KIDS_PANEL", 400)  /* ... a wider one with more than this many per panel */ \
+    FLAG_ON(bundle_cost, "HIPKKT_BUNDLE_COST")              /* ... and children whose update blocks dwarf the parent's front; bundles beyond one-wave size where that shrinks panel + update-block storage */ \
     /* ---- schedule (handle creation) */                                                                                              \
     KNOB(int, merge_small, "HIPKKT_MERGE_SMALL", 128)       /* up to this many one-wave fronts ride with their level's block-class launch */ \
     KNOB(int, slice_rows, "HIPKKT_SLICE_ROWS", 128)         /* row-sliced panels: rows per slice (0: as few slices as LDS allows) */   \

@@ -213,6 +213,89 @@ void analyse(int N, const int64_t* colptr, const int64_t* rowval, int base,
                 }
             }
             ks.swap(newkids);
+            // SIBLING BUNDLES.  A supernode left with very many children -- the multiplier of a dense equality row whose
+            // 3000 singleton columns hang off the root, a hub variable of a transportation LP, the n-column block under
+            // the 840 one-column slack leaves of a dense A -- is assembled by ONE workgroup (or one wave) that walks its
+            // children in turn, and gathered from by one workgroup in the forward sweep: 2.3 ms for those 3000 children
+            // where the rest of the factorisation takes 0.2.  Children are therefore put together, in the order of
+            // their row counts, into supernodes of their own ("bundles": siblings side by side, explicit zeros
+            // between them -- the same layout a parent gets when it absorbs two children) as long as a bundle stays
+            // a one-wave front (f <= 64), or beyond that, up to the widest panel, where the bundle's panel and update block
+            // are smaller than its members' together (children that share a tall row structure: 96 one-column leaves of
+            // 600 rows are one 600 x 600 update block instead of 96).  The row count of a bundle is not known here; its
+            // bound -- the members' sum, at most the parent's front -- errs on the side of not bundling.
+            //   WHEN.  Measured per child (MI355X): 0.77 us in the one-wave front kernel, 0.13 us in the forward sweep's
+            // gather, 0.055 us in the 1024-thread panel kernel, against ~0.1 ms that a level of bundles costs (a launch
+            // class more at the bottom of the tree, larger blocks to add).  So: a parent that is a one-wave front itself
+            // (f <= 64) from bundle_kids children (200; cfg2's second-order-cone columns have up to ~190 and are left
+            // alone: bundling them cost 1.3 % of a step), a wider parent from bundle_kids_panel (400) children per panel of
+            // panel_max_cols columns (cfg3's 500 one-row slack leaves per dense block stay as they are: bundled they
+            // made its factorisation 12 % slower), and any parent whose children's update blocks together are more than
+            // 16 times its own front (the dense-A case: storage and traffic, not the count).
+            const Knobs& kn = knobs();
+            const double umax = (double)fs_nc[p] + fs_nb[p];
+            bool bundle = false;
+            if (kn.bundle_kids > 0 && ks.size() >= 2) {
+                const double K = (double)ks.size();
+                if (umax <= 64) bundle = K > kn.bundle_kids;
+                else bundle = K * std::min(1.0, (double)opt.panel_max_cols / std::max(1, fs_nc[p])) > kn.bundle_kids_panel;
+                if (!bundle && kn.bundle_cost) {
+                    double upd = 0;
+                    for (int c : ks) upd += (double)fs_nb[c] * fs_nb[c];
+                    bundle = upd > 16.0 * umax * umax;
+                }
+            }
+            if (bundle) {
+                const bool by_cost = kn.bundle_cost;
+                auto cost = [&](double nc, double nb) { return trap(nc, nb) + nb * nb; };
+                // sqrt(K) members each: the bundles assemble side by side one level down, the parent walks K / g of
+                // them, and the explicit zeros grow with g -- K (g / 2 + rows) entries in all
+                const int per_bundle = std::max(8, (int)std::ceil(std::sqrt((double)ks.size())));
+                std::vector<int> order(ks);
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fs_nb[a] > fs_nb[b]; });
+                std::vector<int> out, cur;
+                double cur_nc = 0, cur_nbsum = 0, cur_cost = 0, cur_true = 0;
+                auto close = [&]() {
+                    if (cur.size() > 1) {
+                        const int r = *std::max_element(cur.begin(), cur.end());      // the representative: the last in postorder
+                        const double u = std::min(cur_nbsum, umax);
+                        std::vector<int> gk;
+                        int h = 1;
+                        for (int c : cur) {
+                            h = std::max(h, hgt[c]);
+                            gk.insert(gk.end(), kids[c].begin(), kids[c].end());
+                            if (c != r) merged[c] = r;
+                        }
+                        kids[r].swap(gk);
+                        hgt[r] = h;
+                        fs_nc[r] = (int)cur_nc;
+                        fs_nb[r] = (int)u;
+                        fs_zeros[r] = trap(cur_nc, u) - cur_true;
+                        out.push_back(r);
+                    } else if (cur.size() == 1) {
+                        out.push_back(cur[0]);
+                    }
+                    cur.clear();
+                    cur_nc = cur_nbsum = cur_cost = cur_true = 0;
+                };
+                for (int c : order) {
+                    const double nc_c = fs_nc[c], nb_c = fs_nb[c];
+                    if (!cur.empty()) {
+                        const double nc2 = cur_nc + nc_c, u2 = std::min(cur_nbsum + nb_c, umax);
+                        const bool fits = nc2 <= (double)opt.panel_max_cols && (opt.panel_cap <= 0 || (nc2 + u2) * nc2 <= (double)opt.panel_cap);   // one panel, no chain
+                        const bool one_wave = nc2 + u2 <= 64;
+                        const bool cheaper = by_cost && cost(nc2, u2) <= cur_cost + cost(nc_c, nb_c);
+                        if (!(fits && (one_wave || cheaper)) || (int)cur.size() >= per_bundle) close();
+                    }
+                    cur.push_back(c);
+                    cur_nc += nc_c;
+                    cur_nbsum += nb_c;
+                    cur_cost += cost(nc_c, nb_c);
+                    cur_true += trap(nc_c, nb_c) - fs_zeros[c];
+                }
+                close();
+                ks.swap(out);
+            }
             for (int c : ks) { fs_parent[c] = p; hgt[p] = std::max(hgt[p], hgt[c] + 1); }
         }
     }

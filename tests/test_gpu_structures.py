@@ -42,7 +42,10 @@ def test_structure_zoo_factor_and_solves_match_oracle(name, maker):
         assert ks.kktsolver_update_from_sz(s, z)
         assert o.update_scaling(s, z) and o.kktsolver_update()
         np.testing.assert_allclose(ks.get_Hs(), o.get_Hs(), rtol=1e-13, atol=0)
-        np.testing.assert_allclose(ks.KKT().data, o.K().data, rtol=1e-11, atol=1e-300)
+        # the sparse SOC columns u, v come from reductions over up to 4000 terms, summed in a different order on the
+        # device: entries that nearly cancel differ by a few ulps of the LARGEST term, hence the absolute part
+        Ko = o.K().data
+        np.testing.assert_allclose(ks.KKT().data, Ko, rtol=1e-11, atol=1e-15 * np.abs(Ko).max())
         assert ks.diagonal_regularizer == pytest.approx(o.last_regularizer, rel=1e-15)
         for _ in range(2):
             rx, rz = rng.standard_normal(pb.n), rng.standard_normal(pb.m)
