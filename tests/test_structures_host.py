@@ -66,3 +66,50 @@ def test_block_diagonal_fill_is_the_sum_of_its_parts():
     perm, info = _lib.symbolic_analyse(K, ordering=_lib.ORDER_ND, nd_leaf_size=200)
     assert sorted(perm.tolist()) == list(range(K.shape[0]))
     assert info["nnzL"] == total
+
+
+_BUNDLE_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, {root!r})
+from cuclarabel_amd import problems, _lib
+from tests.oracle_bindings import make_oracle
+out = {{}}
+for name, mk in [("cfg2", lambda: problems.config2(n=6000)), ("cfg3", lambda: problems.config3(nblocks=6, blk=300)),
+                 ("cfg5", lambda: problems.config5(n=600, npsd=12, psd_dim=12, nsoc=8, soc_dim=30)),
+                 ("arrow", lambda: problems.zoo_arrow(n=8000)), ("dense", lambda: problems.zoo_dense(n=200, m=400)),
+                 ("lp", lambda: problems.zoo_lp_transport(60, 500))]:
+    pb = mk()
+    perm, info = _lib.symbolic_analyse(make_oracle(pb).K())
+    out[name] = dict(nsuper=info["nsuper"], nnzL=info["nnzL"], stored=info["nnzL_stored"], levels=info["nlevels"],
+                     upd=info["update_bytes"], perm_ok=sorted(perm.tolist()) == list(range(len(perm))))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_sibling_bundles_only_where_children_are_very_many():
+    """HIPKKT_BUNDLE_KIDS=0 (no bundles) against the default, host-side symbolic analysis only (the knobs are read once
+    per process, hence two child processes).  The BASELINE generators' structures must not move at all; a dense row's
+    singleton columns, the slack leaves under a dense A and a transportation LP's hub variables must end up with fewer
+    supernodes, the same structural nnz(L), no additional level, and -- for the dense A -- a fraction of the update
+    storage (one block per bundle instead of one per leaf)."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("off", {"HIPKKT_BUNDLE_KIDS": "0"}), ("on", {})):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("HIPKKT_BUNDLE")}
+        r = subprocess.run([sys.executable, "-c", _BUNDLE_SCRIPT.format(root=root)], env=dict(e, **env), cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[tag] = json.loads(re.search(r"RESULT (.*)", r.stdout).group(1))
+    for name in ("cfg2", "cfg3", "cfg5"):
+        assert res["on"][name] == res["off"][name], name
+    for name in ("arrow", "dense", "lp"):
+        on, off = res["on"][name], res["off"][name]
+        assert on["perm_ok"] and on["nnzL"] == off["nnzL"], name
+        assert on["nsuper"] < (0.95 if name != "lp" else 1.0) * off["nsuper"], (name, on, off)
+        assert on["levels"] <= off["levels"], (name, on, off)
+    assert res["on"]["dense"]["upd"] < 0.2 * res["off"]["dense"]["upd"], res
